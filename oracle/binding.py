@@ -1,0 +1,204 @@
+"""TEST INFRASTRUCTURE — ctypes binding of the CPU oracle (oracle/liboracle.so) and of the
+reference-derived checkers under oracle/_ref/.  Import only from tests/, smoke() and the
+cpu_baseline leg of bench.py."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+EVAL_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+
+
+class Config(C.Structure):
+    """Layout shared by orc::Config (oracle) and frx_config (include/frx.h)."""
+    _fields_ = [
+        ("rho", C.c_double), ("total_t", C.c_double), ("grid_res", C.c_double),
+        ("qd_intervals", C.c_int), ("c2_diffeo", C.c_int),
+        ("horiz_half_len", C.c_double), ("vert_half_len", C.c_double), ("safe_margin", C.c_double),
+        ("vel_max", C.c_double), ("thr_acc_min", C.c_double), ("thr_acc_max", C.c_double),
+        ("body_rate_max", C.c_double), ("grav_acc", C.c_double),
+        ("penalty_pvtb", C.c_double * 4),
+    ]
+
+    @classmethod
+    def from_params(cls, params: dict, **override):
+        p = dict(params); p.update(override)
+        c = cls()
+        for name, _ in cls._fields_:
+            if name == "penalty_pvtb":
+                c.penalty_pvtb = (C.c_double * 4)(*p["penalty_pvtb"])
+            else:
+                setattr(c, name, p[name])
+        return c
+
+
+def lbfgs_params(mem_size=8, g_epsilon=1e-5, past=0, delta=1e-5, max_iterations=0, max_linesearch=40,
+                 min_step=1e-20, max_step=1e20, f_dec_coeff=1e-4, s_curv_coeff=0.9, xtol=1e-16):
+    return np.array([mem_size, g_epsilon, past, delta, max_iterations, max_linesearch, min_step, max_step,
+                     f_dec_coeff, s_curv_coeff, xtol], dtype=np.float64)
+
+
+_lib = None
+_ref_lbfgs = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so missing — run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(Config), _dp, _dp, C.c_int, _ip, _dp, _ip, _dp]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_dims.argtypes = [C.c_void_p, _ip]
+        L.orc_set_abscissa_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_maps.argtypes = [C.c_void_p, _ip, _ip, _ip]
+        L.orc_initial_guess.argtypes = [C.c_void_p, _dp]
+        L.orc_set_initial.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_objective.restype = C.c_double
+        L.orc_objective.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.orc_backward.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_generate.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_dense_A.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_solve_adj.argtypes = [C.c_void_p, _dp]
+        L.orc_solve.argtypes = [C.c_void_p, _dp]
+        L.orc_jerk_cost.restype = C.c_double
+        L.orc_jerk_cost.argtypes = [C.c_void_p]
+        L.orc_penalty.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.orc_optimize.restype = C.c_int
+        L.orc_optimize.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_int)]
+        L.orc_set_lbfgs.argtypes = [C.c_void_p]
+        L.orc_lbfgs_run.restype = C.c_int
+        L.orc_lbfgs_run.argtypes = [C.c_int, _dp, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, _dp, C.c_int, _dp, _dp, _ip,
+                                    C.POINTER(C.c_int)]
+        L.orc_objective_fnptr.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def ref_lbfgs():
+    """oracle/_ref/libref_lbfgs.so = the reference's own lbfgs.hpp compiled where it lies; None if absent."""
+    global _ref_lbfgs
+    if _ref_lbfgs is None:
+        path = os.path.join(HERE, "_ref", "libref_lbfgs.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_lbfgs_run.restype = C.c_int
+        R.ref_lbfgs_run.argtypes = [C.c_int, _dp, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, _dp, C.c_int, _dp, _dp, _ip,
+                                    C.POINTER(C.c_int)]
+        R.ref_lbfgs_optimize.restype = C.c_int
+        _ref_lbfgs = R
+    return _ref_lbfgs
+
+
+def use_reference_lbfgs(enable: bool) -> bool:
+    """Make the oracle's optimize()/backwardP run on the reference's own L-BFGS (oracle/_ref)."""
+    R = ref_lbfgs() if enable else None
+    if enable and R is None:
+        return False
+    lib().orc_set_lbfgs(C.cast(R.ref_lbfgs_optimize, C.c_void_p) if enable else None)
+    return True
+
+
+class Oracle:
+    """One trajectory problem = SE3GCOPTER after setup() (CPU.hpp:1076-1186)."""
+
+    def __init__(self, cand, params: dict, **override):
+        self.cfg = Config.from_params(params, **override)
+        h_off, h_rec, v_off, v_rec = cand.packed()
+        ini = np.ascontiguousarray(cand.ini_state.T.reshape(-1))   # column-major 3x3
+        fin = np.ascontiguousarray(cand.fin_state.T.reshape(-1))
+        self.h = lib().orc_create(C.byref(self.cfg), ini, fin, cand.coarse_n, h_off, h_rec, v_off, v_rec)
+        if not self.h:
+            raise RuntimeError("oracle setup failed (empty polytope interior)")
+        d = np.zeros(4, dtype=np.int32)
+        lib().orc_dims(self.h, d)
+        self.coarse_n, self.fine_n, self.dim_t, self.dim_p = (int(v) for v in d)
+        self.n = self.dim_t + self.dim_p
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def set_abscissa_mode(self, accumulate: bool):
+        lib().orc_set_abscissa_mode(self.h, int(accumulate))
+
+    def maps(self):
+        iv = np.zeros(self.coarse_n, np.int32); ivs = np.zeros(max(self.fine_n - 1, 1), np.int32); ihs = np.zeros(self.fine_n, np.int32)
+        lib().orc_get_maps(self.h, iv, ivs, ihs)
+        return iv, ivs[: self.fine_n - 1], ihs
+
+    def initial_guess(self):
+        x = np.zeros(self.n)
+        lib().orc_initial_guess(self.h, x)
+        return x
+
+    def set_initial(self):
+        T = np.zeros(self.coarse_n); P = np.zeros(3 * (self.fine_n - 1))
+        lib().orc_set_initial(self.h, T, P)
+        return T, P.reshape(-1, 3)
+
+    def objective(self, x):
+        g = np.zeros(self.n)
+        f = lib().orc_objective(self.h, np.ascontiguousarray(x, dtype=np.float64), g)
+        return f, g
+
+    def forward(self, x):
+        T = np.zeros(self.fine_n); P = np.zeros(3 * (self.fine_n - 1)); Cf = np.zeros(18 * self.fine_n)
+        lib().orc_forward(self.h, np.ascontiguousarray(x, dtype=np.float64), T, P, Cf)
+        return T, P.reshape(-1, 3), Cf.reshape(-1, 3)
+
+    def backward(self, Tcoarse, P):
+        x = np.zeros(self.n)
+        lib().orc_backward(self.h, np.ascontiguousarray(Tcoarse, dtype=np.float64), np.ascontiguousarray(P, dtype=np.float64).reshape(-1), x)
+        return x
+
+    def generate(self, inPs, T):
+        Cf = np.zeros(18 * self.fine_n)
+        lib().orc_generate(self.h, np.ascontiguousarray(inPs, dtype=np.float64).reshape(-1), np.ascontiguousarray(T, dtype=np.float64), Cf)
+        return Cf.reshape(-1, 3)
+
+    def dense_A(self, T):
+        n6 = 6 * self.fine_n
+        A = np.zeros(n6 * n6)
+        lib().orc_dense_A(self.h, np.ascontiguousarray(T, dtype=np.float64), A)
+        return A.reshape(n6, n6)
+
+    def solve_adj(self, rhs):
+        r = np.ascontiguousarray(rhs, dtype=np.float64).reshape(-1).copy()
+        lib().orc_solve_adj(self.h, r)
+        return r.reshape(-1, 3)
+
+    def solve(self, rhs):
+        r = np.ascontiguousarray(rhs, dtype=np.float64).reshape(-1).copy()
+        lib().orc_solve(self.h, r)
+        return r.reshape(-1, 3)
+
+    def jerk_cost(self):
+        return lib().orc_jerk_cost(self.h)
+
+    def penalty(self, T, Cf):
+        """a7 alone: returns (cost, gdT[N], gdC[6N,3]) accumulated from zero."""
+        cost = np.zeros(1); gdT = np.zeros(self.fine_n); gdC = np.zeros(18 * self.fine_n)
+        lib().orc_penalty(self.h, np.ascontiguousarray(T, dtype=np.float64), np.ascontiguousarray(Cf, dtype=np.float64).reshape(-1), cost, gdT, gdC)
+        return float(cost[0]), gdT, gdC.reshape(-1, 3)
+
+    def optimize(self, rel_cost_tol, max_iterations=0, x0=None):
+        x = np.zeros(self.n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        Cf = np.zeros(18 * self.fine_n); T = np.zeros(self.fine_n)
+        jc = C.c_double(); fo = C.c_double(); ne = C.c_long(); ni = C.c_int()
+        ret = lib().orc_optimize(self.h, rel_cost_tol, max_iterations, x, int(x0 is not None), Cf, T, C.byref(jc), C.byref(fo),
+                                 C.byref(ne), C.byref(ni))
+        return dict(status=ret, x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc.value, objective=fo.value, evals=ne.value, iters=ni.value)
