@@ -1,0 +1,209 @@
+"""fast-racing_amd — MI355X-native back-end for Fast-Racing's SE(3) MINCO trajectory optimiser.
+
+Python here is plumbing only: a ctypes mirror of the C ABI in include/frx.h (the drop-in
+boundary) plus the synthetic scenario generator.  All arithmetic of the hot path runs in
+libfrx.so (HIP kernels for gfx950 + the host L-BFGS driver); there is no Python or CPU fallback,
+and importing this package fails loudly when the library has not been built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scenario  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfrx.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class FrxConfig(C.Structure):
+    """struct frx_config (include/frx.h) = scalar arguments of SE3GCOPTER::setup (CPU.hpp:1076-1092)."""
+    _fields_ = [
+        ("rho", C.c_double), ("total_t", C.c_double), ("grid_res", C.c_double),
+        ("qd_intervals", C.c_int), ("c2_diffeo", C.c_int),
+        ("horiz_half_len", C.c_double), ("vert_half_len", C.c_double), ("safe_margin", C.c_double),
+        ("vel_max", C.c_double), ("thr_acc_min", C.c_double), ("thr_acc_max", C.c_double),
+        ("body_rate_max", C.c_double), ("grav_acc", C.c_double),
+        ("penalty_pvtb", C.c_double * 4),
+    ]
+
+    @classmethod
+    def from_params(cls, params: dict, **override):
+        p = dict(params); p.update(override)
+        c = cls()
+        for name, _ in cls._fields_:
+            if name == "penalty_pvtb":
+                c.penalty_pvtb = (C.c_double * 4)(*p["penalty_pvtb"])
+            else:
+                setattr(c, name, p[name])
+        return c
+
+
+class LbfgsParams(C.Structure):
+    """struct frx_lbfgs_params = lbfgs::lbfgs_parameter_t (lbfgs.hpp:18-140)."""
+    _fields_ = [
+        ("mem_size", C.c_int), ("g_epsilon", C.c_double), ("past", C.c_int), ("delta", C.c_double),
+        ("max_iterations", C.c_int), ("max_linesearch", C.c_int), ("min_step", C.c_double), ("max_step", C.c_double),
+        ("f_dec_coeff", C.c_double), ("s_curv_coeff", C.c_double), ("xtol", C.c_double),
+    ]
+
+
+BATCH_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                            C.POINTER(C.c_double))
+
+# every symbol include/frx.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params", "frx_lbfgs_gcopter_params",
+    "frx_problem_create", "frx_problem_destroy", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
+    "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
+    "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libfrx.so (built in-tree by __graft_entry__.build() / make -C fast-racing_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                               "There is no fallback implementation.")
+        L = C.CDLL(LIB_PATH)
+        L.frx_version.restype = C.c_int
+        L.frx_last_error.restype = C.c_char_p
+        L.frx_device_count.restype = C.c_int
+        L.frx_lbfgs_default_params.argtypes = [C.POINTER(LbfgsParams)]
+        L.frx_lbfgs_gcopter_params.argtypes = [C.POINTER(LbfgsParams), C.c_double]
+        L.frx_problem_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
+        L.frx_problem_destroy.argtypes = [C.c_void_p]
+        L.frx_problem_totals.argtypes = [C.c_void_p, _ip]
+        L.frx_problem_layout.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip]
+        L.frx_initial_guess.argtypes = [C.c_void_p, _dp]
+        L.frx_objective_eval.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.frx_objective_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.frx_penalty_eval.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.frx_penalty_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.frx_forward.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.frx_optimize.argtypes = [C.c_void_p, C.POINTER(LbfgsParams), _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+        L.frx_optimize_stats.argtypes = [C.c_void_p, _dp]
+        L.frx_lbfgs_minimize_batch.argtypes = [C.c_int, _ip, _dp, _dp, _ip, _ip, _ip, C.POINTER(LbfgsParams), BATCH_EVAL_FN,
+                                               C.c_void_p, C.c_int]
+        for name in ABI_SYMBOLS:
+            fn = getattr(L, name)
+            if name not in ("frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params",
+                            "frx_lbfgs_gcopter_params", "frx_problem_destroy"):
+                fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class FrxError(RuntimeError):
+    pass
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise FrxError(f"frx error {rc}: {lib().frx_last_error().decode()}")
+
+
+def gcopter_lbfgs_params(rel_cost_tol: float, max_iterations: int = 0) -> LbfgsParams:
+    p = LbfgsParams()
+    lib().frx_lbfgs_gcopter_params(C.byref(p), rel_cost_tol)
+    p.max_iterations = max_iterations
+    return p
+
+
+def pack_batch(cands):
+    """Pack a list of scenario.Candidate into the CSR arrays of frx_problem_create."""
+    coarse_n = np.array([c.coarse_n for c in cands], dtype=np.int32)
+    ini = np.concatenate([c.ini_state.T.reshape(-1) for c in cands]).astype(np.float64)
+    fin = np.concatenate([c.fin_state.T.reshape(-1) for c in cands]).astype(np.float64)
+    h_off = [0]; v_off = [0]; h_rec = []; v_rec = []
+    for c in cands:
+        for h in c.h_polys:
+            h_off.append(h_off[-1] + h.shape[1]); h_rec.append(h.T.reshape(-1))
+        for v in c.v_polys:
+            v_off.append(v_off[-1] + v.shape[1]); v_rec.append(v.T.reshape(-1))
+    return (coarse_n, ini, fin, np.array(h_off, dtype=np.int32), np.concatenate(h_rec).astype(np.float64),
+            np.array(v_off, dtype=np.int32), np.concatenate(v_rec).astype(np.float64))
+
+
+class Problem:
+    """A batch of candidate trajectories resident on one MI355X: the SE3GCOPTER::setup / optimize
+    pair (CPU.hpp:1076, :1230) behind the C ABI."""
+
+    def __init__(self, cands, params: dict, device: int = 0, **override):
+        self.cfg = FrxConfig.from_params(params, **override)
+        self.kappa = int(self.cfg.qd_intervals)
+        coarse_n, ini, fin, h_off, h_rec, v_off, v_rec = pack_batch(cands)
+        h = C.c_void_p()
+        _check(lib().frx_problem_create(C.byref(self.cfg), device, len(cands), coarse_n, ini, fin, h_off, h_rec, v_off, v_rec,
+                                        C.byref(h)))
+        self.h = h
+        t = np.zeros(6, dtype=np.int32)
+        _check(lib().frx_problem_totals(self.h, t))
+        self.B, self.P, self.Pc, self.NX, self.Kmax, self.sum_K = (int(v) for v in t)
+        self.piece_off = np.zeros(self.B + 1, np.int32); self.coarse_off = np.zeros(self.B + 1, np.int32)
+        self.x_off = np.zeros(self.B + 1, np.int32); self.dim_t = np.zeros(self.B, np.int32)
+        _check(lib().frx_problem_layout(self.h, self.piece_off, self.coarse_off, self.x_off, self.dim_t))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().frx_problem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def initial_guess(self):
+        x = np.zeros(self.NX)
+        _check(lib().frx_initial_guess(self.h, x))
+        return x
+
+    def objective(self, x):
+        f = np.zeros(self.B); g = np.zeros(self.NX)
+        _check(lib().frx_objective_eval(self.h, np.ascontiguousarray(x, dtype=np.float64), f, g))
+        return f, g
+
+    def objective_device(self, x_ptr: int, f_ptr: int, g_ptr: int, stream: int = 0):
+        _check(lib().frx_objective_eval_device(self.h, x_ptr, f_ptr, g_ptr, stream))
+
+    def penalty(self, T, Cf):
+        cost = np.zeros(self.B); gdT = np.zeros(self.P); gdC = np.zeros(self.P * 18)
+        _check(lib().frx_penalty_eval(self.h, np.ascontiguousarray(T, dtype=np.float64),
+                                      np.ascontiguousarray(Cf, dtype=np.float64).reshape(-1), cost, gdT, gdC))
+        return cost, gdT, gdC.reshape(-1, 3)
+
+    def penalty_device(self, T_ptr: int, C_ptr: int, out_ptr: int, stream: int = 0):
+        _check(lib().frx_penalty_eval_device(self.h, T_ptr, C_ptr, out_ptr, stream))
+
+    def forward(self, x):
+        T = np.zeros(self.P); Cf = np.zeros(self.P * 18)
+        _check(lib().frx_forward(self.h, np.ascontiguousarray(x, dtype=np.float64), T, Cf))
+        return T, Cf.reshape(-1, 3)
+
+    def optimize(self, rel_cost_tol: float, x0=None, max_iterations: int = 0):
+        x = self.initial_guess() if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        pm = gcopter_lbfgs_params(rel_cost_tol, max_iterations)
+        Cf = np.zeros(self.P * 18); T = np.zeros(self.P)
+        jc = np.zeros(self.B); obj = np.zeros(self.B)
+        st = np.zeros(self.B, np.int32); it = np.zeros(self.B, np.int32); ev = np.zeros(self.B, np.int32)
+        _check(lib().frx_optimize(self.h, C.byref(pm), x, Cf, T, jc, obj, st, it, ev))
+        stats = np.zeros(4)
+        _check(lib().frx_optimize_stats(self.h, stats))
+        return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
+                    ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]))
+
+    def algorithmic_bytes(self) -> int:
+        """Penalty-kernel bytes per evaluation, SURVEY.md §8d: sum over pieces of 312 + 48 K_i."""
+        return 312 * self.P + 48 * self.sum_K
+
+    def samples(self) -> int:
+        """constraint samples per evaluation: pieces x (kappa + 1)."""
+        return self.P * (self.kappa + 1)

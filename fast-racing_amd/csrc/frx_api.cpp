@@ -1,0 +1,634 @@
+// C ABI (include/frx.h) of the MI355X back-end: problem set-up, batched device evaluation,
+// batched host L-BFGS driver.  Host-only translation unit (g++); the kernels live in
+// frx_device.hip.  No CPU fallback: without a HIP device create() fails.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/frx.h"
+#include "frx_device.hpp"
+#include "frx_lbfgs.hpp"
+
+namespace {
+
+thread_local std::string g_err = "";
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(FRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+// ---- a tiny spinning parallel-for (one evaluation round is ~100 us: no condvars) ----
+class SpinPool {
+public:
+    explicit SpinPool(int nthreads) : n_(std::max(1, nthreads)) {
+        for (int t = 1; t < n_; t++) workers_.emplace_back([this] { loop(); });
+    }
+    ~SpinPool() {
+        stop_.store(true, std::memory_order_release);
+        for (auto &w : workers_) w.join();
+    }
+    template <class F> void run(int count, F &&fn) {
+        if (count <= 0) return;
+        if (n_ == 1 || count == 1) { for (int i = 0; i < count; i++) fn(i); return; }
+        fn_ = [&fn](int i) { fn(i); };
+        count_ = count;
+        next_.store(0, std::memory_order_relaxed);
+        pending_.store(count, std::memory_order_relaxed);
+        epoch_.fetch_add(1, std::memory_order_release);
+        drain();
+        while (pending_.load(std::memory_order_acquire) > 0) cpu_relax();
+    }
+private:
+    static void cpu_relax() { __builtin_ia32_pause(); }
+    void drain() {
+        for (;;) {
+            int i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= count_) break;
+            fn_(i);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    void loop() {
+        unsigned seen = 0;
+        int idle = 0;
+        while (!stop_.load(std::memory_order_acquire)) {
+            unsigned e = epoch_.load(std::memory_order_acquire);
+            if (e != seen) { seen = e; drain(); idle = 0; }
+            else if (++idle > 2000) { std::this_thread::yield(); }
+            else cpu_relax();
+        }
+    }
+    int n_;
+    std::vector<std::thread> workers_;
+    std::function<void(int)> fn_;
+    int count_ = 0;
+    std::atomic<int> next_{0}, pending_{0};
+    std::atomic<unsigned> epoch_{0};
+    std::atomic<bool> stop_{false};
+};
+
+// ---- per-candidate host description (what setup() keeps for the initial guess) ----
+struct HostCand {
+    int coarseN = 0, fineN = 0, dimT = 0, dimP = 0;
+    double iState[9], fState[9];                 // clipped copies (CPU.hpp:1166-1170)
+    std::vector<std::vector<double>> cfgVs;      // [v0, v_r - v0] (CPU.hpp:1049)
+    std::vector<int> intervals, idxVs;
+};
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+template <class T> struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t alloc(size_t count) {
+        n = count;
+        hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) std::memset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        return e;
+    }
+};
+
+} // namespace
+
+struct frx_problem {
+    frx_config cfg;
+    int device = 0, B = 0, P = 0, Pc = 0, NX = 0, Kmax = 0, maxN = 0, maxCN = 0, sumKfine = 0;
+    bool softT = true;
+    std::vector<HostCand> cand;
+    std::vector<int> poff, coff, xoff, boff, dimT;
+    frx::DevProblem dp;
+    hipStream_t stream = nullptr;
+    // device-resident constants
+    DevBuf<int> d_poff, d_coff, d_xoff, d_boff, d_piece_hbeg, d_piece_K, d_piece_coarse, d_coarse_iv, d_coarse_fbeg, d_wp_vbeg,
+        d_wp_nv, d_wp_xbeg;
+    DevBuf<double> d_head, d_tail, d_hrec, d_vrec;
+    // device work space
+    DevBuf<double> d_x, d_f, d_g, d_T, d_C, d_band, d_out20;
+    // pinned staging
+    PinBuf<double> h_x, h_f, h_g, h_T, h_C, h_out20;
+    frx::LaunchGeom geo;
+    double stats[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+// objectiveNLS (CPU.hpp:749-774): squared distance between a target point and the image of the
+// sphere parameterisation of one V-polytope; pobs = [target, v0, edges...]
+double nls_objective(const double *pobs, const double *x, double *grad, int n, std::vector<double> &r, std::vector<double> &gdr) {
+    double qn = 0.0;
+    for (int a = 0; a < n; a++) qn += x[a] * x[a];
+    const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;
+    r.resize(n); gdr.resize(n);
+    for (int a = 0; a < n; a++) r[a] = sc * x[a];
+    double delta[3];
+    for (int q = 0; q < 3; q++) {
+        double s = 0.0;
+        for (int a = 0; a < n; a++) s += pobs[3 * (a + 2) + q] * (r[a] * r[a]);
+        delta[q] = s + pobs[3 + q] - pobs[q];
+    }
+    const double cost = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2];
+    const double g3[3] = {2 * delta[0], 2 * delta[1], 2 * delta[2]};
+    for (int a = 0; a < n; a++)
+        gdr[a] = (pobs[3 * (a + 2)] * g3[0] + pobs[3 * (a + 2) + 1] * g3[1] + pobs[3 * (a + 2) + 2] * g3[2]) * r[a] * 2.0;
+    double gq = 0.0;
+    for (int a = 0; a < n; a++) gq += gdr[a] * x[a];
+    for (int a = 0; a < n; a++) grad[a] = gdr[a] * 2.0 / qp1 - x[a] * 4.0 * gq / qp1sq;
+    return cost;
+}
+
+void poly_centre(const std::vector<double> &V, double *c) {     // CPU.hpp:1018-1019 / 1206-1207
+    const int k = (int)(V.size() / 3) - 1;
+    for (int r = 0; r < 3; r++) {
+        double s = 0.0;
+        for (int a = 0; a < k; a++) s += V[3 * (a + 1) + r];
+        c[r] = s / (1.0 + k) + V[r];
+    }
+}
+double dist3(const double *a, const double *b) {
+    return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+}
+
+// setInitial + backwardT + backwardP for one candidate (CPU.hpp:1188-1228, 679-726, 777-813)
+void initial_guess_one(const frx_problem &P, const HostCand &hc, double *x) {
+    const double vAlloc = std::min(P.cfg.vel_max, 10.0);                 // maxSpeedForAllocatiion, CPU.hpp:1193
+    const int M = hc.coarseN;
+    std::vector<double> vecT(M), inP(3 * (size_t)std::max(hc.fineN - 1, 0));
+    double lastP[3], curP[3] = {hc.iState[0], hc.iState[1], hc.iState[2]}, delta[3];
+    int offset = 0;
+    for (int i = 0; i < M; i++) {
+        std::memcpy(lastP, curP, sizeof(curP));
+        const int interv = hc.intervals[i];
+        if (i < M - 1) poly_centre(hc.cfgVs[2 * i + 1], curP);
+        else { curP[0] = hc.fState[0]; curP[1] = hc.fState[1]; curP[2] = hc.fState[2]; }
+        for (int r = 0; r < 3; r++) delta[r] = curP[r] - lastP[r];
+        vecT[i] = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]) / vAlloc;
+        for (int r = 0; r < 3; r++) delta[r] /= interv;
+        const int cnt = (i < M - 1) ? interv : interv - 1;
+        for (int j = 0; j < cnt; j++) {
+            for (int r = 0; r < 3; r++) inP[offset * 3 + r] = (j + 1) * delta[r] + lastP[r];
+            offset++;
+        }
+    }
+    // backwardT
+    const bool c2 = P.cfg.c2_diffeo != 0;
+    if (P.softT) {
+        for (int i = 0; i < M; i++)
+            x[i] = c2 ? (vecT[i] > 1.0 ? (std::sqrt(2.0 * vecT[i] - 1.0) - 1.0) : (1.0 - std::sqrt(2.0 / vecT[i] - 1.0)))
+                      : std::log(vecT[i]);
+    } else {
+        for (int i = 0; i < M - 1; i++) {
+            const double r = vecT[i] / vecT[M - 1];
+            x[i] = c2 ? (r > 1.0 ? (std::sqrt(2.0 * r - 1.0) - 1.0) : (1.0 - std::sqrt(2.0 / r - 1.0))) : std::log(r);
+        }
+    }
+    // backwardP: one tiny L-BFGS per waypoint (default parameters, g_epsilon = FLT_EPSILON, 128 iterations)
+    frx_lbfgs_params nls;
+    frx::lbfgs_defaults(nls);
+    nls.g_epsilon = FLT_EPSILON;
+    nls.max_iterations = 128;
+    double *p = x + hc.dimT;
+    int j = 0;
+    std::vector<double> pobs, grad, r, gdr;
+    for (int i = 0; i < hc.fineN - 1; i++) {
+        const std::vector<double> &V = hc.cfgVs[hc.idxVs[i]];
+        const int k = (int)(V.size() / 3) - 1;
+        for (int a = 0; a < k; a++) p[j + a] = 1.0 / (std::sqrt(k + 1.0) + 1.0);
+        pobs.resize(3 * (size_t)(k + 2));
+        for (int q = 0; q < 3; q++) pobs[q] = inP[i * 3 + q];
+        std::memcpy(&pobs[3], V.data(), sizeof(double) * 3 * (k + 1));
+        grad.assign(k, 0.0);
+        frx::Solver s;
+        s.start(k, p + j, grad.data(), nls);
+        while (!s.done()) s.feed(nls_objective(pobs.data(), p + j, grad.data(), k, r, gdr));
+        j += k;
+    }
+}
+
+int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *st, bool backward) {
+    int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
+    if (e || !backward) return e;
+    if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
+    return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st);
+}
+
+} // namespace
+
+extern "C" {
+
+int frx_version(void) { return FRX_VERSION; }
+const char *frx_last_error(void) { return g_err.c_str(); }
+int frx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+void frx_lbfgs_default_params(frx_lbfgs_params *p) { if (p) frx::lbfgs_defaults(*p); }
+void frx_lbfgs_gcopter_params(frx_lbfgs_params *p, double rel_cost_tol) {
+    if (!p) return;
+    frx::lbfgs_defaults(*p);
+    p->mem_size = 128; p->past = 3; p->g_epsilon = 1.0e-16; p->min_step = 1.0e-32; p->delta = rel_cost_tol;
+}
+
+int frx_problem_create(const frx_config *cfg, int device, int B, const int *coarse_n, const double *ini_state,
+                       const double *fin_state, const int *h_off, const double *h_rec, const int *v_off, const double *v_rec,
+                       frx_problem **out) {
+    if (!cfg || !coarse_n || !ini_state || !fin_state || !h_off || !h_rec || !v_off || !v_rec || !out || B <= 0)
+        return fail(FRX_ERR_INVALID_ARG, "frx_problem_create: null argument or B <= 0");
+    if (cfg->qd_intervals < 1) return fail(FRX_ERR_INVALID_ARG, "qd_intervals must be >= 1");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FRX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(FRX_ERR_INVALID_ARG, "device ordinal out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(FRX_ERR_NO_DEVICE, "hipSetDevice failed");
+
+    frx_problem *p = new (std::nothrow) frx_problem();
+    if (!p) return fail(FRX_ERR_ALLOC, "out of host memory");
+    p->cfg = *cfg;
+    p->device = device;
+    p->B = B;
+    p->softT = cfg->rho > 0;                                             // CPU.hpp:1097
+    p->cand.resize(B);
+    p->poff.assign(B + 1, 0); p->coff.assign(B + 1, 0); p->xoff.assign(B + 1, 0); p->boff.assign(B + 1, 0);
+    p->dimT.assign(B, 0);
+
+    std::vector<int> piece_hbeg, piece_K, piece_coarse, coarse_iv, coarse_fbeg, wp_vbeg, wp_nv, wp_xbeg;
+    std::vector<double> hrec, vrec, head(ini_state, ini_state + 9 * (size_t)B), tail(fin_state, fin_state + 9 * (size_t)B);
+    int hpoly = 0, vpoly = 0;                     // running polytope indices into h_off / v_off
+    for (int b = 0; b < B; b++) {
+        HostCand &hc = p->cand[b];
+        const int cN = coarse_n[b];
+        if (cN < 1) { delete p; return fail(FRX_ERR_INVALID_ARG, "coarse_n[b] < 1"); }
+        hc.coarseN = cN;
+        std::memcpy(hc.iState, ini_state + 9 * (size_t)b, sizeof(hc.iState));
+        std::memcpy(hc.fState, fin_state + 9 * (size_t)b, sizeof(hc.fState));
+        // V-polytopes: [v0, v_r - v0]
+        hc.cfgVs.resize(2 * cN - 1);
+        std::vector<int> vbeg(2 * cN - 1);
+        for (int m = 0; m < 2 * cN - 1; m++) {
+            const int beg = v_off[vpoly + m], nv = v_off[vpoly + m + 1] - beg;
+            if (nv < 1) { delete p; return fail(FRX_ERR_EMPTY_POLYTOPE, "a corridor polytope has no vertices"); }
+            hc.cfgVs[m].resize(3 * (size_t)nv);
+            const double *v = v_rec + 3 * (size_t)beg;
+            for (int r = 0; r < 3; r++) hc.cfgVs[m][r] = v[r];
+            for (int a = 1; a < nv; a++)
+                for (int r = 0; r < 3; r++) hc.cfgVs[m][3 * a + r] = v[3 * a + r] - v[r];
+            vbeg[m] = (int)(vrec.size() / 3);
+            vrec.insert(vrec.end(), hc.cfgVs[m].begin(), hc.cfgVs[m].end());
+        }
+        // gridMesh (CPU.hpp:1003-1029)
+        hc.intervals.assign(cN, 1);
+        {
+            double lastP[3], curP[3] = {hc.iState[0], hc.iState[1], hc.iState[2]};
+            for (int i = 0; i < cN; i++) {
+                std::memcpy(lastP, curP, sizeof(curP));
+                if (i < cN - 1) poly_centre(hc.cfgVs[2 * i + 1], curP);
+                else { curP[0] = hc.fState[0]; curP[1] = hc.fState[1]; curP[2] = hc.fState[2]; }
+                const int cur = (int)std::ceil(dist3(curP, lastP) / cfg->grid_res);
+                hc.intervals[i] = cur > 0 ? cur : 1;
+            }
+        }
+        hc.fineN = 0;
+        for (int i = 0; i < cN; i++) hc.fineN += hc.intervals[i];
+        hc.dimT = p->softT ? cN : cN - 1;                               // CPU.hpp:1131
+        // index maps (CPU.hpp:1129-1152), expanded into per-piece / per-waypoint device descriptors
+        hc.idxVs.assign(std::max(hc.fineN - 1, 0), 0);
+        hc.dimP = 0;
+        const int gp0 = p->poff[b], gc0 = p->coff[b];
+        int offset = 0;
+        int xcur = p->xoff[b] + hc.dimT;
+        for (int i = 0; i < cN; i++) {
+            const int hb = h_off[hpoly + i], K = h_off[hpoly + i + 1] - hb;
+            if (K < 1) { delete p; return fail(FRX_ERR_INVALID_ARG, "an H-polytope has no half-spaces"); }
+            const int hbeg_dev = (int)(hrec.size() / 6);
+            for (int k = 0; k < K; k++) {                                // normalise outer normals, CPU.hpp:1116
+                const double *rec = h_rec + 6 * (size_t)(hb + k);
+                const double nn = std::sqrt(rec[0] * rec[0] + rec[1] * rec[1] + rec[2] * rec[2]);
+                hrec.push_back(rec[0] / nn); hrec.push_back(rec[1] / nn); hrec.push_back(rec[2] / nn);
+                hrec.push_back(rec[3]); hrec.push_back(rec[4]); hrec.push_back(rec[5]);
+            }
+            p->Kmax = std::max(p->Kmax, K);
+            coarse_iv.push_back(hc.intervals[i]);
+            coarse_fbeg.push_back(gp0 + offset);
+            for (int j = 0; j < hc.intervals[i]; j++) {
+                int vm = -1;
+                if (j < hc.intervals[i] - 1) vm = 2 * i;
+                else if (i < cN - 1) vm = 2 * i + 1;
+                if (vm >= 0) {
+                    hc.idxVs[offset] = vm;
+                    const int nv = (int)(hc.cfgVs[vm].size() / 3);
+                    hc.dimP += nv - 1;
+                    wp_vbeg.push_back(vbeg[vm]); wp_nv.push_back(nv); wp_xbeg.push_back(xcur);
+                    xcur += nv - 1;
+                }
+                piece_hbeg.push_back(hbeg_dev); piece_K.push_back(K); piece_coarse.push_back(gc0 + i);
+                p->sumKfine += K;
+                offset++;
+            }
+        }
+        // legal boundary speed on the copies only (CPU.hpp:1166-1170)
+        for (double *st : {hc.iState, hc.fState}) {
+            const double tn = std::sqrt(st[3] * st[3] + st[4] * st[4] + st[5] * st[5]);
+            const double sc = tn > cfg->vel_max ? (cfg->vel_max / tn) : 1.0;
+            for (int r = 0; r < 3; r++) st[3 + r] *= sc;
+        }
+        hpoly += cN;
+        vpoly += 2 * cN - 1;
+        p->dimT[b] = hc.dimT;
+        p->poff[b + 1] = gp0 + hc.fineN;
+        p->coff[b + 1] = gc0 + cN;
+        p->xoff[b + 1] = p->xoff[b] + hc.dimT + hc.dimP;
+        p->boff[b + 1] = p->boff[b] + 6 * hc.fineN * FRX_BAND_W;
+        p->maxN = std::max(p->maxN, hc.fineN);
+        p->maxCN = std::max(p->maxCN, cN);
+    }
+    p->P = p->poff[B]; p->Pc = p->coff[B]; p->NX = p->xoff[B];
+
+    // launch geometry + LDS budgets
+    const int spp = cfg->qd_intervals + 1;
+    frx::LaunchGeom &ge = p->geo;
+    ge.maxN = p->maxN; ge.maxCN = p->maxCN; ge.Kmax = p->Kmax;
+    ge.lpp = std::min(spp, 64);
+    ge.ppw = 64 / ge.lpp;
+    const int ppb = 4 * ge.ppw;
+    ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
+    ge.lds_bwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 6) + 2 * (size_t)p->maxN + p->maxCN);
+    ge.lds_pen = sizeof(double) * ((size_t)ppb * 19 + (size_t)ppb * p->Kmax * 6 + 4 * 64 * 21);
+    const size_t lds_cap = 160 * 1024;
+    if (ge.lds_bwd > lds_cap || ge.lds_fwd > lds_cap || ge.lds_pen > lds_cap) {
+        delete p;
+        return fail(FRX_ERR_CAPACITY, "piece count / half-space count too large for the LDS-resident kernels (160 KiB per CU)");
+    }
+
+#define CR(expr)                                                                                        \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            delete p;                                                                                   \
+            return fail(FRX_ERR_NO_DEVICE, m_);                                                         \
+        }                                                                                               \
+    } while (0)
+    CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    CR((hipError_t)frx::launch_set_limits(p->geo));
+    CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
+    CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse));
+    CR(p->d_coarse_iv.upload(coarse_iv)); CR(p->d_coarse_fbeg.upload(coarse_fbeg));
+    CR(p->d_wp_vbeg.upload(wp_vbeg)); CR(p->d_wp_nv.upload(wp_nv)); CR(p->d_wp_xbeg.upload(wp_xbeg));
+    CR(p->d_head.upload(head)); CR(p->d_tail.upload(tail)); CR(p->d_hrec.upload(hrec)); CR(p->d_vrec.upload(vrec));
+    CR(p->d_x.alloc(p->NX)); CR(p->d_f.alloc(B)); CR(p->d_g.alloc(p->NX));
+    CR(p->d_T.alloc(p->P)); CR(p->d_C.alloc((size_t)p->P * 18)); CR(p->d_band.alloc(p->boff[B])); CR(p->d_out20.alloc((size_t)p->P * 20));
+    CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
+    CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
+#undef CR
+
+    frx::DevProblem &d = p->dp;
+    d.B = B; d.P = p->P; d.kappa = cfg->qd_intervals; d.soft = p->softT ? 1 : 0; d.c2 = cfg->c2_diffeo ? 1 : 0;
+    d.rho = p->softT ? cfg->rho : 0.0;                                   // CPU.hpp:1098-1107
+    d.sumT = p->softT ? 1.0 : cfg->total_t;
+    d.pc.ell[0] = cfg->horiz_half_len; d.pc.ell[1] = cfg->horiz_half_len; d.pc.ell[2] = cfg->vert_half_len;
+    d.pc.safeMargin = cfg->safe_margin;
+    d.pc.vMaxSqr = cfg->vel_max * cfg->vel_max;
+    d.pc.thrMinSqr = cfg->thr_acc_min * cfg->thr_acc_min;
+    d.pc.thrMaxSqr = cfg->thr_acc_max * cfg->thr_acc_max;
+    d.pc.bdrMaxSqr = cfg->body_rate_max * cfg->body_rate_max;
+    d.pc.gAcc = cfg->grav_acc;
+    for (int q = 0; q < 4; q++) d.pc.chi[q] = cfg->penalty_pvtb[q];
+    d.poff = p->d_poff.p; d.coff = p->d_coff.p; d.xoff = p->d_xoff.p; d.boff = p->d_boff.p;
+    d.headPVA = p->d_head.p; d.tailPVA = p->d_tail.p;
+    d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p;
+    d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
+    d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
+    d.hrec = p->d_hrec.p; d.vrec = p->d_vrec.p;
+    *out = p;
+    return FRX_OK;
+}
+
+void frx_problem_destroy(frx_problem *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    delete p;
+}
+
+int frx_problem_totals(const frx_problem *p, int *out6) {
+    if (!p || !out6) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    out6[0] = p->B; out6[1] = p->P; out6[2] = p->Pc; out6[3] = p->NX; out6[4] = p->Kmax; out6[5] = p->sumKfine;
+    return FRX_OK;
+}
+int frx_problem_layout(const frx_problem *p, int *piece_off, int *coarse_off, int *x_off, int *dim_t) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (piece_off) std::copy(p->poff.begin(), p->poff.end(), piece_off);
+    if (coarse_off) std::copy(p->coff.begin(), p->coff.end(), coarse_off);
+    if (x_off) std::copy(p->xoff.begin(), p->xoff.end(), x_off);
+    if (dim_t) std::copy(p->dimT.begin(), p->dimT.end(), dim_t);
+    return FRX_OK;
+}
+
+int frx_initial_guess(frx_problem *p, double *x0) {
+    if (!p || !x0) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    const int nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)p->B));
+    SpinPool pool(nt);
+    pool.run(p->B, [&](int b) { initial_guess_one(*p, p->cand[b], x0 + p->xoff[b]); });
+    return FRX_OK;
+}
+
+int frx_objective_eval_device(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *hip_stream) {
+    if (!p || !x_dev || !f_dev || !g_dev) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY((hipError_t)launch_eval(p, x_dev, f_dev, g_dev, hip_stream, true));
+    return FRX_OK;
+}
+
+int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g) {
+    if (!p || !x || !f || !g) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+    HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
+    HIP_TRY(hipMemcpyAsync(p->h_f.p, p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_g.p, p->d_g.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::memcpy(f, p->h_f.p, sizeof(double) * p->B);
+    std::memcpy(g, p->h_g.p, sizeof(double) * p->NX);
+    return FRX_OK;
+}
+
+int frx_penalty_eval_device(frx_problem *p, const double *T_dev, const double *C_dev, double *out_dev, void *hip_stream) {
+    if (!p || !T_dev || !C_dev || !out_dev) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY((hipError_t)frx::launch_penalty(p->dp, p->geo, T_dev, C_dev, out_dev, hip_stream));
+    return FRX_OK;
+}
+
+int frx_penalty_eval(frx_problem *p, const double *T, const double *C, double *cost, double *gdT, double *gdC) {
+    if (!p || !T || !C || !cost || !gdT || !gdC) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    std::memcpy(p->h_T.p, T, sizeof(double) * p->P);
+    std::memcpy(p->h_C.p, C, sizeof(double) * 18 * (size_t)p->P);
+    HIP_TRY(hipMemcpyAsync(p->d_T.p, p->h_T.p, sizeof(double) * p->P, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_C.p, p->h_C.p, sizeof(double) * 18 * (size_t)p->P, hipMemcpyHostToDevice, p->stream));
+    int rc = frx_penalty_eval_device(p, p->d_T.p, p->d_C.p, p->d_out20.p, p->stream);
+    if (rc != FRX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(p->h_out20.p, p->d_out20.p, sizeof(double) * 20 * (size_t)p->P, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    // accumulate, like cuda_computer::compute (cc.cu:549-559)
+    for (int b = 0; b < p->B; b++) {
+        double s = 0.0;
+        for (int gp = p->poff[b]; gp < p->poff[b + 1]; gp++) {
+            const double *o = p->h_out20.p + 20 * (size_t)gp;
+            s += o[0];
+            gdT[gp] += o[1];
+            for (int v = 0; v < 18; v++) gdC[18 * (size_t)gp + v] += o[2 + v];
+        }
+        cost[b] += s;
+    }
+    return FRX_OK;
+}
+
+int frx_forward(frx_problem *p, const double *x, double *T, double *C) {
+    if (!p || !x) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+    HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, nullptr, nullptr, p->stream, false));
+    HIP_TRY(hipMemcpyAsync(p->h_T.p, p->d_T.p, sizeof(double) * p->P, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_C.p, p->d_C.p, sizeof(double) * 18 * (size_t)p->P, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (T) std::memcpy(T, p->h_T.p, sizeof(double) * p->P);
+    if (C) std::memcpy(C, p->h_C.p, sizeof(double) * 18 * (size_t)p->P);
+    return FRX_OK;
+}
+
+} // extern "C"
+
+// The batched driver shared by frx_optimize (device evaluator) and frx_lbfgs_minimize_batch (callback evaluator).
+template <class EvalAll>
+static int drive_batch(int count, const int *x_off, double *x, double *g, double *f, const frx_lbfgs_params &pm, int n_threads,
+                       int *status, int *iters, int *evals, double *f_out, double *stats, EvalAll &&eval_all) {
+    std::vector<frx::Solver> sv(count);
+    for (int i = 0; i < count; i++) sv[i].start(x_off[i + 1] - x_off[i], x + x_off[i], g + x_off[i], pm);
+    SpinPool pool(n_threads);
+    std::vector<int> active;
+    active.reserve(count);
+    double t_eval = 0.0, t_host = 0.0;
+    long rounds = 0;
+    const auto t0 = clk::now();
+    for (;;) {
+        active.clear();
+        for (int i = 0; i < count; i++)
+            if (!sv[i].done()) active.push_back(i);
+        if (active.empty()) break;
+        auto te = clk::now();
+        int rc = eval_all((int)active.size(), active.data());
+        if (rc != FRX_OK) return rc;
+        t_eval += ms_since(te);
+        auto th = clk::now();
+        pool.run((int)active.size(), [&](int a) { const int i = active[a]; sv[i].feed(f[i]); });
+        t_host += ms_since(th);
+        rounds++;
+    }
+    if (stats) { stats[0] = ms_since(t0); stats[1] = t_eval; stats[2] = t_host; stats[3] = (double)rounds; }
+    for (int i = 0; i < count; i++) {
+        if (status) status[i] = sv[i].status();
+        if (iters) iters[i] = sv[i].iterations();
+        if (evals) evals[i] = sv[i].evaluations();
+        if (f_out) f_out[i] = sv[i].value();
+    }
+    return FRX_OK;
+}
+
+extern "C" {
+
+int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, double *C, double *T, double *jerk_cost,
+                 double *objective, int *status, int *iters, int *evals) {
+    if (!p || !params || !x || !status) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+    const int nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)p->B));
+    int hip_rc = FRX_OK;
+    auto eval_all = [&](int, const int *) -> int {
+        hipError_t e;
+        if ((e = hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream)) != hipSuccess) goto bad;
+        if ((e = (hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true)) != hipSuccess) goto bad;
+        if ((e = hipMemcpyAsync(p->h_f.p, p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;
+        if ((e = hipMemcpyAsync(p->h_g.p, p->d_g.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;
+        if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) goto bad;
+        return FRX_OK;
+    bad:
+        hip_rc = fail(FRX_ERR_HIP, std::string("device evaluation failed: ") + hipGetErrorString(e));
+        return hip_rc;
+    };
+    int rc = drive_batch(p->B, p->xoff.data(), p->h_x.p, p->h_g.p, p->h_f.p, *params, nt, status, iters, evals, objective, p->stats,
+                         eval_all);
+    if (rc != FRX_OK) return rc;
+    std::memcpy(x, p->h_x.p, sizeof(double) * p->NX);
+    // final generate (CPU.hpp:1258-1263) and the reference's return value (CPU.hpp:1267)
+    std::vector<double> Tt(p->P), Cc((size_t)p->P * 18);
+    rc = frx_forward(p, x, Tt.data(), Cc.data());
+    if (rc != FRX_OK) return rc;
+    if (T) std::copy(Tt.begin(), Tt.end(), T);
+    if (C) std::copy(Cc.begin(), Cc.end(), C);
+    if (jerk_cost) {
+        for (int b = 0; b < p->B; b++) {
+            double obj = 0.0;                                            // getTrajJerkCost, CPU.hpp:507-520
+            for (int gp = p->poff[b]; gp < p->poff[b + 1]; gp++) {
+                const double *c3 = &Cc[18 * (size_t)gp + 9], *c4 = c3 + 3, *c5 = c3 + 6;
+                const double t1 = Tt[gp], t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+                obj += 36.0 * frx::dot3(c3, c3) * t1 + 144.0 * frx::dot3(c4, c3) * t2 + 192.0 * frx::dot3(c4, c4) * t3 +
+                       240.0 * frx::dot3(c5, c3) * t3 + 720.0 * frx::dot3(c5, c4) * t4 + 720.0 * frx::dot3(c5, c5) * t5;
+            }
+            jerk_cost[b] = obj;
+        }
+    }
+    return FRX_OK;
+}
+
+int frx_optimize_stats(const frx_problem *p, double *out4) {
+    if (!p || !out4) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < 4; i++) out4[i] = p->stats[i];
+    return FRX_OK;
+}
+
+int frx_lbfgs_minimize_batch(int count, const int *x_off, double *x, double *f_out, int *status, int *iters, int *evals,
+                             const frx_lbfgs_params *params, frx_batch_eval_fn eval, void *instance, int n_threads) {
+    if (count <= 0 || !x_off || !x || !params || !eval || !status) return fail(FRX_ERR_INVALID_ARG, "null argument or count <= 0");
+    const int NX = x_off[count];
+    std::vector<double> g(NX, 0.0), f(count, 0.0);
+    auto eval_all = [&](int na, const int *ids) -> int {
+        eval(instance, na, ids, x, f.data(), g.data());
+        return FRX_OK;
+    };
+    return drive_batch(count, x_off, x, g.data(), f.data(), *params, std::max(1, n_threads), status, iters, evals, f_out, nullptr,
+                       eval_all);
+}
+
+} // extern "C"

@@ -1,0 +1,43 @@
+// Device-side problem description and the host-callable kernel launchers.
+// frx_device.hip (hipcc, gfx950) implements the launchers; frx_api.cpp (g++) calls them, so the
+// host-side optimiser is built with exactly the flags of the CPU oracle (bit-identical L-BFGS
+// arithmetic) while the kernels keep hipcc's device code generation.
+#pragma once
+#include <cstddef>
+
+#include "frx_math.hpp"
+
+#define FRX_BAND_W 13
+
+namespace frx {
+
+struct DevProblem {
+    int B, P, kappa, soft, c2;
+    double rho, sumT;
+    PenaltyConst pc;
+    // per candidate
+    const int *poff, *coff, *xoff, *boff;     // [B+1] fine pieces, coarse pieces, variables, band offsets (doubles)
+    const double *headPVA, *tailPVA;          // [B][9] column-major (p|v|a)
+    // per fine piece
+    const int *piece_hbeg, *piece_K;          // [P] first half-space record / count of the piece's polytope (idxHs expanded)
+    const int *piece_coarse;                  // [P] global coarse index of the piece
+    // per coarse piece
+    const int *coarse_iv, *coarse_fbeg;       // [Pc] interval count, first fine piece (global)
+    // per waypoint (candidate b owns N_b-1, global index = poff[b] - b + i)
+    const int *wp_vbeg, *wp_nv, *wp_xbeg;     // first vertex record, vertex count, absolute index of its xi segment in x
+    const double *hrec, *vrec;                // half-space records [..][6]; vertices [..][3] in [v0, v_r - v0] form
+};
+
+struct LaunchGeom {
+    int maxN, maxCN, Kmax, lpp, ppw;
+    size_t lds_fwd, lds_bwd, lds_pen;
+};
+
+// all return a hipError_t value as int (0 = hipSuccess); stream is a hipStream_t
+int launch_set_limits(const LaunchGeom &g);
+int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *band, void *stream);
+int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, const double *C, double *out20, void *stream);
+int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
+                    const double *band, const double *out20, double *f, double *grad, void *stream);
+
+} // namespace frx

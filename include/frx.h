@@ -1,0 +1,188 @@
+/*
+ * frx.h — C ABI of the MI355X-native back-end for Fast-Racing's SE(3) MINCO optimiser.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference
+ * interface it replaces; paths are relative to /root/reference/src/plan_manage/:
+ *   CPU.hpp = include/se3gcopter/se3gcopter_cpu.hpp     GPU.hpp = include/se3gcopter/se3gcopter_gpu.hpp
+ *   cc.cuh  = include/cuda_computer.cuh                 cc.cu   = src/cuda_computer.cu
+ *   lbfgs.hpp = include/se3gcopter/lbfgs.hpp
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions cross the ABI; every call returns an int
+ *     status (0 = FRX_OK, <0 = error, see frx_status) and frx_last_error() gives the text.
+ *   - all floating point is IEEE binary64, exactly like the reference.
+ *   - a problem handle holds a BATCH of B independent candidate trajectories (the reference
+ *     has B = 1); candidates may have different piece counts and different
+ *     numbers of free variables.  Per-candidate quantities are packed back to back and
+ *     addressed through the offset arrays returned by frx_problem_layout().
+ *   - 3x3 boundary states are column-major (p | v | a), as Eigen stores the reference's
+ *     iniState/finState (se3_node_cpu.cpp:98-99, CPU.hpp:440-442).
+ *   - coefficient blocks are (6N x 3) ROW-major per candidate: row 6i+k = coefficient of t^k
+ *     of piece i (CPU.hpp:244,260); i.e. piece-major, 18 contiguous doubles per piece.
+ *   - "_device" variants take device pointers and a hipStream_t (passed as void*) and are
+ *     asynchronous; the plain variants take host pointers and block.
+ *   - the library never falls back to a CPU implementation: without a usable HIP device
+ *     frx_problem_create() fails with FRX_ERR_NO_DEVICE.
+ */
+#ifndef FRX_H
+#define FRX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRX_VERSION 100
+
+typedef enum frx_status {
+    FRX_OK = 0,
+    FRX_ERR_INVALID_ARG = -1,
+    FRX_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime error at create */
+    FRX_ERR_HIP = -3,              /* HIP runtime error later on */
+    FRX_ERR_EMPTY_POLYTOPE = -4,   /* a corridor cell or overlap has no vertices: SE3GCOPTER::setup returns false (CPU.hpp:1118-1121) */
+    FRX_ERR_CAPACITY = -5,         /* piece count too large for the LDS-resident band (reference silently caps N <= 100, cc.cuh:24) */
+    FRX_ERR_ALLOC = -6
+} frx_status;
+
+/* Scalar arguments of SE3GCOPTER::setup (CPU.hpp:1076-1092), named after the ROS parameters
+ * that feed them (se3_planner.h:61-98, misc/zhangjiajie_params.yaml). */
+typedef struct frx_config {
+    double rho;             /* Rho        > 0: soft total time, weight of sum(T) (CPU.hpp:1097-1102) */
+    double total_t;         /* TotalT     used only when rho <= 0 */
+    double grid_res;        /* gridRes    INFINITY at the only call site (MinCoPlan_CPU.cpp:117) */
+    int qd_intervals;       /* QdIntervals = kappa, trapezoid intervals per piece */
+    int c2_diffeo;          /* UseC2Diffeo */
+    double horiz_half_len;  /* HorizHalfLen  ellipsoid semi-axes (x, y) */
+    double vert_half_len;   /* VertHalfLen   ellipsoid semi-axis z */
+    double safe_margin;     /* SafeMargin */
+    double vel_max;         /* VelMax */
+    double thr_acc_min;     /* ThrustAccMin */
+    double thr_acc_max;     /* ThrustAccMax */
+    double body_rate_max;   /* BodyRateMax */
+    double grav_acc;        /* GravAcc */
+    double penalty_pvtb[4]; /* PenaltyPVTB  weights: corridor, velocity, thrust (both bounds), body rate */
+} frx_config;
+
+/* L-BFGS parameters = lbfgs::lbfgs_parameter_t (lbfgs.hpp:18-140), same defaults. */
+typedef struct frx_lbfgs_params {
+    int mem_size;
+    double g_epsilon;
+    int past;
+    double delta;
+    int max_iterations;
+    int max_linesearch;
+    double min_step;
+    double max_step;
+    double f_dec_coeff;
+    double s_curv_coeff;
+    double xtol;
+} frx_lbfgs_params;
+
+typedef struct frx_problem frx_problem;
+
+int frx_version(void);
+/* Text of the last error raised on this thread (never NULL). */
+const char *frx_last_error(void);
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int frx_device_count(void);
+
+/* Fills p with lbfgs_load_default_parameters (lbfgs.hpp:1040-1043). */
+void frx_lbfgs_default_params(frx_lbfgs_params *p);
+/* Fills p with the values SE3GCOPTER::optimize uses (CPU.hpp:1243-1247): mem_size 128, past 3,
+ * g_epsilon 1e-16, min_step 1e-32, delta = rel_cost_tol, everything else default. */
+void frx_lbfgs_gcopter_params(frx_lbfgs_params *p, double rel_cost_tol);
+
+/*
+ * Replaces SE3GCOPTER::setup (CPU.hpp:1076-1186) + cuda_computer::setup (cc.cu:413-466) for a
+ * batch of B candidates on HIP device `device`.  Everything that is constant during the
+ * optimisation (polytopes, index maps, boundary states, parameters) is uploaded ONCE here;
+ * the reference re-packs ~257 KB through mapped memory on every evaluation (cc.cu:492-527).
+ *
+ *   coarse_n[B]            polytopes (= coarse pieces) per candidate
+ *   ini_state, fin_state   B x 9 doubles, column-major 3x3 (p | v | a) per candidate
+ *   h_off, h_rec           CSR over ALL candidates' H-polytopes in order: polytope m owns the
+ *                          half-space records h_off[m] .. h_off[m+1]-1, 6 doubles each
+ *                          (outer normal, point) = one column of the reference's 6 x K matrix
+ *                          (MinCoPlan_CPU.cpp:93-105).  Normals are re-normalised (CPU.hpp:1116).
+ *   v_off, v_rec           CSR over ALL candidates' V-polytopes; candidate b owns 2*coarse_n[b]-1
+ *                          of them in the order [cell 0, overlap 0|1, cell 1, ...] (CPU.hpp:1031-1074);
+ *                          3 doubles per vertex.  These are the OUTPUT of geoutils::enumerateVs,
+ *                          which stays on the caller's side for now; the
+ *                          [v0, v_r - v0] re-basing of CPU.hpp:1049 is done inside.
+ */
+int frx_problem_create(const frx_config *cfg, int device, int B, const int *coarse_n,
+                       const double *ini_state, const double *fin_state,
+                       const int *h_off, const double *h_rec,
+                       const int *v_off, const double *v_rec,
+                       frx_problem **out);
+/* Replaces ~cuda_computer / kill_kernel (cc.cu:44-49, 566-579; GPU.hpp:907-909). */
+void frx_problem_destroy(frx_problem *p);
+
+/* Totals: out6 = {B, total fine pieces, total coarse pieces, total free variables, max half-spaces per piece,
+ * sum over fine pieces of their half-space count}. */
+int frx_problem_totals(const frx_problem *p, int *out6);
+/* Offsets (each B+1 ints): fine pieces, coarse pieces, free variables; plus dimFreeT per candidate (B ints).
+ * Candidate b's variables are x[x_off[b] .. x_off[b+1]) = (tau[dim_t[b]], xi[...]) as in CPU.hpp:970-971. */
+int frx_problem_layout(const frx_problem *p, int *piece_off, int *coarse_off, int *x_off, int *dim_t);
+
+/* First half of SE3GCOPTER::optimize (CPU.hpp:1237-1240): setInitial + backwardT + backwardP.
+ * Host work (tiny NLS solves, CPU.hpp:777-813); x0 has total-free-variables doubles. */
+int frx_initial_guess(frx_problem *p, double *x0);
+
+/*
+ * Replaces SE3GCOPTER::objectiveFunc (CPU.hpp:961-1000) for the whole batch: x -> (f, grad).
+ * One call = steps 1-7 of SURVEY.md §3.4 for every candidate, entirely on the device.
+ *   x, g : total-free-variables doubles;  f : B doubles.
+ */
+int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g);
+int frx_objective_eval_device(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *hip_stream);
+
+/*
+ * Replaces cuda_computer::compute (cc.cuh:118-134, cc.cu:469-563) = MINCO_S3::addTimeIntPenalty
+ * (CPU.hpp:188-408) for the whole batch, with the same ACCUMULATING semantics (cc.cu:551-558):
+ *   cost[b] += penalty,  gdT[piece] += d/dT,  gdC[piece*18 ..] += d/dc.
+ *   T    : total-fine-pieces doubles (piece durations)
+ *   C    : total-fine-pieces x 18 doubles (piece-major coefficients)
+ * The _device variant OVERWRITES per-piece partials out_dev[piece*20 + {0: cost, 1: gdT, 2..19: gdC}]
+ * and leaves the accumulation to the caller.
+ */
+int frx_penalty_eval(frx_problem *p, const double *T, const double *C, double *cost, double *gdT, double *gdC);
+int frx_penalty_eval_device(frx_problem *p, const double *T_dev, const double *C_dev, double *out_dev, void *hip_stream);
+
+/* x -> piece durations T (total fine pieces) and coefficients C (x 18): forwardT/forwardP + MINCO_S3::generate
+ * (CPU.hpp:1258-1262, 425-505).  Either output may be NULL. */
+int frx_forward(frx_problem *p, const double *x, double *T, double *C);
+
+/*
+ * Replaces SE3GCOPTER::optimize (CPU.hpp:1230-1268) for the whole batch: every candidate runs
+ * its own L-BFGS (host, lbfgs.hpp:1103-1444 semantics incl. the Moré–Thuente search and the
+ * backtracking fallback); all candidates that need an objective value at a given moment share
+ * ONE batched device evaluation.
+ *   x        in: start point (from frx_initial_guess or the caller); out: minimiser
+ *   C, T     optimised coefficients / durations of the final generate() (CPU.hpp:1262-1263); may be NULL
+ *   jerk_cost[B]   what the reference returns (CPU.hpp:1267); may be NULL
+ *   objective[B]   final penalised objective (discarded by the reference, CPU.hpp:1242); may be NULL
+ *   status[B]      lbfgs_optimize return code per candidate (ignored by the reference, CPU.hpp:1249)
+ *   iters[B], evals[B]  iteration / evaluation counts; may be NULL
+ */
+int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, double *C, double *T,
+                 double *jerk_cost, double *objective, int *status, int *iters, int *evals);
+
+/* Wall-clock split of the last frx_optimize call, milliseconds: out4 = {total, device evaluations
+ * (launch + copies + sync), host L-BFGS, evaluation rounds}. */
+int frx_optimize_stats(const frx_problem *p, double *out4);
+
+/*
+ * Host-side solver on its own (used by the CPU tests and by integrators that bring their own
+ * objective): minimises `count` independent problems with the batched state machine.  `eval`
+ * is called with the ids of the problems that need a value; x/g are the packed arrays
+ * (problem i at x_off[i]).  Semantics of each problem = lbfgs::lbfgs_optimize (lbfgs.hpp:1103).
+ */
+typedef void (*frx_batch_eval_fn)(void *instance, int n_active, const int *active_ids,
+                                  const double *x, double *f, double *g);
+int frx_lbfgs_minimize_batch(int count, const int *x_off, double *x, double *f_out, int *status, int *iters, int *evals,
+                             const frx_lbfgs_params *params, frx_batch_eval_fn eval, void *instance, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRX_H */

@@ -1,0 +1,144 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/frx.h), against the
+CPU oracle on identical seeded inputs.  Tolerances (all relative, FP64):
+  per-stage / per-evaluation quantities  1e-9   (re-association + FMA contraction only; measured ~1e-13)
+  optimised coefficients                 1e-6   (BASELINE.json north_star), see test_optimize_parity
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PER_EVAL_TOL = 1e-9
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    den = max(np.abs(b).max(), 1e-300)
+    return float(np.abs(a - b).max() / den)
+
+
+def make(frx, sc, ob, B, N, gates, kappa, scenario_id=0, obstacles=False, **over):
+    cands = sc.make_batch(scenario_id, B, N, gates, obstacles=obstacles)
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa, **over)
+    oracles = [ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=kappa, **over) for c in cands]
+    for o in oracles:
+        o.set_abscissa_mode(False)      # device uses s = step*j (cc.cu:152); faithful += form is used end to end
+    return cands, prob, oracles
+
+
+def iterates(o, n_iter_list=(0, 15, 60)):
+    """Points along an oracle L-BFGS run: the initial guess and a few early/mid iterates, so the
+    active-constraint pattern is realistic (SURVEY.md §8d 'kernel-only benchmark state')."""
+    x0 = o.initial_guess()
+    xs = [x0]
+    for it in n_iter_list[1:]:
+        xs.append(o.optimize(1e-6, max_iterations=it, x0=x0)["x"])
+    return xs
+
+
+@pytest.mark.parametrize("B,N,gates,kappa,obst", [(3, 32, 8, 8, False), (2, 64, 16, 16, True), (2, 8, 2, 48, True), (1, 12, 3, 70, False)])
+def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst):
+    cands, prob, oracles = make(frx, sc, ob, B, N, gates, kappa, obstacles=obst)
+    assert prob.B == B and prob.P == B * N
+    # initial guess (host: setInitial + backwardT + backwardP)
+    x0 = prob.initial_guess()
+    for b, o in enumerate(oracles):
+        assert rel(x0[prob.x_off[b]:prob.x_off[b + 1]], o.initial_guess()) < 1e-12
+    pts = [iterates(o) for o in oracles]
+    for s in range(len(pts[0])):
+        x = np.concatenate([pts[b][s] for b in range(B)])
+        # forward: tau->T, xi->q, banded LU + solve
+        T, Cf = prob.forward(x)
+        refs = [o.forward(pts[b][s]) for b, o in enumerate(oracles)]
+        for b in range(B):
+            sl = slice(prob.piece_off[b], prob.piece_off[b + 1])
+            assert rel(T[sl], refs[b][0]) < 1e-13, f"T stage {s} cand {b}"
+            assert rel(Cf[6 * sl.start:6 * sl.stop], refs[b][2]) < PER_EVAL_TOL, f"C stage {s} cand {b}"
+        # penalty kernel on the ORACLE's coefficients (isolates the kernel)
+        Tref = np.concatenate([r[0] for r in refs]); Cref = np.concatenate([r[2] for r in refs])
+        cost, gdT, gdC = prob.penalty(Tref, Cref)
+        for b, o in enumerate(oracles):
+            c_ref, gT_ref, gC_ref = o.penalty(refs[b][0], refs[b][2])
+            sl = slice(prob.piece_off[b], prob.piece_off[b + 1])
+            assert abs(cost[b] - c_ref) <= PER_EVAL_TOL * max(abs(c_ref), 1e-300), f"penalty cost stage {s} cand {b}"
+            assert rel(gdT[sl], gT_ref) < PER_EVAL_TOL, f"penalty gdT stage {s} cand {b}"
+            assert rel(gdC[6 * sl.start:6 * sl.stop], gC_ref) < PER_EVAL_TOL, f"penalty gdC stage {s} cand {b}"
+        # full objective
+        f, g = prob.objective(x)
+        for b, o in enumerate(oracles):
+            f_ref, g_ref = o.objective(pts[b][s])
+            assert abs(f[b] - f_ref) <= PER_EVAL_TOL * abs(f_ref), f"f stage {s} cand {b}: {f[b]} vs {f_ref}"
+            assert rel(g[prob.x_off[b]:prob.x_off[b + 1]], g_ref) < PER_EVAL_TOL, f"grad stage {s} cand {b}"
+    prob.close()
+
+
+def test_penalty_accumulates_like_compute(frx, sc, ob):
+    """cuda_computer::compute ADDS into cost/gdT/gdC (cc.cu:551-558); so does frx_penalty_eval."""
+    cands, prob, oracles = make(frx, sc, ob, 2, 16, 4, 8)
+    x = np.concatenate([o.initial_guess() for o in oracles])
+    T, Cf = prob.forward(x)
+    c1, t1, g1 = prob.penalty(T, Cf)
+    import ctypes as C
+    cost = np.full(prob.B, 3.0); gdT = np.full(prob.P, -2.0); gdC = np.full(prob.P * 18, 0.5)
+    rc = frx.lib().frx_penalty_eval(prob.h, T, np.ascontiguousarray(Cf.reshape(-1)), cost, gdT, gdC)
+    assert rc == 0
+    np.testing.assert_allclose(cost, c1 + 3.0, rtol=1e-14)
+    np.testing.assert_allclose(gdT, t1 - 2.0, rtol=1e-14)
+    np.testing.assert_allclose(gdC, g1.reshape(-1) + 0.5, rtol=1e-14)
+    prob.close()
+
+
+def test_fixed_total_time_branch(frx, sc, ob):
+    """rho <= 0: fixed total time (CPU.hpp:651-673, 851-879), exponential and C2 maps."""
+    for c2 in (1, 0):
+        cands, prob, oracles = make(frx, sc, ob, 2, 16, 4, 8, rho=0.0, total_t=9.0, c2_diffeo=c2)
+        x = np.concatenate([o.initial_guess() for o in oracles])
+        assert rel(prob.initial_guess(), x) < 1e-12
+        rng = np.random.default_rng(5)
+        x = x + 0.05 * rng.standard_normal(x.size)
+        f, g = prob.objective(x)
+        for b, o in enumerate(oracles):
+            xs = x[prob.x_off[b]:prob.x_off[b + 1]]
+            f_ref, g_ref = o.objective(xs)
+            assert abs(f[b] - f_ref) <= PER_EVAL_TOL * abs(f_ref)
+            assert rel(g[prob.x_off[b]:prob.x_off[b + 1]], g_ref) < PER_EVAL_TOL
+        prob.close()
+
+
+def test_optimize_short_run_tracks_oracle(frx, sc, ob):
+    """Same start, same L-BFGS arithmetic: for the first iterations the device-evaluated run follows
+    the oracle run (differences only from ~1e-13 per-evaluation rounding)."""
+    cands, prob, oracles = make(frx, sc, ob, 3, 32, 8, 8)
+    for o in oracles:
+        o.set_abscissa_mode(True)
+    res = prob.optimize(1e-6, max_iterations=25)
+    for b, o in enumerate(oracles):
+        r = o.optimize(1e-6, max_iterations=25)
+        assert res["status"][b] == r["status"]
+        assert abs(res["objective"][b] - r["objective"]) <= 1e-6 * abs(r["objective"])
+    prob.close()
+
+
+@pytest.mark.parametrize("B,N,gates,kappa", [(4, 32, 8, 8)])
+def test_optimize_parity(frx, sc, ob, B, N, gates, kappa):
+    """End-to-end contract (north_star): optimised MINCO coefficients within 1e-6 relative of the CPU
+    reference path on identical inputs.  L-BFGS with the stock stop rule (relative cost decrease
+    over 3 iterations < OptRelTol) does not pin the minimiser to 1e-6, so — as SURVEY.md §7.3-3
+    prescribes — both sides run to a tight tolerance (delta = 1e-12); the stock-tolerance result is
+    compared on the objective value."""
+    cands, prob, oracles = make(frx, sc, ob, B, N, gates, kappa)
+    for o in oracles:
+        o.set_abscissa_mode(True)                      # the faithful CPU path (s1 += step)
+    tight = prob.optimize(1e-12)
+    stock = prob.optimize(1e-6)
+    for b, o in enumerate(oracles):
+        rt = o.optimize(1e-12)
+        rs = o.optimize(1e-6)
+        sl = slice(6 * prob.piece_off[b], 6 * prob.piece_off[b + 1])
+        e = rel(tight["C"][sl], rt["C"])
+        eT = rel(tight["T"][prob.piece_off[b]:prob.piece_off[b + 1]], rt["T"])
+        print(f"cand {b}: coeff rel err {e:.2e}, T rel err {eT:.2e}, objective {tight['objective'][b]:.9f} vs {rt['objective']:.9f}, "
+              f"iters {tight['iters'][b]} vs {rt['iters']}, stock obj {stock['objective'][b]:.6f} vs {rs['objective']:.6f}")
+        assert e < 1e-6 and eT < 1e-6
+        assert abs(stock["objective"][b] - rs["objective"]) <= 1e-4 * abs(rs["objective"])
+    prob.close()
