@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X back-end (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE batched cost/gradient evaluation x -> (f, grad f) of the headline workload
+(BASELINE.json configs[2]: 32 candidate trajectories x 64 pieces x 16 quadrature intervals,
+synthetic Zhangjiajie-like 16-gate corridor) = the three kernels k_forward, k_penalty, k_backward
+on inputs that are already resident in HBM.  value = constraint-samples/s = ranks * B*N*(kappa+1) * K / t,
+t = max over ranks of the barrier-bracketed wall time of the K steps.  Weak scaling: every rank
+owns its own batch of 32 candidates (different gate perturbations); the evaluation needs no
+collective — the only exchange is the final winner selection, outside the timed region.
+
+The JSON line also carries:
+  roofline      for the dominant kernel k_penalty: algorithmic bytes (sum over pieces of 312 + 48 K_i,
+                SURVEY.md §8d) / its average duration measured with HIP events on the launch stream
+  cpu_baseline  the CPU oracle (faithful restatement of the reference CPU path) timed on the host cores
+  plan_*        full SE(3) plan (frx_optimize from the reference's initial guess, stock OptRelTol)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
+    """Time the CPU oracle on the host cores: objective evaluations of the same candidates at the same
+    state, one candidate per task, as many threads as cores.  Test-infrastructure use of oracle/ (the
+    measured thing here IS the baseline, never the product)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    workers = min(cores, len(cands))
+    oracles = [ob.Oracle(c, params, qd_intervals=kappa) for c in cands]
+    xs = [x_state[x_off[b]:x_off[b + 1]].copy() for b in range(len(cands))]
+
+    def work(b, reps):
+        o, x = oracles[b], xs[b]
+        for _ in range(reps):
+            o.objective(x)
+        return reps
+
+    t0 = time.perf_counter(); work(0, 3); per_eval = (time.perf_counter() - t0) / 3
+    # bounded sample: ~budget_s seconds of wall time
+    reps = max(1, int(budget_s * workers / (per_eval * len(cands))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        done = sum(ex.map(lambda b: work(b, reps), range(len(cands))))
+    dt = time.perf_counter() - t0
+    samples = done * oracles[0].fine_n * (kappa + 1)
+    # one full plan of candidate 0 (stock tolerance) for the plan-ms comparison
+    t0 = time.perf_counter()
+    r = oracles[0].optimize(params["opt_rel_tol"])
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    return {
+        "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "kind": "port",
+        "sample": f"{done} objective evaluations (x->f,grad) of the {len(cands)} headline candidates at the bench state, "
+                  f"{workers} threads, oracle built -O3 -march=x86-64-v3",
+        "us_per_eval_per_candidate_1thread": per_eval * 1e6,
+        "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="headline", help="scenario.CONFIGS key (bench workload = headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plan", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from frx_import import frx
+    from fast_racing_amd import scenario as sc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or frx.lib().frx_device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (libfrx has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    B, N, gates, kappa = sc.CONFIGS[args.config]
+    params = sc.ZHANGJIAJIE
+    # weak scaling: rank r owns candidates [r*B, (r+1)*B) of the same scenario ("random gate perturbations")
+    cands = [sc.make_candidate(0, N, gates, perturb_id=rank * B + b) for b in range(B)]
+    prob = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # bench state: the iterate after 60 L-BFGS iterations from the reference's initial guess (untimed)
+    x0 = prob.initial_guess()
+    warm = prob.optimize(params["opt_rel_tol"], x0=x0, max_iterations=60)
+    x_state = warm["x"]
+    x_dev = torch.from_numpy(x_state).cuda()
+    f_dev = torch.zeros(prob.B, dtype=torch.float64, device="cuda")
+    g_dev = torch.zeros(prob.NX, dtype=torch.float64, device="cuda")
+
+    def step():
+        prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    samples_per_step = prob.samples()
+
+    # dominant kernel alone, HIP events on the launch stream
+    T_dev = torch.zeros(prob.P, dtype=torch.float64, device="cuda")
+    C_dev = torch.zeros(prob.P * 18, dtype=torch.float64, device="cuda")
+    T_h, C_h = prob.forward(x_state)
+    T_dev.copy_(torch.from_numpy(T_h)); C_dev.copy_(torch.from_numpy(C_h.reshape(-1)))
+    out_dev = torch.zeros(prob.P * 20, dtype=torch.float64, device="cuda")
+    for _ in range(10):
+        prob.penalty_device(T_dev.data_ptr(), C_dev.data_ptr(), out_dev.data_ptr(), stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(args.steps, 50)
+    e0.record()
+    for _ in range(reps):
+        prob.penalty_device(T_dev.data_ptr(), C_dev.data_ptr(), out_dev.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    pen_us = e0.elapsed_time(e1) * 1e3 / reps
+    alg_bytes = prob.algorithmic_bytes()
+    achieved = alg_bytes / (pen_us * 1e-6) / 1e9
+
+    plan = {}
+    if not args.no_plan:
+        if dist: dist.barrier()
+        r = prob.optimize(params["opt_rel_tol"], x0=x0)
+        plan = {"plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
+                "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
+                "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min())}
+        # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
+        from fast_racing_amd.dist import select_winner
+        ids = np.arange(rank * B, rank * B + B)
+        gid, obj, owner, wc, wT = select_winner(
+            dist, torch.device("cuda", local_rank), r["objective"], ids,
+            lambda i: r["C"][6 * prob.piece_off[i]:6 * prob.piece_off[i + 1]], lambda i: r["T"][prob.piece_off[i]:prob.piece_off[i + 1]], N)
+        plan.update({"winner_id": gid, "winner_rank": owner, "winner_objective": obj, "winner_total_time_s": float(wT.sum())})
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cands, params, kappa, x_state, prob.x_off)
+
+    if rank == 0:
+        out = {
+            "metric": "constraint-samples/s", "value": world * samples_per_step * args.steps / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {B} candidate trajs/GPU x {N} pieces x {kappa} quadrature intervals "
+                                   f"({samples_per_step} constraint samples/step/GPU), 16-gate Zhangjiajie-like corridor, K_i=8",
+                       "step": "one batched objective evaluation x->(f,grad): k_forward + k_penalty + k_backward, inputs resident in HBM",
+                       "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
+                       "parallelism": f"candidates sharded {B}/GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "frx::k_penalty", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_kernel_us": pen_us, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6)},
+            "cpu_baseline": cpu,
+        }
+        out.update(plan)
+        print(json.dumps(out), flush=True)
+    prob.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Multi-GPU plumbing: candidates are independent optimisation problems, so the
+batch is block-partitioned over ranks and an evaluation needs NO collective.  The only exchange
+of a plan is the final winner selection: all-gather of (objective, global candidate id) — 16 B per
+rank — then a broadcast of the winner's (6N x 3) coefficients and N durations from its owner.
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Block partition [lo, hi) of `total` candidates for `rank`; earlier ranks take the remainder."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def select_winner(dist, device, local_objective: np.ndarray, local_ids: np.ndarray, local_coeffs, local_T, n_pieces_max: int):
+    """All ranks learn the best candidate of the whole job.
+
+    local_coeffs(i) / local_T(i) return the coefficient block (6N x 3) / durations (N) of local
+    candidate i.  Returns (global_id, objective, owner_rank, coeffs, T).  Ties go to the lowest
+    global id so every rank takes the same decision."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    if len(local_objective):
+        order = np.lexsort((local_ids, local_objective))
+        best = int(order[0])
+        mine = torch.tensor([float(local_objective[best]), float(local_ids[best])], dtype=torch.float64, device=device)
+    else:
+        best = -1
+        mine = torch.tensor([float("inf"), -1.0], dtype=torch.float64, device=device)
+    if world > 1:
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        table = torch.stack(allv).cpu().numpy()
+    else:
+        table = mine.cpu().numpy()[None, :]
+    order = np.lexsort((table[:, 1], table[:, 0]))
+    owner = int(order[0])
+    gid, obj = int(table[owner, 1]), float(table[owner, 0])
+    payload = torch.zeros(1 + n_pieces_max * 19, dtype=torch.float64, device=device)
+    if rank == owner:
+        c = np.asarray(local_coeffs(best), dtype=np.float64).reshape(-1)
+        t = np.asarray(local_T(best), dtype=np.float64).reshape(-1)
+        n = t.size
+        buf = np.zeros(1 + n_pieces_max * 19)
+        buf[0] = n; buf[1:1 + 18 * n] = c; buf[1 + 18 * n_pieces_max:1 + 18 * n_pieces_max + n] = t
+        payload.copy_(torch.from_numpy(buf))
+    if world > 1:
+        dist.broadcast(payload, src=owner)
+    buf = payload.cpu().numpy()
+    n = int(buf[0])
+    coeffs = buf[1:1 + 18 * n].reshape(6 * n, 3).copy()
+    T = buf[1 + 18 * n_pieces_max:1 + 18 * n_pieces_max + n].copy()
+    return gid, obj, owner, coeffs, T

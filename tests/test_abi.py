@@ -1,0 +1,59 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol include/frx.h declares, and
+fails loudly (no CPU fallback) when there is no HIP device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "frx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(frx_[a-z_0-9]+)\s*\(", src)) - {"frx_batch_eval_fn"})
+
+
+def test_every_declared_symbol_is_exported(frx):
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    L = C.CDLL(frx.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/frx.h but not exported by libfrx.so"
+    assert sorted(frx.ABI_SYMBOLS) == syms
+    assert frx.lib().frx_version() == 100
+
+
+def test_config_struct_layout_matches_header(frx):
+    assert C.sizeof(frx.FrxConfig) == 3 * 8 + 2 * 4 + 8 * 8 + 4 * 8
+    assert C.sizeof(frx.LbfgsParams) == 80
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_create_fails_loudly_without_device(frx, sc):
+    assert frx.lib().frx_device_count() == 0
+    with pytest.raises(frx.FrxError, match="no HIP device"):
+        frx.Problem(sc.make_batch(0, 1, 8, 2), sc.ZHANGJIAJIE, qd_intervals=8)
+
+
+def test_argument_validation(frx):
+    h = C.c_void_p()
+    z = np.zeros(1); zi = np.zeros(2, np.int32)
+    cfg = frx.FrxConfig.from_params(__import__("fast_racing_amd").scenario.ZHANGJIAJIE)
+    rc = frx.lib().frx_problem_create(C.byref(cfg), 0, 0, zi, z, z, zi, z, zi, z, C.byref(h))
+    assert rc == -1 and b"B <= 0" in frx.lib().frx_last_error()
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "fast-racing_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dp, fn)).read()
+                assert "oracle/" not in txt.replace("the CPU oracle (oracle/Makefile)", "") and "liboracle" not in txt and "import oracle" not in txt, fn
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libfrx.so")], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out
