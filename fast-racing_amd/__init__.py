@@ -59,7 +59,7 @@ BATCH_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POI
 # every symbol include/frx.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params", "frx_lbfgs_gcopter_params",
-    "frx_problem_create", "frx_problem_destroy", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
+    "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
 ]
@@ -82,6 +82,7 @@ def lib():
         L.frx_lbfgs_gcopter_params.argtypes = [C.POINTER(LbfgsParams), C.c_double]
         L.frx_problem_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
+        L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_totals.argtypes = [C.c_void_p, _ip]
         L.frx_problem_layout.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip]
         L.frx_initial_guess.argtypes = [C.c_void_p, _dp]
@@ -160,6 +161,10 @@ class Problem:
 
     def __del__(self):
         self.close()
+
+    def set_solver(self, name: str):
+        """'knot_pcr' (default) or 'banded_lu' (reference elimination order, cross-check)."""
+        _check(lib().frx_problem_set_solver(self.h, {"knot_pcr": 0, "banded_lu": 1}[name]))
 
     def initial_guess(self):
         x = np.zeros(self.NX)

@@ -137,6 +137,7 @@ struct frx_problem {
     // pinned staging
     PinBuf<double> h_x, h_f, h_g, h_T, h_C, h_out20;
     frx::LaunchGeom geo;
+    bool banded_ok = true;
     double stats[4] = {0, 0, 0, 0};
 };
 
@@ -384,8 +385,22 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
     ge.lds_bwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 6) + 2 * (size_t)p->maxN + p->maxCN);
     ge.lds_pen = sizeof(double) * ((size_t)ppb * 19 + (size_t)ppb * p->Kmax * 6 + 4 * 64 * 21);
+    ge.solver = frx::SOLVER_KNOT_PCR;
+    ge.knot_threads = 64 * ((p->maxN + 63) / 64);
+    {
+        const size_t nt = ge.knot_threads;
+        ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN);
+        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * (nt / 64) + 2);
+    }
     const size_t lds_cap = 160 * 1024;
-    if (ge.lds_bwd > lds_cap || ge.lds_fwd > lds_cap || ge.lds_pen > lds_cap) {
+    if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
+        delete p;
+        return fail(FRX_ERR_CAPACITY, "more than 256 pieces in one candidate: not supported (the reference caps at 100, cuda_computer.cuh:24)");
+    }
+    // the banded-LU cross-check kernels need the whole band in LDS; fall back to "unavailable" instead of failing create
+    p->banded_ok = !(ge.lds_bwd > lds_cap || ge.lds_fwd > lds_cap);
+    if (!p->banded_ok) { ge.lds_fwd = ge.lds_bwd = 1024; }
+    if (ge.lds_pen > lds_cap) {
         delete p;
         return fail(FRX_ERR_CAPACITY, "piece count / half-space count too large for the LDS-resident kernels (160 KiB per CU)");
     }
@@ -439,6 +454,15 @@ void frx_problem_destroy(frx_problem *p) {
     (void)hipSetDevice(p->device);
     if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
     delete p;
+}
+
+int frx_problem_set_solver(frx_problem *p, int solver) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (solver != FRX_SOLVER_KNOT_PCR && solver != FRX_SOLVER_BANDED_LU) return fail(FRX_ERR_INVALID_ARG, "unknown solver id");
+    if (solver == FRX_SOLVER_BANDED_LU && !p->banded_ok)
+        return fail(FRX_ERR_CAPACITY, "banded-LU kernels need the 6N x 13 band in LDS: too many pieces");
+    p->geo.solver = solver;
+    return FRX_OK;
 }
 
 int frx_problem_totals(const frx_problem *p, int *out6) {

@@ -28,9 +28,14 @@ struct DevProblem {
     const double *hrec, *vrec;                // half-space records [..][6]; vertices [..][3] in [v0, v_r - v0] form
 };
 
+enum { SOLVER_KNOT_PCR = 0, SOLVER_BANDED_LU = 1 };
+
 struct LaunchGeom {
     int maxN, maxCN, Kmax, lpp, ppw;
-    size_t lds_fwd, lds_bwd, lds_pen;
+    size_t lds_fwd, lds_bwd, lds_pen;      // banded-LU kernels + penalty kernel
+    int solver;                            // SOLVER_KNOT_PCR (default) | SOLVER_BANDED_LU
+    int knot_threads;                      // workgroup size of the knot kernels: 64 * ceil(maxN / 64)
+    size_t lds_kfwd, lds_kbwd;
 };
 
 // all return a hipError_t value as int (0 = hipSuccess); stream is a hipStream_t

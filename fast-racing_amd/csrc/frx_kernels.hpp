@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "frx_device.hpp"
+#include "frx_minco.hpp"
 
 namespace frx {
 
@@ -411,6 +412,332 @@ __global__ __launch_bounds__(64) void k_backward(DevProblem dp, const double *__
         }
     }
 }
+
+// =============================================================================================
+// Knot-form MINCO map (frx_minco.hpp): O(log N) depth instead of five 6N-row sequential sweeps.
+// One workgroup per candidate, thread k = piece k (0..N-1) AND interior knot k (1..N-1).
+// LDS (doubles): rows[2][18][nthr] (SoA, conflict-free) | KP,KV,KA [3][nthr+1] x 3 arrays | Tf[nthr] | Tc[maxCN] | red
+// =============================================================================================
+#define ROWF(buf, f, t) rowbuf[((buf) * 18 + (f)) * nthr + (t)]
+
+__device__ __forceinline__ void row_store(double *rowbuf, int nthr, int buf, int t, const KnotRow &R) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ROWF(buf, i, t) = R.D[i]; ROWF(buf, 4 + i, t) = R.L[i]; ROWF(buf, 8 + i, t) = R.U[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) ROWF(buf, 12 + i, t) = R.r[i];
+}
+__device__ __forceinline__ void row_load(const double *rowbuf, int nthr, int buf, int t, KnotRow &R) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { R.D[i] = ROWF(buf, i, t); R.L[i] = ROWF(buf, 4 + i, t); R.U[i] = ROWF(buf, 8 + i, t); }
+#pragma unroll
+    for (int i = 0; i < 6; i++) R.r[i] = ROWF(buf, 12 + i, t);
+}
+
+// Parallel cyclic reduction over knots 1..N-1 (thread k owns knot k); returns this knot's (v, a) solution.
+__device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nthr, int k, int N, KnotRow &me, double *v, double *a) {
+    const bool act = k >= 1 && k <= N - 1;
+    int buf = 0;
+    if (act) row_store(rowbuf, nthr, 0, k, me);
+    __syncthreads();
+    for (int s = 1; s < N - 1; s <<= 1) {
+        if (act) {
+            KnotRow lo, hi, out;
+            if (k - s >= 1) row_load(rowbuf, nthr, buf, k - s, lo); else knot_row_identity(lo);
+            if (k + s <= N - 1) row_load(rowbuf, nthr, buf, k + s, hi); else knot_row_identity(hi);
+            pcr_step(me, lo, hi, out);
+            me = out;
+            row_store(rowbuf, nthr, buf ^ 1, k, me);
+        }
+        buf ^= 1;
+        __syncthreads();
+    }
+    if (act) pcr_finish(me, v, a);
+}
+
+__global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
+                               int maxCN) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
+    const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
+    const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
+    const int x0 = dp.xoff[b];
+    double *rowbuf = sm;
+    double *KP = rowbuf + (size_t)36 * nthr;          // knot positions  [3][nthr+1]
+    double *KV = KP + 3 * (nthr + 1);
+    double *KA = KV + 3 * (nthr + 1);
+    double *Tf = KA + 3 * (nthr + 1);
+    double *Tc = Tf + nthr;
+#define KN(arr, axis, idx) arr[(axis) * (nthr + 1) + (idx)]
+
+    // forwardT (CPU.hpp:626-676)
+    if (dp.soft) {
+        for (int i = k; i < cN; i += nthr) Tc[i] = tau_to_T(x[x0 + i], dp.c2 != 0);
+    } else if (k == 0) {
+        const int Ms1 = cN - 1;
+        double sum = 0.0;
+        for (int i = 0; i < Ms1; i++) Tc[i] = tau_to_T(x[x0 + i], dp.c2 != 0);
+        Tc[Ms1] = 0.0;
+        for (int i = 0; i <= Ms1; i++) sum += Tc[i];
+        const double den = 1.0 + sum;
+        for (int i = 0; i <= Ms1; i++) Tc[i] /= den;
+        sum = 0.0;
+        for (int i = 0; i <= Ms1; i++) sum += Tc[i];
+        Tc[Ms1] = 1.0 - sum;
+        for (int i = 0; i <= Ms1; i++) Tc[i] *= dp.sumT;
+    }
+    __syncthreads();
+    // splitToFineT (CPU.hpp:930-944)
+    double hMine = 1.0;
+    if (k < N) {
+        const int gc = dp.piece_coarse[p0 + k];
+        hMine = Tc[gc - c0] / dp.coarse_iv[gc];
+        Tf[k] = hMine;
+        Tout[p0 + k] = hMine;
+    }
+    // forwardP (CPU.hpp:729-747): knot k = waypoint k-1
+    if (k >= 1 && k <= N - 1) {
+        const int gw = p0 - b + (k - 1);
+        const int nv1 = dp.wp_nv[gw] - 1;
+        const double *V = dp.vrec + 3 * (size_t)dp.wp_vbeg[gw];
+        const double *xi = x + dp.wp_xbeg[gw];
+        double nrm = 0.0;
+        for (int a = 0; a < nv1; a++) nrm += xi[a] * xi[a];
+        const double sc = 2.0 / (1.0 + nrm);
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+        for (int a = 0; a < nv1; a++) {
+            const double r = sc * xi[a], rr = r * r;
+            q0 += V[3 * (a + 1)] * rr; q1 += V[3 * (a + 1) + 1] * rr; q2 += V[3 * (a + 1) + 2] * rr;
+        }
+        KN(KP, 0, k) = q0 + V[0]; KN(KP, 1, k) = q1 + V[1]; KN(KP, 2, k) = q2 + V[2];
+    }
+    if (k < 3) {                                       // fixed head / tail knot states (CPU.hpp:440-442, 497-499)
+        KN(KP, k, 0) = dp.headPVA[b * 9 + k]; KN(KV, k, 0) = dp.headPVA[b * 9 + 3 + k]; KN(KA, k, 0) = dp.headPVA[b * 9 + 6 + k];
+        KN(KP, k, N) = dp.tailPVA[b * 9 + k]; KN(KV, k, N) = dp.tailPVA[b * 9 + 3 + k]; KN(KA, k, N) = dp.tailPVA[b * 9 + 6 + k];
+    }
+    __syncthreads();
+
+    // knot system rows + PCR
+    KnotRow me;
+    double vk[3] = {0, 0, 0}, ak[3] = {0, 0, 0};
+    if (k >= 1 && k <= N - 1) {
+        const double hL = Tf[k - 1], hR = hMine;
+        knot_row_matrix(hL, hR, me);
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+            knot_row_rhs(hL, hR, KN(KP, ax, k) - KN(KP, ax, k - 1), KN(KP, ax, k + 1) - KN(KP, ax, k), me.r[ax], me.r[3 + ax]);
+        if (k == 1) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                me.r[ax] -= me.L[0] * KN(KV, ax, 0) + me.L[1] * KN(KA, ax, 0);
+                me.r[3 + ax] -= me.L[2] * KN(KV, ax, 0) + me.L[3] * KN(KA, ax, 0);
+            }
+            me.L[0] = me.L[1] = me.L[2] = me.L[3] = 0.0;
+        }
+        if (k == N - 1) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                me.r[ax] -= me.U[0] * KN(KV, ax, N) + me.U[1] * KN(KA, ax, N);
+                me.r[3 + ax] -= me.U[2] * KN(KV, ax, N) + me.U[3] * KN(KA, ax, N);
+            }
+            me.U[0] = me.U[1] = me.U[2] = me.U[3] = 0.0;
+        }
+    }
+    pcr_solve_wg(rowbuf, nthr, k, N, me, vk, ak);
+    if (k >= 1 && k <= N - 1) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { KN(KV, ax, k) = vk[ax]; KN(KA, ax, k) = ak[ax]; }
+    }
+    __syncthreads();
+    // piece coefficients (quintic Hermite), 18 contiguous doubles per piece
+    if (k < N) {
+        double *co = Cout + (size_t)(p0 + k) * 18;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            double c[6];
+            hermite_coeffs(hMine, KN(KP, ax, k), KN(KV, ax, k), KN(KA, ax, k), KN(KP, ax, k + 1), KN(KV, ax, k + 1), KN(KA, ax, k + 1), c);
+#pragma unroll
+            for (int q = 0; q < 6; q++) co[q * 3 + ax] = c[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+                                const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
+                                double *__restrict__ g, int maxCN) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
+    const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
+    const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
+    const int x0 = dp.xoff[b];
+    double *rowbuf = sm;
+    double *KP = rowbuf + (size_t)36 * nthr;          // reused: knot states, then end-of-piece adjoints, then mu
+    double *KV = KP + 3 * (nthr + 1);
+    double *KA = KV + 3 * (nthr + 1);
+    double *Tf = KA + 3 * (nthr + 1);
+    double *gT = Tf + nthr;
+    double *gCo = gT + nthr;
+    double *red = gCo + maxCN;                         // [2 * nthr/64] cross-wave partials
+
+    // ---- piece-local: load, jerk energy + gradients (CPU.hpp:507-520, 65-95), cbar = d f / d c ----
+    double h = 1.0, c[18], cb[18], gTl = 0.0, costAcc = 0.0;
+    if (k < N) {
+        h = Tin[p0 + k];
+        Tf[k] = h;
+        const double *ci = Cin + (size_t)(p0 + k) * 18;
+        const double *o = out20 + (size_t)(p0 + k) * 20;
+#pragma unroll
+        for (int q = 0; q < 18; q++) { c[q] = ci[q]; cb[q] = o[2 + q]; }
+        const double t1 = h, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+        const double *c3 = c + 9, *c4 = c + 12, *c5 = c + 15;
+        const double s33 = dot3(c3, c3), s43 = dot3(c4, c3), s44 = dot3(c4, c4), s53 = dot3(c5, c3), s54 = dot3(c5, c4), s55 = dot3(c5, c5);
+        costAcc = o[0] + (36.0 * s33 * t1 + 144.0 * s43 * t2 + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
+        gTl = o[1] + (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2 + 720.0 * s53 * t2 + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            cb[9 + d] += 72.0 * c3[d] * t1 + 144.0 * c4[d] * t2 + 240.0 * c5[d] * t3;
+            cb[12 + d] += 144.0 * c3[d] * t2 + 384.0 * c4[d] * t3 + 720.0 * c5[d] * t4;
+            cb[15 + d] += 240.0 * c3[d] * t3 + 720.0 * c4[d] * t4 + 1440.0 * c5[d] * t5;
+        }
+        // knot states recovered from the coefficients: p = c0, v = c1, a = 2 c2 at the piece start
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { KN(KP, ax, k) = c[ax]; KN(KV, ax, k) = c[3 + ax]; KN(KA, ax, k) = 2.0 * c[6 + ax]; }
+    }
+    if (k < 3) { KN(KP, k, N) = dp.tailPVA[b * 9 + k]; KN(KV, k, N) = dp.tailPVA[b * 9 + 3 + k]; KN(KA, k, N) = dp.tailPVA[b * 9 + 6 + k]; }
+    __syncthreads();
+
+    // ---- Hermite adjoint per piece; end-of-piece parts go to the next knot through LDS ----
+    double p1[3], v1[3], a1[3], sP[3] = {0, 0, 0}, sV[3] = {0, 0, 0}, sA[3] = {0, 0, 0}, eP[3], eV[3], eA[3], hb = 0.0;
+    if (k < N) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { p1[ax] = KN(KP, ax, k + 1); v1[ax] = KN(KV, ax, k + 1); a1[ax] = KN(KA, ax, k + 1); }
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            double cba[6], db[6], hba;
+#pragma unroll
+            for (int q = 0; q < 6; q++) cba[q] = cb[q * 3 + ax];
+            hermite_adjoint(h, c[ax], c[3 + ax], 2.0 * c[6 + ax], p1[ax], v1[ax], a1[ax], cba, db, hba);
+            sP[ax] = db[0]; sV[ax] = db[1]; sA[ax] = db[2];
+            eP[ax] = db[3]; eV[ax] = db[4]; eA[ax] = db[5];
+            hb += hba;
+        }
+    }
+    __syncthreads();                                    // everyone has read the knot states
+    if (k < N) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { KN(KP, ax, k + 1) = eP[ax]; KN(KV, ax, k + 1) = eV[ax]; KN(KA, ax, k + 1) = eA[ax]; }
+    }
+    __syncthreads();
+
+    // ---- mu = K^-1 wbar (same SPD knot matrix, PCR) ----
+    KnotRow me;
+    double muv[3] = {0, 0, 0}, mua[3] = {0, 0, 0}, pbk[3] = {0, 0, 0};
+    if (k >= 1 && k <= N - 1) {
+        knot_row_matrix(Tf[k - 1], h, me);
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            me.r[ax] = sV[ax] + KN(KV, ax, k);
+            me.r[3 + ax] = sA[ax] + KN(KA, ax, k);
+            pbk[ax] = sP[ax] + KN(KP, ax, k);          // direct d f / d p_k (both adjacent pieces)
+        }
+        if (k == 1) me.L[0] = me.L[1] = me.L[2] = me.L[3] = 0.0;
+        if (k == N - 1) me.U[0] = me.U[1] = me.U[2] = me.U[3] = 0.0;
+    }
+    pcr_solve_wg(rowbuf, nthr, k, N, me, muv, mua);
+    // publish mu (zero at the fixed end knots) — reuse KV/KA
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        if (k <= N) { KN(KV, ax, k) = (k >= 1 && k <= N - 1) ? muv[ax] : 0.0; KN(KA, ax, k) = (k >= 1 && k <= N - 1) ? mua[ax] : 0.0; }
+    }
+    if (k == 0 && N == nthr) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { KN(KV, ax, N) = 0.0; KN(KA, ax, N) = 0.0; }
+    }
+    __syncthreads();
+    // ---- through the knot system: duration term and d f / d(p_{k+1} - p_k) ----
+    double dlb[3] = {0, 0, 0};
+    if (k < N) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+            dlb[ax] = knot_adjoint_piece(h, p1[ax] - c[ax], c[3 + ax], 2.0 * c[6 + ax], v1[ax], a1[ax], KN(KV, ax, k), KN(KA, ax, k),
+                                         KN(KV, ax, k + 1), KN(KA, ax, k + 1), hb);
+        gT[k] = gTl + hb + dp.rho;                     // + rho: CPU.hpp:989
+    }
+    __syncthreads();
+    if (k < N) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) KN(KP, ax, k + 1) = dlb[ax];       // +dl to knot k+1
+    }
+    __syncthreads();
+    double gq[3] = {0, 0, 0};
+    if (k >= 1 && k <= N - 1) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) gq[ax] = pbk[ax] + KN(KP, ax, k) - dlb[ax];   // -dl of the piece starting here
+    }
+
+    // ---- cost (CPU.hpp:988) and mergeToCoarseGradT (CPU.hpp:946-959) ----
+    double sumTc = 0.0;
+    for (int i = k; i < cN; i += nthr) {
+        const int gc = c0 + i;
+        const int iv = dp.coarse_iv[gc], fb = dp.coarse_fbeg[gc] - p0;
+        double s = 0.0, tt = 0.0;
+        for (int a = 0; a < iv; a++) { s += gT[fb + a]; tt += Tf[fb + a]; }
+        gCo[i] = s / iv;
+        sumTc += tt;
+    }
+    {
+        const double wc = wave_sum(costAcc), wt = wave_sum(sumTc);
+        const int nw = nthr >> 6, w = k >> 6;
+        if ((k & 63) == 0) { red[w] = wc; red[nw + w] = wt; }
+        __syncthreads();
+        if (k == 0) {
+            double tc = 0.0, tt = 0.0;
+            for (int i = 0; i < nw; i++) { tc += red[i]; tt += red[nw + i]; }
+            f[b] = tc + dp.rho * tt;
+        }
+    }
+    // ---- addLayerTGrad (CPU.hpp:816-894) ----
+    if (dp.soft) {
+        for (int i = k; i < cN; i += nthr) g[x0 + i] = gCo[i] * dT_dtau(x[x0 + i], dp.c2 != 0);
+    } else if (k == 0) {
+        const int Ms1 = cN - 1;
+        const double gTail = dp.sumT * gCo[Ms1];
+        double expTauSum = 0.0, gFreeDotExpTau = 0.0;
+        for (int i = 0; i < Ms1; i++) {
+            const double e = tau_to_T(x[x0 + i], dp.c2 != 0);
+            expTauSum += e;
+            gFreeDotExpTau += e * (dp.sumT * gCo[i]);
+        }
+        const double den = expTauSum + 1.0;
+        for (int i = 0; i < Ms1; i++) {
+            const double de = dT_dtau(x[x0 + i], dp.c2 != 0);
+            g[x0 + i] = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
+        }
+    }
+    // ---- addLayerPGrad (CPU.hpp:897-928): knot k = waypoint k-1 ----
+    if (k >= 1 && k <= N - 1) {
+        const int gw = p0 - b + (k - 1);
+        const int nv1 = dp.wp_nv[gw] - 1;
+        const double *V = dp.vrec + 3 * (size_t)dp.wp_vbeg[gw];
+        const int xb = dp.wp_xbeg[gw];
+        const double *xi = x + xb;
+        double qn = 0.0;
+        for (int a = 0; a < nv1; a++) qn += xi[a] * xi[a];
+        const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;
+        double gdq = 0.0;
+        for (int a = 0; a < nv1; a++) {
+            const double r = sc * xi[a];
+            const double gdr = (V[3 * (a + 1)] * gq[0] + V[3 * (a + 1) + 1] * gq[1] + V[3 * (a + 1) + 2] * gq[2]) * r * 2.0;
+            gdq += gdr * xi[a];
+        }
+        for (int a = 0; a < nv1; a++) {
+            const double r = sc * xi[a];
+            const double gdr = (V[3 * (a + 1)] * gq[0] + V[3 * (a + 1) + 1] * gq[1] + V[3 * (a + 1) + 2] * gq[2]) * r * 2.0;
+            g[xb + a] = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
+        }
+    }
+#undef KN
+}
+#undef ROWF
 
 #undef BAND
 } // namespace frx

@@ -185,15 +185,18 @@ def make_candidate(scenario_id: int, n_pieces: int, n_gates: int, perturb_id: in
     """Candidate `perturb_id` of scenario `scenario_id`: 0 = nominal gates, >0 = i.i.d. N(0, 0.5 m)
     perturbation of every gate centre ("random gate perturbations", BASELINE.json configs[3])."""
     rng = SplitMix64(BASE_SEED + scenario_id)
-    gates = make_gates(rng, n_gates)
+    start = np.array([0.0, 0.0, 1.0])                    # se3_node_cpu.cpp:18
+    if n_gates == 0:                                     # degenerate test case: one "gate" 4 m per piece ahead, no goal leg
+        gates = np.array([start + np.array([0.5 * rng.uniform(-1, 1), 4.0 * n_pieces, 0.3 * rng.uniform(-1, 1)])])
+    else:
+        gates = make_gates(rng, n_gates)
     if perturb_id > 0:
         prng = SplitMix64((BASE_SEED + scenario_id) * 1000003 + perturb_id)
-        for k in range(n_gates):
+        for k in range(len(gates)):
             gates[k] += 0.5 * np.array([prng.normal(), prng.normal(), 0.3 * prng.normal()])
             gates[k, 2] = min(2.4, max(0.8, gates[k, 2]))
-    start = np.array([0.0, 0.0, 1.0])                    # se3_node_cpu.cpp:18
-    goal = gates[-1] + np.array([0.0, 15.0, 0.0])
-    poly = np.vstack([start, gates, goal])
+    goal = gates[-1] + np.array([0.0, 15.0, 0.0]) if n_gates > 0 else gates[-1]
+    poly = np.vstack([start, gates, goal]) if n_gates > 0 else np.vstack([start, goal])
     knots = resample_polyline(poly, n_pieces)
     seg_len = np.linalg.norm(np.diff(knots, axis=0), axis=1)
     assert seg_len.max() <= 6.0, "segments must stay short enough for consecutive boxes to overlap"

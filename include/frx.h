@@ -117,6 +117,15 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
 /* Replaces ~cuda_computer / kill_kernel (cc.cu:44-49, 566-579; GPU.hpp:907-909). */
 void frx_problem_destroy(frx_problem *p);
 
+/* How the MINCO map (q,T)->c and its adjoint are evaluated on the device.  Both compute the same spline:
+ *   FRX_SOLVER_KNOT_PCR  (default) quintic-Hermite knot form, SPD 2x2-block tridiagonal system in the knot (v,a),
+ *                        parallel cyclic reduction: O(log N) depth (fast-racing_amd/csrc/frx_minco.hpp)
+ *   FRX_SOLVER_BANDED_LU the reference's own elimination order: 6N x 6N band, no-pivot LU, solve, solveAdj
+ *                        (trajectory.hpp:655-751); sequential in 6N, kept as an on-device cross-check. */
+#define FRX_SOLVER_KNOT_PCR 0
+#define FRX_SOLVER_BANDED_LU 1
+int frx_problem_set_solver(frx_problem *p, int solver);
+
 /* Totals: out6 = {B, total fine pieces, total coarse pieces, total free variables, max half-spaces per piece,
  * sum over fine pieces of their half-space count}. */
 int frx_problem_totals(const frx_problem *p, int *out6);

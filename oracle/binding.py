@@ -71,6 +71,7 @@ def lib():
         L.orc_dense_A.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_solve_adj.argtypes = [C.c_void_p, _dp]
         L.orc_solve.argtypes = [C.c_void_p, _dp]
+        L.orc_backprop.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.orc_jerk_cost.restype = C.c_double
         L.orc_jerk_cost.argtypes = [C.c_void_p]
         L.orc_penalty.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
@@ -185,6 +186,13 @@ class Oracle:
         r = np.ascontiguousarray(rhs, dtype=np.float64).reshape(-1).copy()
         lib().orc_solve(self.h, r)
         return r.reshape(-1, 3)
+
+    def backprop(self, gdC):
+        """lambda = A^-T gdC with the factors of the last generate(); returns (gdT[N], gdP[N-1,3]) from zero."""
+        lam = np.ascontiguousarray(gdC, dtype=np.float64).reshape(-1).copy()
+        gdT = np.zeros(self.fine_n); gdP = np.zeros(3 * (self.fine_n - 1))
+        lib().orc_backprop(self.h, lam, gdT, gdP)
+        return gdT, gdP.reshape(-1, 3)
 
     def jerk_cost(self):
         return lib().orc_jerk_cost(self.h)

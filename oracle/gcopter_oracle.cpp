@@ -1007,6 +1007,14 @@ void orc_dense_A(void *h, const double *T, double *Adense /* (6N)^2 row-major */
 // in-place A^T \ rhs with the factors left by the last generate()/objective (a8)
 void orc_solve_adj(void *h, double *rhs /* 6N x 3 row-major */) { ((orc::Problem *)h)->jerkOpt.A.solveAdj(rhs, 3); }
 void orc_solve(void *h, double *rhs) { ((orc::Problem *)h)->jerkOpt.A.solve(rhs, 3); }
+// a8 + a9 alone: with the factors left by the last generate(), lambda = A^-T gdC, then addPropCtoT / addPropCtoP
+// (CPU.hpp:97-161).  gdC is overwritten with lambda; gdT (N) and gdP (3 x (N-1) col-major) are ACCUMULATED into.
+void orc_backprop(void *h, double *gdC, double *gdT, double *gdP) {
+    orc::Problem *p = (orc::Problem *)h;
+    p->jerkOpt.A.solveAdj(gdC, 3);
+    p->jerkOpt.addPropCtoT(gdC, gdT);
+    p->jerkOpt.addPropCtoP(gdC, gdP);
+}
 double orc_jerk_cost(void *h) { return ((orc::Problem *)h)->jerkOpt.getTrajJerkCost(); }
 
 // a7 alone with cuda_computer::compute semantics (accumulates into cost/gdT/gdC — cuda_computer.cu:551-558)

@@ -39,3 +39,106 @@ extern "C" void hostcheck_penalty(int N, int kappa, const double *T, const doubl
         }
     }
 }
+
+// ---- MINCO map in knot form (fast-racing_amd/csrc/frx_minco.hpp), emulated sequentially on the host ----
+#include <vector>
+#include "../../fast-racing_amd/csrc/frx_minco.hpp"
+
+namespace {
+// solve the knot system for all interior knots by PCR, lanes emulated by a loop; rows[k-1] = knot k
+void pcr_solve(std::vector<frx::KnotRow> rows, std::vector<double> &v, std::vector<double> &a) {
+    const int n = (int)rows.size();
+    frx::KnotRow id; frx::knot_row_identity(id);
+    std::vector<frx::KnotRow> nxt(n);
+    for (int s = 1; s < n; s *= 2) {
+        for (int k = 0; k < n; k++) frx::pcr_step(rows[k], k - s >= 0 ? rows[k - s] : id, k + s < n ? rows[k + s] : id, nxt[k]);
+        rows.swap(nxt);
+    }
+    v.assign(3 * n, 0.0); a.assign(3 * n, 0.0);
+    for (int k = 0; k < n; k++) frx::pcr_finish(rows[k], &v[3 * k], &a[3 * k]);
+}
+void build_rows(int N, const double *T, std::vector<frx::KnotRow> &rows) {
+    rows.resize(N - 1);
+    for (int k = 1; k <= N - 1; k++) frx::knot_row_matrix(T[k - 1], T[k], rows[k - 1]);
+}
+} // namespace
+
+// forward: q (3 x (N-1) col-major), T[N], head/tail (col-major p|v|a) -> C (6N x 3 row-major)
+extern "C" void hostcheck_minco_forward(int N, const double *T, const double *q, const double *head, const double *tail, double *C,
+                                        double *Vout, double *Aout) {
+    std::vector<double> P(3 * (N + 1)), V(3 * (N + 1)), A(3 * (N + 1));
+    for (int x = 0; x < 3; x++) {
+        P[x] = head[x]; V[x] = head[3 + x]; A[x] = head[6 + x];
+        P[3 * N + x] = tail[x]; V[3 * N + x] = tail[3 + x]; A[3 * N + x] = tail[6 + x];
+    }
+    for (int k = 1; k < N; k++) for (int x = 0; x < 3; x++) P[3 * k + x] = q[3 * (k - 1) + x];
+    if (N > 1) {
+        std::vector<frx::KnotRow> rows;
+        build_rows(N, T, rows);
+        for (int k = 1; k <= N - 1; k++) {
+            frx::KnotRow &R = rows[k - 1];
+            for (int x = 0; x < 3; x++)
+                frx::knot_row_rhs(T[k - 1], T[k], P[3 * k + x] - P[3 * (k - 1) + x], P[3 * (k + 1) + x] - P[3 * k + x], R.r[x], R.r[3 + x]);
+            if (k == 1) {           // known head (v,a) moves to the right-hand side
+                for (int x = 0; x < 3; x++) { R.r[x] -= R.L[0] * V[x] + R.L[1] * A[x]; R.r[3 + x] -= R.L[2] * V[x] + R.L[3] * A[x]; }
+                for (int i = 0; i < 4; i++) R.L[i] = 0.0;
+            }
+            if (k == N - 1) {
+                for (int x = 0; x < 3; x++) { R.r[x] -= R.U[0] * V[3 * N + x] + R.U[1] * A[3 * N + x]; R.r[3 + x] -= R.U[2] * V[3 * N + x] + R.U[3] * A[3 * N + x]; }
+                for (int i = 0; i < 4; i++) R.U[i] = 0.0;
+            }
+        }
+        std::vector<double> v, a;
+        pcr_solve(rows, v, a);
+        for (int k = 1; k < N; k++) for (int x = 0; x < 3; x++) { V[3 * k + x] = v[3 * (k - 1) + x]; A[3 * k + x] = a[3 * (k - 1) + x]; }
+    }
+    for (int i = 0; i < N; i++)
+        for (int x = 0; x < 3; x++) {
+            double c[6];
+            frx::hermite_coeffs(T[i], P[3 * i + x], V[3 * i + x], A[3 * i + x], P[3 * i + 3 + x], V[3 * i + 3 + x], A[3 * i + 3 + x], c);
+            for (int k = 0; k < 6; k++) C[(6 * i + k) * 3 + x] = c[k];
+        }
+    if (Vout) for (int i = 0; i < 3 * (N + 1); i++) { Vout[i] = V[i]; Aout[i] = A[i]; }
+}
+
+// adjoint: given dC = d f/d c (6N x 3 row-major) at the point (T, q): gdT[N] += implicit part, gdQ (3 x (N-1)) += d f / d q
+extern "C" void hostcheck_minco_adjoint(int N, const double *T, const double *q, const double *head, const double *tail,
+                                        const double *dC, double *gdT, double *gdQ) {
+    std::vector<double> C(18 * N), V(3 * (N + 1)), A(3 * (N + 1)), P(3 * (N + 1));
+    hostcheck_minco_forward(N, T, q, head, tail, C.data(), V.data(), A.data());
+    for (int x = 0; x < 3; x++) { P[x] = head[x]; P[3 * N + x] = tail[x]; }
+    for (int k = 1; k < N; k++) for (int x = 0; x < 3; x++) P[3 * k + x] = q[3 * (k - 1) + x];
+    std::vector<double> pb(3 * (N + 1), 0.0), vb(3 * (N + 1), 0.0), ab(3 * (N + 1), 0.0);
+    for (int i = 0; i < N; i++)
+        for (int x = 0; x < 3; x++) {
+            double cb[6], db[6], hb;
+            for (int k = 0; k < 6; k++) cb[k] = dC[(6 * i + k) * 3 + x];
+            frx::hermite_adjoint(T[i], P[3 * i + x], V[3 * i + x], A[3 * i + x], P[3 * i + 3 + x], V[3 * i + 3 + x], A[3 * i + 3 + x], cb, db, hb);
+            pb[3 * i + x] += db[0]; vb[3 * i + x] += db[1]; ab[3 * i + x] += db[2];
+            pb[3 * i + 3 + x] += db[3]; vb[3 * i + 3 + x] += db[4]; ab[3 * i + 3 + x] += db[5];
+            gdT[i] += hb;
+        }
+    std::vector<double> muv(3 * (N + 1), 0.0), mua(3 * (N + 1), 0.0);
+    if (N > 1) {
+        std::vector<frx::KnotRow> rows;
+        build_rows(N, T, rows);
+        for (int k = 1; k <= N - 1; k++) {
+            frx::KnotRow &R = rows[k - 1];
+            for (int x = 0; x < 3; x++) { R.r[x] = vb[3 * k + x]; R.r[3 + x] = ab[3 * k + x]; }
+            if (k == 1) for (int i = 0; i < 4; i++) R.L[i] = 0.0;
+            if (k == N - 1) for (int i = 0; i < 4; i++) R.U[i] = 0.0;
+        }
+        std::vector<double> v, a;
+        pcr_solve(rows, v, a);
+        for (int k = 1; k < N; k++) for (int x = 0; x < 3; x++) { muv[3 * k + x] = v[3 * (k - 1) + x]; mua[3 * k + x] = a[3 * (k - 1) + x]; }
+    }
+    for (int i = 0; i < N; i++)
+        for (int x = 0; x < 3; x++) {
+            double hb = 0.0;
+            const double dlb = frx::knot_adjoint_piece(T[i], P[3 * i + 3 + x] - P[3 * i + x], V[3 * i + x], A[3 * i + x], V[3 * i + 3 + x],
+                                                       A[3 * i + 3 + x], muv[3 * i + x], mua[3 * i + x], muv[3 * i + 3 + x], mua[3 * i + 3 + x], hb);
+            gdT[i] += hb;
+            pb[3 * i + 3 + x] += dlb; pb[3 * i + x] -= dlb;
+        }
+    for (int k = 1; k < N; k++) for (int x = 0; x < 3; x++) gdQ[3 * (k - 1) + x] += pb[3 * k + x];
+}

