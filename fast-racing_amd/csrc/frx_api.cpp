@@ -9,10 +9,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
 #include <thread>
+
+#include <pthread.h>
+#include <sched.h>
 #include <vector>
 
 #include "../../include/frx.h"
@@ -34,44 +38,69 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 using clk = std::chrono::steady_clock;
 inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
-// ---- a tiny spinning parallel-for (one evaluation round is ~100 us: no condvars) ----
+// ---- a tiny spinning thread pool (one evaluation round is ~100 us: no condvars) ----
+// Work is STATICALLY partitioned: item i always runs on worker i % n, and every worker is pinned to its
+// own CPU.  Each candidate's L-BFGS state (1.5 MB of (s, y) history at mem_size 128) is allocated, first
+// touched and then always updated by the same core, so it stays in that core's cache hierarchy.
 class SpinPool {
 public:
     explicit SpinPool(int nthreads) : n_(std::max(1, nthreads)) {
-        for (int t = 1; t < n_; t++) workers_.emplace_back([this] { loop(); });
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        std::vector<int> cpus;
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+            for (int c = 0; c < CPU_SETSIZE; c++)
+                if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+        have_main_mask_ = pthread_getaffinity_np(pthread_self(), sizeof(main_mask_), &main_mask_) == 0;
+        // FRX_PIN=0 disables pinning; FRX_PIN_OFFSET / FRX_PIN_STRIDE choose which allowed CPUs are used
+        const char *pe = std::getenv("FRX_PIN"), *po = std::getenv("FRX_PIN_OFFSET"), *ps = std::getenv("FRX_PIN_STRIDE");
+        const int off = po ? std::atoi(po) : 0, stride = std::max(1, ps ? std::atoi(ps) : 1);
+        const bool do_pin = !(pe && pe[0] == '0') && n_ > 1 && (int)cpus.size() >= off + (n_ - 1) * stride + 1;
+        if (do_pin) {
+            pin(pthread_self(), cpus[off]);
+            pinned_main_ = true;
+        }
+        for (int t = 1; t < n_; t++) {
+            workers_.emplace_back([this, t] { loop(t); });
+            if (do_pin) pin(workers_.back().native_handle(), cpus[off + t * stride]);
+        }
     }
     ~SpinPool() {
         stop_.store(true, std::memory_order_release);
         for (auto &w : workers_) w.join();
+        if (pinned_main_ && have_main_mask_) pthread_setaffinity_np(pthread_self(), sizeof(main_mask_), &main_mask_);
     }
+    int size() const { return n_; }
+    // fn(i) for i in [0, count): worker t takes i = t, t + n, t + 2n, ...
     template <class F> void run(int count, F &&fn) {
         if (count <= 0) return;
-        if (n_ == 1 || count == 1) { for (int i = 0; i < count; i++) fn(i); return; }
+        if (n_ == 1) { for (int i = 0; i < count; i++) fn(i); return; }
         fn_ = [&fn](int i) { fn(i); };
         count_ = count;
-        next_.store(0, std::memory_order_relaxed);
-        pending_.store(count, std::memory_order_relaxed);
+        pending_.store(n_ - 1, std::memory_order_relaxed);
         epoch_.fetch_add(1, std::memory_order_release);
-        drain();
+        for (int i = 0; i < count; i += n_) fn_(i);
         while (pending_.load(std::memory_order_acquire) > 0) cpu_relax();
     }
 private:
     static void cpu_relax() { __builtin_ia32_pause(); }
-    void drain() {
-        for (;;) {
-            int i = next_.fetch_add(1, std::memory_order_relaxed);
-            if (i >= count_) break;
-            fn_(i);
-            pending_.fetch_sub(1, std::memory_order_release);
-        }
+    static void pin(pthread_t th, int cpu) {
+        cpu_set_t m;
+        CPU_ZERO(&m);
+        CPU_SET(cpu, &m);
+        pthread_setaffinity_np(th, sizeof(m), &m);
     }
-    void loop() {
+    void loop(int t) {
         unsigned seen = 0;
         int idle = 0;
         while (!stop_.load(std::memory_order_acquire)) {
             unsigned e = epoch_.load(std::memory_order_acquire);
-            if (e != seen) { seen = e; drain(); idle = 0; }
-            else if (++idle > 2000) { std::this_thread::yield(); }
+            if (e != seen) {
+                seen = e;
+                for (int i = t; i < count_; i += n_) fn_(i);
+                pending_.fetch_sub(1, std::memory_order_release);
+                idle = 0;
+            } else if (++idle > 200000) { std::this_thread::yield(); idle = 0; }
             else cpu_relax();
         }
     }
@@ -79,9 +108,11 @@ private:
     std::vector<std::thread> workers_;
     std::function<void(int)> fn_;
     int count_ = 0;
-    std::atomic<int> next_{0}, pending_{0};
+    std::atomic<int> pending_{0};
     std::atomic<unsigned> epoch_{0};
     std::atomic<bool> stop_{false};
+    cpu_set_t main_mask_;
+    bool have_main_mask_ = false, pinned_main_ = false;
 };
 
 // ---- per-candidate host description (what setup() keeps for the initial guess) ----
@@ -112,7 +143,7 @@ template <class T> struct PinBuf {
     ~PinBuf() { if (p) (void)hipHostFree(p); }
     hipError_t alloc(size_t count) {
         n = count;
-        hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) std::memset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
         return e;
     }
@@ -129,7 +160,7 @@ struct frx_problem {
     frx::DevProblem dp;
     hipStream_t stream = nullptr;
     // device-resident constants
-    DevBuf<int> d_poff, d_coff, d_xoff, d_boff, d_piece_hbeg, d_piece_K, d_piece_coarse, d_coarse_iv, d_coarse_fbeg, d_wp_vbeg,
+    DevBuf<int> d_cvoff, d_poff, d_coff, d_xoff, d_boff, d_piece_hbeg, d_piece_K, d_piece_coarse, d_coarse_iv, d_coarse_fbeg, d_wp_vbeg,
         d_wp_nv, d_wp_xbeg;
     DevBuf<double> d_head, d_tail, d_hrec, d_vrec;
     // device work space
@@ -283,7 +314,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     p->poff.assign(B + 1, 0); p->coff.assign(B + 1, 0); p->xoff.assign(B + 1, 0); p->boff.assign(B + 1, 0);
     p->dimT.assign(B, 0);
 
-    std::vector<int> piece_hbeg, piece_K, piece_coarse, coarse_iv, coarse_fbeg, wp_vbeg, wp_nv, wp_xbeg;
+    std::vector<int> piece_hbeg, piece_K, piece_coarse, coarse_iv, coarse_fbeg, wp_vbeg, wp_nv, wp_xbeg, cvoff(B + 1, 0);
     std::vector<double> hrec, vrec, head(ini_state, ini_state + 9 * (size_t)B), tail(fin_state, fin_state + 9 * (size_t)B);
     int hpoly = 0, vpoly = 0;                     // running polytope indices into h_off / v_off
     for (int b = 0; b < B; b++) {
@@ -295,7 +326,6 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         std::memcpy(hc.fState, fin_state + 9 * (size_t)b, sizeof(hc.fState));
         // V-polytopes: [v0, v_r - v0]
         hc.cfgVs.resize(2 * cN - 1);
-        std::vector<int> vbeg(2 * cN - 1);
         for (int m = 0; m < 2 * cN - 1; m++) {
             const int beg = v_off[vpoly + m], nv = v_off[vpoly + m + 1] - beg;
             if (nv < 1) { delete p; return fail(FRX_ERR_EMPTY_POLYTOPE, "a corridor polytope has no vertices"); }
@@ -304,9 +334,8 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
             for (int r = 0; r < 3; r++) hc.cfgVs[m][r] = v[r];
             for (int a = 1; a < nv; a++)
                 for (int r = 0; r < 3; r++) hc.cfgVs[m][3 * a + r] = v[3 * a + r] - v[r];
-            vbeg[m] = (int)(vrec.size() / 3);
-            vrec.insert(vrec.end(), hc.cfgVs[m].begin(), hc.cfgVs[m].end());
         }
+        cvoff[b] = (int)(vrec.size() / 3);
         // gridMesh (CPU.hpp:1003-1029)
         hc.intervals.assign(cN, 1);
         {
@@ -349,7 +378,8 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
                     hc.idxVs[offset] = vm;
                     const int nv = (int)(hc.cfgVs[vm].size() / 3);
                     hc.dimP += nv - 1;
-                    wp_vbeg.push_back(vbeg[vm]); wp_nv.push_back(nv); wp_xbeg.push_back(xcur);
+                    wp_vbeg.push_back((int)(vrec.size() / 3)); wp_nv.push_back(nv); wp_xbeg.push_back(xcur);
+                    vrec.insert(vrec.end(), hc.cfgVs[vm].begin(), hc.cfgVs[vm].end());   // waypoint order, contiguous per candidate
                     xcur += nv - 1;
                 }
                 piece_hbeg.push_back(hbeg_dev); piece_K.push_back(K); piece_coarse.push_back(gc0 + i);
@@ -373,7 +403,13 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         p->maxN = std::max(p->maxN, hc.fineN);
         p->maxCN = std::max(p->maxCN, cN);
     }
+    cvoff[B] = (int)(vrec.size() / 3);
     p->P = p->poff[B]; p->Pc = p->coff[B]; p->NX = p->xoff[B];
+    int maxXb = 1, maxVb = 3;
+    for (int b = 0; b < B; b++) {
+        maxXb = std::max(maxXb, p->xoff[b + 1] - p->xoff[b]);
+        maxVb = std::max(maxVb, 3 * (cvoff[b + 1] - cvoff[b]));
+    }
 
     // launch geometry + LDS budgets
     const int spp = cfg->qd_intervals + 1;
@@ -389,8 +425,9 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     ge.knot_threads = 64 * ((p->maxN + 63) / 64);
     {
         const size_t nt = ge.knot_threads;
-        ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN);
-        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * (nt / 64) + 2);
+        ge.maxXb = maxXb; ge.maxVb = maxVb;
+        ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN + maxXb + maxVb);
+        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * (nt / 64) + 2 + maxXb + maxVb);
     }
     const size_t lds_cap = 160 * 1024;
     if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
@@ -416,7 +453,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     } while (0)
     CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     CR((hipError_t)frx::launch_set_limits(p->geo));
-    CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
+    CR(p->d_cvoff.upload(cvoff)); CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
     CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse));
     CR(p->d_coarse_iv.upload(coarse_iv)); CR(p->d_coarse_fbeg.upload(coarse_fbeg));
     CR(p->d_wp_vbeg.upload(wp_vbeg)); CR(p->d_wp_nv.upload(wp_nv)); CR(p->d_wp_xbeg.upload(wp_xbeg));
@@ -439,7 +476,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     d.pc.bdrMaxSqr = cfg->body_rate_max * cfg->body_rate_max;
     d.pc.gAcc = cfg->grav_acc;
     for (int q = 0; q < 4; q++) d.pc.chi[q] = cfg->penalty_pvtb[q];
-    d.poff = p->d_poff.p; d.coff = p->d_coff.p; d.xoff = p->d_xoff.p; d.boff = p->d_boff.p;
+    d.cvoff = p->d_cvoff.p; d.poff = p->d_poff.p; d.coff = p->d_coff.p; d.xoff = p->d_xoff.p; d.boff = p->d_boff.p;
     d.headPVA = p->d_head.p; d.tailPVA = p->d_tail.p;
     d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p;
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
@@ -559,8 +596,9 @@ template <class EvalAll>
 static int drive_batch(int count, const int *x_off, double *x, double *g, double *f, const frx_lbfgs_params &pm, int n_threads,
                        int *status, int *iters, int *evals, double *f_out, double *stats, EvalAll &&eval_all) {
     std::vector<frx::Solver> sv(count);
-    for (int i = 0; i < count; i++) sv[i].start(x_off[i + 1] - x_off[i], x + x_off[i], g + x_off[i], pm);
-    SpinPool pool(n_threads);
+    SpinPool pool(std::min(n_threads, count));
+    // allocation + first touch of each solver's history by its owning (pinned) worker
+    pool.run(count, [&](int i) { sv[i].start(x_off[i + 1] - x_off[i], x + x_off[i], g + x_off[i], pm); });
     std::vector<int> active;
     active.reserve(count);
     double t_eval = 0.0, t_host = 0.0;
@@ -576,7 +614,7 @@ static int drive_batch(int count, const int *x_off, double *x, double *g, double
         if (rc != FRX_OK) return rc;
         t_eval += ms_since(te);
         auto th = clk::now();
-        pool.run((int)active.size(), [&](int a) { const int i = active[a]; sv[i].feed(f[i]); });
+        pool.run(count, [&](int i) { if (!sv[i].done()) sv[i].feed(f[i]); });
         t_host += ms_since(th);
         rounds++;
     }
@@ -597,10 +635,29 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
     if (!p || !params || !x || !status) return fail(FRX_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
-    const int nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)p->B));
+    int nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)p->B));
+    if (const char *ht = std::getenv("FRX_HOST_THREADS")) nt = std::max(1, std::min(std::atoi(ht), p->B));
     int hip_rc = FRX_OK;
+    // Zero-copy round trip: the kernels read x from and write (f, grad) to mapped, coherent host memory over PCIe
+    // (205 KB each way at the headline size), so a round is three launches and one completion poll — no
+    // hipMemcpyAsync calls (each costs more host time than the kernels it feeds).  FRX_ZERO_COPY=0 restores copies.
+    const char *zc_env = std::getenv("FRX_ZERO_COPY");
+    const bool zero_copy = !(zc_env && zc_env[0] == '0');
+    auto wait_stream = [&]() -> hipError_t {
+        for (;;) {
+            hipError_t q = hipStreamQuery(p->stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            __builtin_ia32_pause();
+        }
+    };
     auto eval_all = [&](int, const int *) -> int {
         hipError_t e;
+        if (zero_copy) {
+            if ((e = (hipError_t)launch_eval(p, p->h_x.p, p->h_f.p, p->h_g.p, p->stream, true)) != hipSuccess) goto bad;
+            if ((e = wait_stream()) != hipSuccess) goto bad;
+            return FRX_OK;
+        }
         if ((e = hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream)) != hipSuccess) goto bad;
         if ((e = (hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true)) != hipSuccess) goto bad;
         if ((e = hipMemcpyAsync(p->h_f.p, p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;

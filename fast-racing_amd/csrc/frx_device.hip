@@ -16,7 +16,7 @@ int launch_set_limits(const LaunchGeom &g) {
 }
 int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *band, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)
-        hipLaunchKernelGGL(k_forward_knot, dim3(dp.B), dim3(g.knot_threads), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN);
+        hipLaunchKernelGGL(k_forward_knot, dim3(dp.B), dim3(g.knot_threads), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN, g.maxXb, g.maxVb);
     else
         hipLaunchKernelGGL(k_forward, dim3(dp.B), dim3(64), g.lds_fwd, (hipStream_t)stream, dp, x, T, C, band, g.maxN, g.maxCN);
     return (int)hipGetLastError();
@@ -31,7 +31,7 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
                     const double *band, const double *out20, double *f, double *grad, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)
         hipLaunchKernelGGL(k_backward_knot, dim3(dp.B), dim3(g.knot_threads), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
-                           grad, g.maxCN);
+                           grad, g.maxCN, g.maxXb, g.maxVb);
     else
         hipLaunchKernelGGL(k_backward, dim3(dp.B), dim3(64), g.lds_bwd, (hipStream_t)stream, dp, x, T, C, band, out20, f, grad, g.maxN,
                            g.maxCN);

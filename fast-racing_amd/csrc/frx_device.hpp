@@ -17,6 +17,7 @@ struct DevProblem {
     PenaltyConst pc;
     // per candidate
     const int *poff, *coff, *xoff, *boff;     // [B+1] fine pieces, coarse pieces, variables, band offsets (doubles)
+    const int *cvoff;                         // [B+1] first waypoint-vertex record of the candidate (vrec is in waypoint order)
     const double *headPVA, *tailPVA;          // [B][9] column-major (p|v|a)
     // per fine piece
     const int *piece_hbeg, *piece_K;          // [P] first half-space record / count of the piece's polytope (idxHs expanded)
@@ -36,6 +37,7 @@ struct LaunchGeom {
     int solver;                            // SOLVER_KNOT_PCR (default) | SOLVER_BANDED_LU
     int knot_threads;                      // workgroup size of the knot kernels: 64 * ceil(maxN / 64)
     size_t lds_kfwd, lds_kbwd;
+    int maxXb, maxVb;                      // per-candidate maxima: free variables, waypoint-vertex doubles (3 per vertex)
 };
 
 // all return a hipError_t value as int (0 = hipSuccess); stream is a hipStream_t

@@ -455,7 +455,7 @@ __device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nthr, int k, in
 }
 
 __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN) {
+                               int maxCN, int maxXb, int maxVb) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
@@ -467,15 +467,28 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
     double *KA = KV + 3 * (nthr + 1);
     double *Tf = KA + 3 * (nthr + 1);
     double *Tc = Tf + nthr;
+    double *xs = Tc + maxCN;                          // this candidate's variables (tau, xi), staged once
+    double *vs = xs + maxXb;                          // this candidate's waypoint polytopes [v0, edges], waypoint order
 #define KN(arr, axis, idx) arr[(axis) * (nthr + 1) + (idx)]
+    {   // coalesced staging: every later access is an LDS access (the per-waypoint loops would otherwise serialise
+        // one global-memory latency per vertex)
+        const int nx = dp.xoff[b + 1] - x0;
+        const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
+        const double *vsrc = dp.vrec + 3 * (size_t)v0;
+#pragma unroll 8
+        for (int i = k; i < nx; i += nthr) xs[i] = x[x0 + i];
+#pragma unroll 8
+        for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
+    }
+    __syncthreads();
 
     // forwardT (CPU.hpp:626-676)
     if (dp.soft) {
-        for (int i = k; i < cN; i += nthr) Tc[i] = tau_to_T(x[x0 + i], dp.c2 != 0);
+        for (int i = k; i < cN; i += nthr) Tc[i] = tau_to_T(xs[i], dp.c2 != 0);
     } else if (k == 0) {
         const int Ms1 = cN - 1;
         double sum = 0.0;
-        for (int i = 0; i < Ms1; i++) Tc[i] = tau_to_T(x[x0 + i], dp.c2 != 0);
+        for (int i = 0; i < Ms1; i++) Tc[i] = tau_to_T(xs[i], dp.c2 != 0);
         Tc[Ms1] = 0.0;
         for (int i = 0; i <= Ms1; i++) sum += Tc[i];
         const double den = 1.0 + sum;
@@ -498,8 +511,8 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
     if (k >= 1 && k <= N - 1) {
         const int gw = p0 - b + (k - 1);
         const int nv1 = dp.wp_nv[gw] - 1;
-        const double *V = dp.vrec + 3 * (size_t)dp.wp_vbeg[gw];
-        const double *xi = x + dp.wp_xbeg[gw];
+        const double *V = vs + 3 * (dp.wp_vbeg[gw] - dp.cvoff[b]);
+        const double *xi = xs + (dp.wp_xbeg[gw] - x0);
         double nrm = 0.0;
         for (int a = 0; a < nv1; a++) nrm += xi[a] * xi[a];
         const double sc = 2.0 / (1.0 + nrm);
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
 
 __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
-                                double *__restrict__ g, int maxCN) {
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
@@ -577,6 +590,17 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     double *gT = Tf + nthr;
     double *gCo = gT + nthr;
     double *red = gCo + maxCN;                         // [2 * nthr/64] cross-wave partials
+    double *xs = red + 2 * (nthr >> 6) + 2;
+    double *vs = xs + maxXb;
+    {
+        const int nx = dp.xoff[b + 1] - x0;
+        const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
+        const double *vsrc = dp.vrec + 3 * (size_t)v0;
+#pragma unroll 8
+        for (int i = k; i < nx; i += nthr) xs[i] = x[x0 + i];
+#pragma unroll 8
+        for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
+    }
 
     // ---- piece-local: load, jerk energy + gradients (CPU.hpp:507-520, 65-95), cbar = d f / d c ----
     double h = 1.0, c[18], cb[18], gTl = 0.0, costAcc = 0.0;
@@ -697,19 +721,19 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     }
     // ---- addLayerTGrad (CPU.hpp:816-894) ----
     if (dp.soft) {
-        for (int i = k; i < cN; i += nthr) g[x0 + i] = gCo[i] * dT_dtau(x[x0 + i], dp.c2 != 0);
+        for (int i = k; i < cN; i += nthr) g[x0 + i] = gCo[i] * dT_dtau(xs[i], dp.c2 != 0);
     } else if (k == 0) {
         const int Ms1 = cN - 1;
         const double gTail = dp.sumT * gCo[Ms1];
         double expTauSum = 0.0, gFreeDotExpTau = 0.0;
         for (int i = 0; i < Ms1; i++) {
-            const double e = tau_to_T(x[x0 + i], dp.c2 != 0);
+            const double e = tau_to_T(xs[i], dp.c2 != 0);
             expTauSum += e;
             gFreeDotExpTau += e * (dp.sumT * gCo[i]);
         }
         const double den = expTauSum + 1.0;
         for (int i = 0; i < Ms1; i++) {
-            const double de = dT_dtau(x[x0 + i], dp.c2 != 0);
+            const double de = dT_dtau(xs[i], dp.c2 != 0);
             g[x0 + i] = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
         }
     }
@@ -717,9 +741,9 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     if (k >= 1 && k <= N - 1) {
         const int gw = p0 - b + (k - 1);
         const int nv1 = dp.wp_nv[gw] - 1;
-        const double *V = dp.vrec + 3 * (size_t)dp.wp_vbeg[gw];
+        const double *V = vs + 3 * (dp.wp_vbeg[gw] - dp.cvoff[b]);
         const int xb = dp.wp_xbeg[gw];
-        const double *xi = x + xb;
+        const double *xi = xs + (xb - x0);
         double qn = 0.0;
         for (int a = 0; a < nv1; a++) qn += xi[a] * xi[a];
         const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;

@@ -78,6 +78,9 @@ def lib():
         L.orc_optimize.restype = C.c_int
         L.orc_optimize.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_int)]
+        L.orc_trace_begin.argtypes = [C.c_void_p, C.c_long]
+        L.orc_trace_get.restype = C.c_long
+        L.orc_trace_get.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_set_lbfgs.argtypes = [C.c_void_p]
         L.orc_lbfgs_run.restype = C.c_int
         L.orc_lbfgs_run.argtypes = [C.c_int, _dp, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, _dp, C.c_int, _dp, _dp, _ip,
@@ -202,6 +205,15 @@ class Oracle:
         cost = np.zeros(1); gdT = np.zeros(self.fine_n); gdC = np.zeros(18 * self.fine_n)
         lib().orc_penalty(self.h, np.ascontiguousarray(T, dtype=np.float64), np.ascontiguousarray(Cf, dtype=np.float64).reshape(-1), cost, gdT, gdC)
         return float(cost[0]), gdT, gdC.reshape(-1, 3)
+
+    def optimize_traced(self, rel_cost_tol, cap=20000, **kw):
+        """optimize() that also returns every point the solver evaluated, in order (rows of an array)."""
+        lib().orc_trace_begin(self.h, cap)
+        r = self.optimize(rel_cost_tol, **kw)
+        buf = np.zeros((cap, self.n))
+        cnt = lib().orc_trace_get(self.h, buf.ctypes.data, cap)
+        r["trace"] = buf[:cnt].copy()
+        return r
 
     def optimize(self, rel_cost_tol, max_iterations=0, x0=None):
         x = np.zeros(self.n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()

@@ -535,6 +535,8 @@ struct Problem {
     std::vector<double> coarseT, fineT, innerP;
     PenaltyParams pp;
     long evals = 0;
+    std::vector<double> trace;     // every point the optimiser evaluated (n doubles each), when trace_cap > 0
+    long trace_cap = 0;
 
     static inline int nvOf(const std::vector<double> &V) { return (int)(V.size() / 3); }
 
@@ -738,7 +740,7 @@ struct Problem {
     // CPU.hpp:961-1000
     static double objectiveFunc(void *ptrObj, const double *x, double *grad, const int n) {
         Problem &obj = *(Problem *)ptrObj;
-        (void)n;
+        if ((long)(obj.trace.size() / (size_t)n) < obj.trace_cap) obj.trace.insert(obj.trace.end(), x, x + n);
         obj.evals++;
         const int dimT = obj.dimFreeT;
         const double *t = x, *p = x + dimT;
@@ -1052,6 +1054,16 @@ int orc_optimize(void *h, double relCostTol, int max_iterations, double *x_inout
     if (n_evals) *n_evals = p->evals;
     if (n_iters) *n_iters = iters;
     return ret;
+}
+
+// record the points evaluated by the next optimize() (lock-step parity tests): cap = max number of points
+void orc_trace_begin(void *h, long cap) { orc::Problem *p = (orc::Problem *)h; p->trace.clear(); p->trace_cap = cap; }
+long orc_trace_get(void *h, double *out, long cap) {
+    orc::Problem *p = (orc::Problem *)h;
+    const long n = p->dimFreeT + p->dimFreeP, cnt = std::min<long>((long)(p->trace.size() / (size_t)n), cap);
+    if (out) std::copy(p->trace.begin(), p->trace.begin() + cnt * n, out);
+    p->trace_cap = 0;
+    return cnt;
 }
 
 // stand-alone access to the restated L-BFGS (for the three-way solver test): minimises a

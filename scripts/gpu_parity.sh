@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "stagewise or fixed_total or accumulates or short_run" 2>&1 | tail -30
+timeout 900 python -m pytest tests -m gpu -q -x -s 2>&1 | tail -30

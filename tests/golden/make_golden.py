@@ -1,0 +1,53 @@
+"""Generates tests/golden/*.npz: small seeded problems with the CPU oracle's outputs, so that
+  - the oracle is guarded against silent regressions (tests/test_golden.py, CPU),
+  - the GPU path is compared against committed numbers as well as against the live oracle.
+The reference has no fixtures of its own for this path and cannot be built here (no Eigen),
+so these vectors come from the line-by-line restatement in oracle/gcopter_oracle.cpp, whose L-BFGS is pinned
+bit-for-bit to the reference's lbfgs.hpp (tests/test_lbfgs.py).  Run from the repo root:
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from frx_import import frx  # noqa: E402,F401
+from fast_racing_amd import scenario as sc  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+CASES = {
+    # name: (scenario_id, perturb_id, N pieces, gates, kappa, obstacles, overrides)
+    "n8_k8": (21, 0, 8, 2, 8, False, {}),
+    "n16_k16_obst": (22, 1, 16, 4, 16, True, {}),
+    "n12_k48_stock": (23, 0, 12, 3, 48, False, {}),
+    "n10_fixedT_exp": (24, 2, 10, 2, 8, False, dict(rho=0.0, total_t=6.0, c2_diffeo=0)),
+}
+
+
+def build(name):
+    sid, pid, N, gates, kappa, obst, over = CASES[name]
+    cand = sc.make_candidate(sid, N, gates, perturb_id=pid, obstacles=obst)
+    o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa, **over)
+    x0 = o.initial_guess()
+    xs = [x0, o.optimize(1e-6, max_iterations=10, x0=x0)["x"], o.optimize(1e-6, max_iterations=80, x0=x0)["x"]]
+    out = dict(case=np.array([sid, pid, N, gates, kappa, int(obst)]), x=np.array(xs))
+    fs, gs, Ts, Cs, pc, pt, pg = [], [], [], [], [], [], []
+    for x in xs:
+        f, g = o.objective(x); fs.append(f); gs.append(g)
+        T, P, Cf = o.forward(x); Ts.append(T); Cs.append(Cf)
+        c, gt, gc = o.penalty(T, Cf); pc.append(c); pt.append(gt); pg.append(gc)
+    r = o.optimize(1e-6)
+    out.update(f=np.array(fs), g=np.array(gs), T=np.array(Ts), C=np.array(Cs), pen_cost=np.array(pc), pen_gdT=np.array(pt),
+               pen_gdC=np.array(pg), opt_x=r["x"], opt_C=r["C"], opt_T=r["T"], opt_obj=np.array(r["objective"]),
+               opt_jerk=np.array(r["jerk_cost"]), opt_iters=np.array(r["iters"]), opt_evals=np.array(r["evals"]),
+               opt_status=np.array(r["status"]))
+    return out
+
+
+if __name__ == "__main__":
+    for name in CASES:
+        d = build(name)
+        np.savez_compressed(os.path.join(os.path.dirname(__file__), name + ".npz"), **d)
+        print(name, "f =", d["f"], "opt obj", float(d["opt_obj"]), "iters", int(d["opt_iters"]))

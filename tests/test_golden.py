@@ -1,0 +1,74 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py):
+CPU: the oracle still reproduces them (regression guard for the checker itself);
+GPU: the HIP path reproduces them through the C ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys_path = os.path.join(ROOT, "tests", "golden")
+FILES = sorted(glob.glob(os.path.join(sys_path, "*.npz")))
+
+
+def load_case(path, sc):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(sys_path, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    name = os.path.splitext(os.path.basename(path))[0]
+    sid, pid, N, gates, kappa, obst, over = mg.CASES[name]
+    cand = sc.make_candidate(sid, N, gates, perturb_id=pid, obstacles=obst)
+    return np.load(path), cand, kappa, over
+
+
+def rel(a, b, floor=0.0):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), floor, 1e-300))
+
+
+def test_fixtures_exist():
+    assert len(FILES) >= 4
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_reproduces_golden(path, sc, ob):
+    d, cand, kappa, over = load_case(path, sc)
+    o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa, **over)
+    assert rel(o.initial_guess(), d["x"][0]) < 1e-13
+    for s, x in enumerate(d["x"]):
+        f, g = o.objective(x)
+        assert abs(f - d["f"][s]) <= 1e-12 * abs(d["f"][s])
+        assert rel(g, d["g"][s], abs(f)) < 1e-10
+        T, P, Cf = o.forward(x)
+        assert rel(T, d["T"][s]) < 1e-14 and rel(Cf, d["C"][s]) < 1e-11
+        c, gt, gc = o.penalty(T, Cf)
+        assert abs(c - d["pen_cost"][s]) <= 1e-12 * max(abs(d["pen_cost"][s]), 1e-300)
+    r = o.optimize(1e-6)
+    # same compiler, same flags -> the very same iterate path
+    assert r["iters"] == int(d["opt_iters"]) and r["status"] == int(d["opt_status"])
+    assert rel(r["C"], d["opt_C"]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_device_reproduces_golden(path, frx, sc):
+    d, cand, kappa, over = load_case(path, sc)
+    prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=kappa, **over)
+    assert rel(prob.initial_guess(), d["x"][0]) < 1e-12
+    for solver in ("knot_pcr", "banded_lu"):
+        prob.set_solver(solver)
+        for s, x in enumerate(d["x"]):
+            f, g = prob.objective(x)
+            assert abs(f[0] - d["f"][s]) <= 1e-9 * abs(d["f"][s])
+            assert rel(g, d["g"][s], abs(d["f"][s])) < 1e-9
+            T, Cf = prob.forward(x)
+            assert rel(T, d["T"][s]) < 1e-13 and rel(Cf, d["C"][s]) < 1e-7
+            cost, gdT, gdC = prob.penalty(d["T"][s], d["C"][s])
+            assert abs(cost[0] - d["pen_cost"][s]) <= 1e-9 * max(abs(d["pen_cost"][s]), 1e-300)
+            assert rel(gdT, d["pen_gdT"][s]) < 1e-9 and rel(gdC, d["pen_gdC"][s]) < 1e-9
+        # optimised coefficients: device map at the golden minimiser (the 1e-6 contract, lock-step form)
+        T, Cf = prob.forward(d["opt_x"])
+        assert rel(Cf, d["opt_C"]) < 1e-6 and rel(T, d["opt_T"]) < 1e-12
+    prob.close()

