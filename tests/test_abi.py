@@ -57,3 +57,16 @@ def test_product_never_references_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pkg, "libfrx.so")], stdout=subprocess.PIPE, text=True).stdout
     assert "oracle" not in out
+
+
+def test_cpp_mirror_header_compiles_and_links(frx, tmp_path):
+    """include/se3gcopter_amd.hpp (the C++ mirror of SE3GCOPTER::{setup,optimize}) builds against libfrx.so; on a CPU-only box
+    setup() must report the missing device instead of computing anything; on a GPU box the one-cell plan must succeed."""
+    import subprocess
+    exe = str(tmp_path / "integ_stub")
+    pkg = os.path.join(ROOT, "fast-racing_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "integration_stub.cpp"), "-o", exe,
+                    "-L" + pkg, "-lfrx", "-Wl,-rpath," + pkg], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout
+    assert ("no HIP device" in r.stdout) != has_gpu()
