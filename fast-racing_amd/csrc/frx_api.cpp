@@ -162,7 +162,7 @@ struct frx_problem {
     // device-resident constants
     DevBuf<int> d_cvoff, d_poff, d_coff, d_xoff, d_boff, d_piece_hbeg, d_piece_K, d_piece_coarse, d_coarse_iv, d_coarse_fbeg, d_wp_vbeg,
         d_wp_nv, d_wp_xbeg;
-    DevBuf<double> d_head, d_tail, d_hrec, d_vrec;
+    DevBuf<double> d_head, d_tail, d_hblk, d_vrec;
     // device work space
     DevBuf<double> d_x, d_f, d_g, d_T, d_C, d_band, d_out20;
     // pinned staging
@@ -315,7 +315,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     p->dimT.assign(B, 0);
 
     std::vector<int> piece_hbeg, piece_K, piece_coarse, coarse_iv, coarse_fbeg, wp_vbeg, wp_nv, wp_xbeg, cvoff(B + 1, 0);
-    std::vector<double> hrec, vrec, head(ini_state, ini_state + 9 * (size_t)B), tail(fin_state, fin_state + 9 * (size_t)B);
+    std::vector<double> hrec, horg, vrec, head(ini_state, ini_state + 9 * (size_t)B), tail(fin_state, fin_state + 9 * (size_t)B);
     int hpoly = 0, vpoly = 0;                     // running polytope indices into h_off / v_off
     for (int b = 0; b < B; b++) {
         HostCand &hc = p->cand[b];
@@ -360,12 +360,16 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         for (int i = 0; i < cN; i++) {
             const int hb = h_off[hpoly + i], K = h_off[hpoly + i + 1] - hb;
             if (K < 1) { delete p; return fail(FRX_ERR_INVALID_ARG, "an H-polytope has no half-spaces"); }
-            const int hbeg_dev = (int)(hrec.size() / 6);
+            const int hbeg_dev = (int)(hrec.size() / 4);
+            const double *org = h_rec + 6 * (size_t)hb + 3;              // polytope origin = point of its first half-space
+            horg.push_back(org[0]); horg.push_back(org[1]); horg.push_back(org[2]);
             for (int k = 0; k < K; k++) {                                // normalise outer normals, CPU.hpp:1116
                 const double *rec = h_rec + 6 * (size_t)(hb + k);
                 const double nn = std::sqrt(rec[0] * rec[0] + rec[1] * rec[1] + rec[2] * rec[2]);
-                hrec.push_back(rec[0] / nn); hrec.push_back(rec[1] / nn); hrec.push_back(rec[2] / nn);
-                hrec.push_back(rec[3]); hrec.push_back(rec[4]); hrec.push_back(rec[5]);
+                const double n0 = rec[0] / nn, n1 = rec[1] / nn, n2 = rec[2] / nn;
+                hrec.push_back(n0); hrec.push_back(n1); hrec.push_back(n2);
+                // n.(pos - p_k) + margin = n.(pos - org) - c   with   c = n.(p_k - org) - margin   (CPU.hpp:325,328)
+                hrec.push_back(n0 * (rec[3] - org[0]) + n1 * (rec[4] - org[1]) + n2 * (rec[5] - org[2]) - cfg->safe_margin);
             }
             p->Kmax = std::max(p->Kmax, K);
             coarse_iv.push_back(hc.intervals[i]);
@@ -417,10 +421,9 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     ge.maxN = p->maxN; ge.maxCN = p->maxCN; ge.Kmax = p->Kmax;
     ge.lpp = std::min(spp, 64);
     ge.ppw = 64 / ge.lpp;
-    const int ppb = 4 * ge.ppw;
     ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
     ge.lds_bwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 6) + 2 * (size_t)p->maxN + p->maxCN);
-    ge.lds_pen = sizeof(double) * ((size_t)ppb * 19 + (size_t)ppb * p->Kmax * 6 + 4 * 64 * 21);
+    ge.lds_pen = sizeof(double) * ((size_t)ge.ppw * 19 + (size_t)ge.ppw * (p->Kmax + 1) * 4 + 64 * 21);
     ge.solver = frx::SOLVER_KNOT_PCR;
     ge.knot_threads = 64 * ((p->maxN + 63) / 64);
     {
@@ -457,7 +460,18 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse));
     CR(p->d_coarse_iv.upload(coarse_iv)); CR(p->d_coarse_fbeg.upload(coarse_fbeg));
     CR(p->d_wp_vbeg.upload(wp_vbeg)); CR(p->d_wp_nv.upload(wp_nv)); CR(p->d_wp_xbeg.upload(wp_xbeg));
-    CR(p->d_head.upload(head)); CR(p->d_tail.upload(tail)); CR(p->d_hrec.upload(hrec)); CR(p->d_vrec.upload(vrec));
+    CR(p->d_head.upload(head)); CR(p->d_tail.upload(tail)); {
+        // per-piece corridor blocks, padded to Kmax: one contiguous, index-free read per piece in k_penalty
+        const int hs = (p->Kmax + 1) * 4;
+        std::vector<double> hblk((size_t)p->P * hs, 0.0);
+        for (int gp = 0; gp < p->P; gp++) {
+            double *blk = &hblk[(size_t)gp * hs];
+            const int gc = piece_coarse[gp], K = piece_K[gp];
+            blk[0] = horg[3 * (size_t)gc]; blk[1] = horg[3 * (size_t)gc + 1]; blk[2] = horg[3 * (size_t)gc + 2]; blk[3] = (double)K;
+            std::memcpy(blk + 4, &hrec[4 * (size_t)piece_hbeg[gp]], sizeof(double) * 4 * K);
+        }
+        CR(p->d_hblk.upload(hblk));
+    } CR(p->d_vrec.upload(vrec));
     CR(p->d_x.alloc(p->NX)); CR(p->d_f.alloc(B)); CR(p->d_g.alloc(p->NX));
     CR(p->d_T.alloc(p->P)); CR(p->d_C.alloc((size_t)p->P * 18)); CR(p->d_band.alloc(p->boff[B])); CR(p->d_out20.alloc((size_t)p->P * 20));
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
@@ -481,7 +495,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p;
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
     d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
-    d.hrec = p->d_hrec.p; d.vrec = p->d_vrec.p;
+    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p;
     *out = p;
     return FRX_OK;
 }

@@ -22,8 +22,7 @@ int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, d
     return (int)hipGetLastError();
 }
 int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, const double *C, double *out20, void *stream) {
-    const int ppb = 4 * g.ppw;
-    hipLaunchKernelGGL(k_penalty, dim3((dp.P + ppb - 1) / ppb), dim3(256), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp,
+    hipLaunchKernelGGL(k_penalty, dim3((dp.P + g.ppw - 1) / g.ppw), dim3(64), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp,
                        g.ppw, g.Kmax);
     return (int)hipGetLastError();
 }

@@ -26,7 +26,8 @@ struct DevProblem {
     const int *coarse_iv, *coarse_fbeg;       // [Pc] interval count, first fine piece (global)
     // per waypoint (candidate b owns N_b-1, global index = poff[b] - b + i)
     const int *wp_vbeg, *wp_nv, *wp_xbeg;     // first vertex record, vertex count, absolute index of its xi segment in x
-    const double *hrec, *vrec;                // half-space records [..][6]; vertices [..][3] in [v0, v_r - v0] form
+    const double *hblk;                       // [P][Kmax+1][4]: {origin xyz, K}, then K x (unit normal, n.(p_k - origin) - margin), zero padded
+    const double *vrec;                       // waypoint vertices [..][3] in [v0, v_r - v0] form, waypoint order
 };
 
 enum { SOLVER_KNOT_PCR = 0, SOLVER_BANDED_LU = 1 };

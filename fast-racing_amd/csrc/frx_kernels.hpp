@@ -12,7 +12,7 @@
 // HBM layout (all FP64):
 //   C      [P][6][3]    piece-major coefficients, 144 B per piece (P = fine pieces of the whole batch)
 //   T      [P]          piece durations
-//   hrec   [sumK][6]    half-space records (unit normal, point), CSR by polytope
+//   hblk   [P][Kmax+1][4]  per-piece corridor block: {origin xyz, K} then K x (unit normal, c = n.(p - org) - margin)
 //   out20  [P][20]      per-piece partials {cost, gdT, gdC[6][3]} written by k_penalty
 //   band   [sum 6N_b*13] LU factors per candidate, row-window layout A(i,j) → [i*13 + (j-i+6)]
 //   x, g   packed per candidate (tau[dimT], xi[...]);  f [B]
@@ -180,79 +180,79 @@ __global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_penalty: block = 256 (4 waves); each wave owns ppw = 64/lpp consecutive pieces, lpp =
-// min(kappa+1, 64) lanes per piece, lane = one quadrature sample (strided when kappa+1 > 64).
-// Dynamic LDS: cS[ppb*18] | tS[ppb] | hsS[ppb*Kmax*6] | red[4][64*21]
+// k_penalty: ONE WAVE per workgroup; the wave owns ppw = 64/lpp consecutive pieces, lpp = min(kappa+1, 64)
+// lanes per piece, lane = one quadrature sample (strided when kappa+1 > 64).
+// Every global read of the wave is an independent, contiguous, coalesced sweep issued up front (coefficients,
+// durations, and the pieces' corridor blocks hblk[gp] = {origin xyz, K | K x (unit normal, c)} padded to Kmax):
+// no index-dependent second round of loads, no block-wide barrier (PMC on the 4-wave version: 61 % of wave
+// cycles parked on s_waitcnt/s_barrier behind three dependent load rounds).
+// Dynamic LDS (doubles): cS[ppw*18] | tS[ppw] | hS[ppw*(Kmax+1)*4] | red[64*21]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
-                                                 double *__restrict__ out20, int lpp, int ppw, int Kmax) {
+__global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                   double *__restrict__ out20, int lpp, int ppw, int Kmax) {
     extern __shared__ double sm[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int ppb = 4 * ppw;
-    const int gp0 = blockIdx.x * ppb;
-    const int npieces = min(ppb, dp.P - gp0);
+    const int lane = threadIdx.x;
+    const int gp0 = blockIdx.x * ppw;
+    const int npieces = min(ppw, dp.P - gp0);
+    const int hstride = (Kmax + 1) * 4;
     double *cS = sm;
-    double *tS = cS + ppb * 18;
-    double *hsS = tS + ppb;
-    double *red = hsS + (size_t)ppb * Kmax * 6 + (size_t)wave * 64 * 21;
+    double *tS = cS + ppw * 18;
+    double *hS = tS + ppw;
+    double *red = hS + (size_t)ppw * hstride;
 
-    // stage coefficients, durations and corridor polytopes (contiguous, coalesced reads)
-    for (int i = tid; i < npieces * 18; i += 256) cS[i] = C[(size_t)gp0 * 18 + i];
-    for (int i = tid; i < npieces; i += 256) tS[i] = T[gp0 + i];
-    const int recs = Kmax * 6;
-    for (int i = tid; i < npieces * recs; i += 256) {
-        const int p = i / recs, r = i - p * recs;
-        const int gp = gp0 + p;
-        if (r < dp.piece_K[gp] * 6) hsS[i] = dp.hrec[(size_t)dp.piece_hbeg[gp] * 6 + r];
+    {
+        const double *csrc = C + (size_t)gp0 * 18, *hsrc = dp.hblk + (size_t)gp0 * hstride;
+        const int nc = npieces * 18, nh = npieces * hstride;
+#pragma unroll 4
+        for (int i = lane; i < nh; i += 64) hS[i] = hsrc[i];
+        for (int i = lane; i < nc; i += 64) cS[i] = csrc[i];
+        if (lane < npieces) tS[lane] = T[gp0 + lane];
     }
     __syncthreads();
 
     const int pl = lane / lpp, jl = lane - pl * lpp;
-    const int p = wave * ppw + pl;
-    const bool active = pl < ppw && p < npieces;
-    double acc[20];
-#pragma unroll
-    for (int v = 0; v < 20; v++) acc[v] = 0.0;
+    const bool active = pl < npieces;
+    double *mine = red + lane * 21;
     if (active) {
-        const int gp = gp0 + p;
-        const double *c = cS + p * 18;
-        const double *hs = hsS + (size_t)p * recs;
-        const int K = dp.piece_K[gp];
+        const double *c = cS + pl * 18;
+        const volatile double *c2 = c;                         // forces the late re-evaluation documented in frx_math.hpp
+        const double *hb = hS + (size_t)pl * hstride;
+        const int K = (int)hb[3];
         const int kappa = dp.kappa;
-        const double step = tS[p] / kappa;                       // CPU.hpp:245
+        const double step = tS[pl] / kappa;                      // CPU.hpp:245
         const double invK = 1.0 / kappa;
+        bool first = true;
         for (int j = jl; j <= kappa; j += lpp) {
             const double s1 = step * j;                           // sample abscissa as cc.cu:152
             const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
-            const double alpha = invK * j;                        // CPU.hpp:259
             double adj[12], Ps, gTa;
-            penalty_sample(c, s1, omg * step, dp.pc, hs, K, adj, Ps, gTa);
+            penalty_sample(c, c2, s1, omg * step, dp.pc, hb, hb + 4, K, adj, Ps, gTa);
+            FRX_PHASE();
+            // outputs go straight to this lane's LDS slot (nothing is kept in registers across samples)
+            const double v0 = omg * step * Ps, v1 = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
             const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-            acc[0] += omg * step * Ps;
-            acc[1] += alpha * gTa + omg * Ps / kappa;
             const double b0[6] = {1.0, s1, s2, s3, s4, s5};
             const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
             const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
             const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+            if (first) { mine[0] = v0; mine[1] = v1; } else { mine[0] += v0; mine[1] += v1; }
 #pragma unroll
             for (int k = 0; k < 6; k++)
 #pragma unroll
-                for (int d = 0; d < 3; d++)
-                    acc[2 + 3 * k + d] += b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
+                for (int d = 0; d < 3; d++) {
+                    const double v = b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
+                    if (first) mine[2 + 3 * k + d] = v; else mine[2 + 3 * k + d] += v;
+                }
+            first = false;
         }
     }
-#pragma unroll
-    for (int v = 0; v < 20; v++) red[lane * 21 + v] = acc[v];
     __syncthreads();
     // fixed-order reduction over the samples of each piece: lane = (piece-in-wave, value)
-    for (int idx = lane; idx < ppw * 20; idx += 64) {
+    for (int idx = lane; idx < npieces * 20; idx += 64) {
         const int p2 = idx / 20, v = idx - p2 * 20;
-        const int pp = wave * ppw + p2;
-        if (pp < npieces) {
-            double s = 0.0;
-            for (int l = 0; l < lpp; l++) s += red[(p2 * lpp + l) * 21 + v];
-            out20[(size_t)(gp0 + pp) * 20 + v] = s;
-        }
+        double s = 0.0;
+        for (int l = 0; l < lpp; l++) s += red[(p2 * lpp + l) * 21 + v];
+        out20[(size_t)gp0 * 20 + idx] = s;
     }
 }
 

@@ -28,6 +28,13 @@
 #else
 #define FRX_HD inline
 #endif
+// phase boundary for the instruction scheduler (device only): keeps the register-hungry phases of a sample from
+// being interleaved for ILP, which costs occupancy on a kernel that is FP64-issue bound anyway
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FRX_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FRX_PHASE() ((void)0)
+#endif
 
 namespace frx {
 
@@ -46,145 +53,189 @@ FRX_HD void cross3(const double *a, const double *b, double *r) {
     r[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// W = dxB^T U0 + dyB^T U1 + dzB^T U2 for the flat-output frame (xB, yB, zB)(h) without forming the Jacobians:
+//   G(h)((0, -P'z, P'y) + U2 + U0 x yB),  P' = G(czB)(U1 + zB x U0),  G(x) v = (v - x^ (x^.v)) / |x|   (file header)
+FRX_HD void frame_reverse(const double *U0, const double *U1, const double *U2, const double *zB, const double *yB, double invF,
+                          double invM, double *W) {
+    double zxU0[3], U0xy[3];
+    cross3(zB, U0, zxU0);
+    cross3(U0, yB, U0xy);
+    const double Pv[3] = {U1[0] + zxU0[0], U1[1] + zxU0[1], U1[2] + zxU0[2]};
+    const double yP = yB[1] * Pv[1] + yB[2] * Pv[2];
+    const double Pp1 = (Pv[1] - yB[1] * yP) * invM, Pp2 = (Pv[2] - yB[2] * yP) * invM;
+    const double q[3] = {U2[0] + U0xy[0], U2[1] + U0xy[1] - Pp2, U2[2] + U0xy[2] + Pp1};
+    const double zq = dot3(zB, q);
+    W[0] = (q[0] - zB[0] * zq) * invF; W[1] = (q[1] - zB[1] * zq) * invF; W[2] = (q[2] - zB[2] * zq) * invF;
+}
+
+// Evaluate derivative `D` (0..4) of the quintic c[k*3+d] at s1 for the three axes.
+template <int D, class CP> FRX_HD void poly_eval(CP c, double s1, double *out) {
+    const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double c1 = c[3 + d], c2 = c[6 + d], c3 = c[9 + d], c4 = c[12 + d], c5 = c[15 + d];
+        if (D == 0) out[d] = c[d] + c1 * s1 + c2 * s2 + c3 * s3 + c4 * s4 + c5 * (s4 * s1);
+        if (D == 1) out[d] = c1 + c2 * (2.0 * s1) + c3 * (3.0 * s2) + c4 * (4.0 * s3) + c5 * (5.0 * s4);
+        if (D == 2) out[d] = c2 * 2.0 + c3 * (6.0 * s1) + c4 * (12.0 * s2) + c5 * (20.0 * s3);
+        if (D == 3) out[d] = c3 * 6.0 + c4 * (24.0 * s1) + c5 * (60.0 * s2);
+        if (D == 4) out[d] = c4 * 24.0 + c5 * (120.0 * s1);
+    }
+}
+
 // One quadrature sample of piece coefficients c[k*3+d] (k = power, d = axis) at local time s1.
 //   ws    = omega * step  (trapezoid weight x step, CPU.hpp:245,306)
-//   hs    = K half-space records (n_x,n_y,n_z,p_x,p_y,p_z), unit normals
+//   hs    = K half-space records, 4 doubles each: (n_x, n_y, n_z, c) with unit normal and
+//           c = n.(p_k - org) - safeMargin, so that  n.(pos - p_k) + safeMargin = n.(pos - org) - c.
+//           `org` is a per-polytope origin (the point of its first half-space): the subtraction pos - org is
+//           done once per sample and keeps the magnitudes at corridor scale (metres), as pos - p_k does in
+//           CPU.hpp:325.
+//   c2    = the same coefficients again; the device passes a volatile-qualified alias of the LDS copy so that
+//           vel/acc/jer/sna and everything derived from them are evaluated AFTER the half-space loop from a
+//           fresh LDS read instead of being kept live across it (occupancy); the host passes c itself.
 //   adj   = out: a0,a1,a2,a3 (12 doubles), already weighted by ws
 //   Psum  = out: sum of chi*viol^3 (not weighted)
 //   gTalpha = out: a0.v + a1.a + a2.j + a3.s  (to be multiplied by alpha = j/kappa)
-FRX_HD void penalty_sample(const double *c, double s1, double ws, const PenaltyConst &pc,
+template <class CPtr2>
+FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, const PenaltyConst &pc, const double *org,
                            const double *hs, int K, double *adj, double &Psum, double &gTalpha) {
-    const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2;
-    // beta rows as in CPU.hpp:254-258; beta0[5] = s5 is only needed for pos
-    const double s5 = s4 * s1;
-    double pos[3], vel[3], acc[3], jer[3], sna[3];
+    // ---- phase A: position and attitude only (CPU.hpp:260-279); everything else is evaluated after the loop ----
+    double pl[3], zB[3], yB[3], xB[3], invF, invM;
+    {
+        double pos[3], acc[3];
+        poly_eval<0>(c, s1, pos);
+        poly_eval<2>(c, s1, acc);
+        const double h[3] = {acc[0], acc[1], acc[2] + pc.gAcc};
+        invF = 1.0 / sqrt(dot3(h, h));
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        const double c0 = c[d], c1 = c[3 + d], c2 = c[6 + d], c3 = c[9 + d], c4 = c[12 + d], c5 = c[15 + d];
-        pos[d] = c0 + c1 * s1 + c2 * s2 + c3 * s3 + c4 * s4 + c5 * s5;
-        vel[d] = c1 + c2 * (2.0 * s1) + c3 * (3.0 * s2) + c4 * (4.0 * s3) + c5 * (5.0 * s4);
-        acc[d] = c2 * 2.0 + c3 * (6.0 * s1) + c4 * (12.0 * s2) + c5 * (20.0 * s3);
-        jer[d] = c3 * 6.0 + c4 * (24.0 * s1) + c5 * (60.0 * s2);
-        sna[d] = c4 * 24.0 + c5 * (120.0 * s1);
+        for (int d = 0; d < 3; d++) { zB[d] = h[d] * invF; pl[d] = pos[d] - org[d]; }
+        invM = 1.0 / sqrt(zB[2] * zB[2] + zB[1] * zB[1]);
+        yB[0] = 0.0; yB[1] = zB[2] * invM; yB[2] = -zB[1] * invM;
+        cross3(yB, zB, xB);
     }
-
-    // attitude from differential flatness (CPU.hpp:266-279)
-    const double h[3] = {acc[0], acc[1], acc[2] + pc.gAcc};
-    const double f2 = dot3(h, h);
-    const double fThr = sqrt(f2);
-    const double invF = 1.0 / fThr;
-    const double zB[3] = {h[0] * invF, h[1] * invF, h[2] * invF};
-    const double m2 = zB[2] * zB[2] + zB[1] * zB[1];
-    const double mN = sqrt(m2);
-    const double invM = 1.0 / mN;
-    const double yB[3] = {0.0, zB[2] * invM, -zB[1] * invM};
-    double xB[3];
-    cross3(yB, zB, xB);
-
-    // body rate (CPU.hpp:285-292)
-    const double r0 = dot3(xB, jer), r1 = dot3(yB, jer);
-    const double sqrMagThr = fThr * fThr;
-    const double b0 = r0 * invF, b1 = r1 * invF;
-    const double sqrMagBdr = b1 * b1 + b0 * b0;
-
-    const double violaVel = dot3(vel, vel) - pc.vMaxSqr;       // CPU.hpp:301-304
-    const double violaThrl = pc.thrMinSqr - sqrMagThr;
-    const double violaThrh = sqrMagThr - pc.thrMaxSqr;
-    const double violaBdr = sqrMagBdr - pc.bdrMaxSqr;
+    FRX_PHASE();
 
     double a0[3] = {0, 0, 0};
     double U0[3] = {0, 0, 0}, U1[3] = {0, 0, 0}, U2[3] = {0, 0, 0};
     double P = 0.0;
     bool needReverse = false;
 
-    // corridor half-spaces (CPU.hpp:310-345); the sign test avoids the sqrt unless violated
-    const double e0 = pc.ell[0], e1 = pc.ell[1], e2 = pc.ell[2];
-    double Pcorr = 0.0;
-    for (int k = 0; k < K; k++) {
-        const double *rec = hs + 6 * k;
-        const double n[3] = {rec[0], rec[1], rec[2]};
-        const double dp[3] = {pos[0] - rec[3], pos[1] - rec[4], pos[2] - rec[5]};
-        const double w0 = dot3(xB, n) * e0, w1 = dot3(yB, n) * e1, w2 = dot3(zB, n) * e2;   // (R^T n) .* ellipsoid
-        const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
-        const double nd = dot3(n, dp);
-        const double d0 = nd + pc.safeMargin;
-        if (d0 >= 0.0 || eN2 > d0 * d0) {
-            const double eNorm = sqrt(eN2);
-            const double sd = (nd + eNorm) + pc.safeMargin;       // CPU.hpp:325,328
-            if (sd > 0.0) {
-                const double sd2 = sd * sd;
-                const double cw = ws * pc.chi[0] * 3.0 * sd2;
-                const double ie = 1.0 / eNorm;
-                const double g0 = w0 * ie * e0, g1 = w1 * ie * e1, g2 = w2 * ie * e2;   // eNormGd, CPU.hpp:324,326
-                const double cg0 = cw * g0, cg1 = cw * g1, cg2 = cw * g2;
+    // ---- corridor half-spaces (CPU.hpp:310-345); the sign test avoids the sqrt unless violated ----
+    {
+        const double e0 = pc.ell[0], e1 = pc.ell[1], e2 = pc.ell[2];
+        double Pcorr = 0.0;
+        for (int k = 0; k < K; k++) {
+            const double *rec = hs + 4 * k;
+            const double n[3] = {rec[0], rec[1], rec[2]};
+            // (R^T n) .* ellipsoid
+            const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
+            const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
+            const double d0 = dot3(n, pl) - rec[3];                    // n.(pos - p_k) + safeMargin
+            if (d0 >= 0.0 || eN2 > d0 * d0) {
+                const double eNorm = sqrt(eN2);
+                const double sd = d0 + eNorm;                          // CPU.hpp:325,328
+                if (sd > 0.0) {
+                    const double sd2 = sd * sd;
+                    const double cw = ws * pc.chi[0] * 3.0 * sd2;
+                    const double ie = cw / eNorm;
+                    const double cg0 = w0 * ie * e0, cg1 = w1 * ie * e1, cg2 = w2 * ie * e2;   // cw * eNormGd, CPU.hpp:324,326
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    a0[d] += cw * n[d];
-                    U0[d] += cg0 * n[d];
-                    U1[d] += cg1 * n[d];
-                    U2[d] += cg2 * n[d];
+                    for (int d = 0; d < 3; d++) {
+                        a0[d] += cw * n[d];
+                        U0[d] += cg0 * n[d];
+                        U1[d] += cg1 * n[d];
+                        U2[d] += cg2 * n[d];
+                    }
+                    Pcorr += sd * sd2;
+                    needReverse = true;
                 }
-                Pcorr += sd * sd2;
-                needReverse = true;
             }
         }
+        P += pc.chi[0] * Pcorr;
     }
-    P += pc.chi[0] * Pcorr;
+    FRX_PHASE();
 
-    double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0}, a3[3] = {0, 0, 0};
-    if (violaVel > 0.0) {                                       // CPU.hpp:347-359
-        const double v2 = violaVel * violaVel;
-        const double wV = ws * pc.chi[1] * 3.0 * v2 * 2.0;
-        a1[0] = wV * vel[0]; a1[1] = wV * vel[1]; a1[2] = wV * vel[2];
-        P += pc.chi[1] * (v2 * violaVel);
-    }
-    double wH = 0.0;                                            // weight on dSqrMagThr = 2h
-    if (violaThrl > 0.0) {                                      // CPU.hpp:361-372
-        const double v2 = violaThrl * violaThrl;
-        wH -= ws * pc.chi[2] * 3.0 * v2;
-        P += pc.chi[2] * (v2 * violaThrl);
-    }
-    if (violaThrh > 0.0) {                                      // CPU.hpp:374-385
-        const double v2 = violaThrh * violaThrh;
-        wH += ws * pc.chi[2] * 3.0 * v2;
-        P += pc.chi[2] * (v2 * violaThrh);
-    }
-    if (violaBdr > 0.0) {                                       // CPU.hpp:387-398
-        const double v2 = violaBdr * violaBdr;
-        const double wB = ws * pc.chi[3] * 3.0 * v2;
-        const double k2 = wB * 2.0 * invF * invF;
-        // d(omega^2)/d jer = (2/f^2)(r0 xB + r1 yB)   (= dJerSqrMagBdr, CPU.hpp:297-299)
+    // ---- phase B: limits (CPU.hpp:281-304, 347-398) and reverse passes, one derivative at a time so that
+    //      vel/acc/jer/sna are never live together; gTalpha = a0.v + a1.a + a2.j + a3.s is accumulated on the way ----
+    double a2[3] = {0, 0, 0};
+    if (needReverse) frame_reverse(U0, U1, U2, zB, yB, invF, invM, a2);      // corridor part of d pen / d acc
+    FRX_PHASE();
+    double gT;
+    {   // velocity limit (CPU.hpp:347-359)
+        double vel[3];
+        poly_eval<1>(c2, s1, vel);
+        gT = dot3(a0, vel);
+        const double violaVel = dot3(vel, vel) - pc.vMaxSqr;
+        double wV = 0.0;
+        if (violaVel > 0.0) {
+            const double v2 = violaVel * violaVel;
+            wV = ws * pc.chi[1] * 3.0 * v2 * 2.0;
+            P += pc.chi[1] * (v2 * violaVel);
+        }
 #pragma unroll
-        for (int d = 0; d < 3; d++) a3[d] = k2 * (r0 * xB[d] + r1 * yB[d]);
-        // d(omega^2)/d h = (2/f^2)(r0 dxB^T jer + r1 dyB^T jer) - 2 omega^2 h / f^2   (= dSqrMagBdr, CPU.hpp:293-296)
-        const double k0 = k2 * r0, k1 = k2 * r1;
-#pragma unroll
-        for (int d = 0; d < 3; d++) { U0[d] += k0 * jer[d]; U1[d] += k1 * jer[d]; }
-        wH -= wB * sqrMagBdr * invF * invF;
-        P += pc.chi[3] * (v2 * violaBdr);
-        needReverse = true;
+        for (int d = 0; d < 3; d++) adj[3 + d] = wV * vel[d];
     }
-#pragma unroll
-    for (int d = 0; d < 3; d++) a2[d] = 2.0 * wH * h[d];
-
-    if (needReverse) {
-        // W = dxB^T U0 + dyB^T U1 + dzB^T U2 without forming the Jacobians (header comment)
-        double zxU0[3], U0xy[3];
-        cross3(zB, U0, zxU0);
-        cross3(U0, yB, U0xy);
-        const double Pv[3] = {U1[0] + zxU0[0], U1[1] + zxU0[1], U1[2] + zxU0[2]};
-        const double yP = dot3(yB, Pv);
-        const double Pp1 = (Pv[1] - yB[1] * yP) * invM, Pp2 = (Pv[2] - yB[2] * yP) * invM;   // G(czB) Pv, rows y,z
-        const double q[3] = {U2[0] + U0xy[0], U2[1] + U0xy[1] - Pp2, U2[2] + U0xy[2] + Pp1};
-        const double zq = dot3(zB, q);
-#pragma unroll
-        for (int d = 0; d < 3; d++) a2[d] += (q[d] - zB[d] * zq) * invF;
+    FRX_PHASE();
+    double h[3], wH = 0.0;                                      // weight on dSqrMagThr = 2h
+    {   // thrust limits (CPU.hpp:361-385; both use chi[2])
+        double acc[3];
+        poly_eval<2>(c2, s1, acc);
+        gT += adj[3] * acc[0] + adj[4] * acc[1] + adj[5] * acc[2];
+        h[0] = acc[0]; h[1] = acc[1]; h[2] = acc[2] + pc.gAcc;
+        const double fThr = sqrt(dot3(h, h));
+        const double sqrMagThr = fThr * fThr;
+        const double violaThrl = pc.thrMinSqr - sqrMagThr, violaThrh = sqrMagThr - pc.thrMaxSqr;
+        if (violaThrl > 0.0) {
+            const double v2 = violaThrl * violaThrl;
+            wH -= ws * pc.chi[2] * 3.0 * v2;
+            P += pc.chi[2] * (v2 * violaThrl);
+        }
+        if (violaThrh > 0.0) {
+            const double v2 = violaThrh * violaThrh;
+            wH += ws * pc.chi[2] * 3.0 * v2;
+            P += pc.chi[2] * (v2 * violaThrh);
+        }
     }
-
+    FRX_PHASE();
+    double a3[3] = {0, 0, 0};
+    {   // body-rate limit (CPU.hpp:285-299, 387-398)
+        double jer[3];
+        poly_eval<3>(c2, s1, jer);
+        const double r0 = dot3(xB, jer), r1 = dot3(yB, jer);
+        const double b0 = r0 * invF, b1 = r1 * invF;
+        const double sqrMagBdr = b1 * b1 + b0 * b0;
+        const double violaBdr = sqrMagBdr - pc.bdrMaxSqr;
+        if (violaBdr > 0.0) {
+            const double v2 = violaBdr * violaBdr;
+            const double wB = ws * pc.chi[3] * 3.0 * v2;
+            const double k2 = wB * 2.0 * invF * invF;
+            // d(omega^2)/d jer = (2/f^2)(r0 xB + r1 yB)   (= dJerSqrMagBdr, CPU.hpp:297-299)
+#pragma unroll
+            for (int d = 0; d < 3; d++) a3[d] = k2 * (r0 * xB[d] + r1 * yB[d]);
+            // d(omega^2)/d h = (2/f^2)(r0 dxB^T jer + r1 dyB^T jer) - 2 omega^2 h / f^2   (= dSqrMagBdr, CPU.hpp:293-296)
+            const double k0 = k2 * r0, k1 = k2 * r1;
+            const double V0[3] = {k0 * jer[0], k0 * jer[1], k0 * jer[2]}, V1[3] = {k1 * jer[0], k1 * jer[1], k1 * jer[2]};
+            const double V2[3] = {0.0, 0.0, 0.0};
+            double Wb[3];
+            frame_reverse(V0, V1, V2, zB, yB, invF, invM, Wb);
+#pragma unroll
+            for (int d = 0; d < 3; d++) a2[d] += Wb[d];
+            wH -= wB * sqrMagBdr * invF * invF;
+            P += pc.chi[3] * (v2 * violaBdr);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) a2[d] += 2.0 * wH * h[d];
+        gT += dot3(a2, jer);
+    }
+    FRX_PHASE();
+    {
+        double sna[3];
+        poly_eval<4>(c2, s1, sna);
+        gT += dot3(a3, sna);
+    }
     Psum = P;
-    gTalpha = dot3(a0, vel) + dot3(a1, acc) + dot3(a2, jer) + dot3(a3, sna);
+    gTalpha = gT;
 #pragma unroll
-    for (int d = 0; d < 3; d++) { adj[d] = a0[d]; adj[3 + d] = a1[d]; adj[6 + d] = a2[d]; adj[9 + d] = a3[d]; }
+    for (int d = 0; d < 3; d++) { adj[d] = a0[d]; adj[6 + d] = a2[d]; adj[9 + d] = a3[d]; }
 }
 
 // C2 / exponential time diffeomorphism, forward and derivative (CPU.hpp:639-641, 826-839)

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q -x -s -k "independent or lockstep" 2>&1 | grep -E "cand|knot_pcr:|banded_lu:|passed|failed"
+timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+timeout 900 python scripts/kernel_sweep.py --full --states it60 2>&1 | grep -v amdgpu.ids | grep -v Traceback -A0 | grep "^{"

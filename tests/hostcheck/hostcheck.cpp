@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE — compiles the product's per-sample math header (fast-racing_amd/csrc/frx_math.hpp)
 // for the HOST so its algebra (reverse-mode adjoints instead of the reference's explicit Jacobians) can be
 // checked against the oracle on a CPU-only box.  Not part of the product library; never used as a fallback.
+#include <vector>
 #include "../../fast-racing_amd/csrc/frx_math.hpp"
 
 extern "C" void hostcheck_penalty(int N, int kappa, const double *T, const double *C, const int *hoff, const double *hrec,
@@ -16,6 +17,15 @@ extern "C" void hostcheck_penalty(int N, int kappa, const double *T, const doubl
     for (int i = 0; i < N; i++) {
         const double *c = C + 18 * i;
         double *o = out20 + 20 * i;
+        // records in device form: (unit normal, n.(p - org) - margin) with org = point of the first half-space
+        const int K = hoff[i + 1] - hoff[i];
+        const double *org = hrec + 6 * hoff[i] + 3;
+        std::vector<double> r4(4 * (size_t)K);
+        for (int k = 0; k < K; k++) {
+            const double *r = hrec + 6 * (hoff[i] + k);
+            r4[4 * k] = r[0]; r4[4 * k + 1] = r[1]; r4[4 * k + 2] = r[2];
+            r4[4 * k + 3] = r[0] * (r[3] - org[0]) + r[1] * (r[4] - org[1]) + r[2] * (r[5] - org[2]) - pc.safeMargin;
+        }
         for (int v = 0; v < 20; v++) o[v] = 0.0;
         const double step = T[i] / kappa;
         double s1acc = 0.0;
@@ -24,7 +34,7 @@ extern "C" void hostcheck_penalty(int N, int kappa, const double *T, const doubl
             const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;
             const double alpha = 1.0 / kappa * j;
             double adj[12], P, gTa;
-            frx::penalty_sample(c, s1, omg * step, pc, hrec + 6 * hoff[i], hoff[i + 1] - hoff[i], adj, P, gTa);
+            frx::penalty_sample(c, c, s1, omg * step, pc, org, r4.data(), K, adj, P, gTa);
             const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
             const double b0[6] = {1.0, s1, s2, s3, s4, s5};
             const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
