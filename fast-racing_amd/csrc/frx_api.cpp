@@ -167,8 +167,14 @@ struct frx_problem {
     DevBuf<double> d_x, d_f, d_g, d_T, d_C, d_band, d_out20;
     // pinned staging
     PinBuf<double> h_x, h_f, h_g, h_T, h_C, h_out20;
+    // device-vector L-BFGS state (allocated on first use)
+    DevBuf<double> d_xp, d_gp, d_dir, d_S, d_Y, d_ys;
+    PinBuf<frx::DvCommand> h_cmd;
+    PinBuf<frx::DvResult> h_res;
+    int dv_mem = 0;
     frx::LaunchGeom geo;
     bool banded_ok = true;
+    int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
     double stats[4] = {0, 0, 0, 0};
 };
 
@@ -642,12 +648,123 @@ static int drive_batch(int count, const int *x_off, double *x, double *g, double
     return FRX_OK;
 }
 
+static int finish_optimize(frx_problem *p, const double *x, double *C, double *T, double *jerk_cost);
+
+// Device-vector optimisation: the host runs one SolverDV (scalars + decisions) per candidate, the device owns every
+// vector.  A round = k_lbfgs_pre (history update + two-loop recursion for candidates that just accepted a step, then the
+// trial point) -> k_forward -> k_penalty -> k_backward -> k_lbfgs_post; 32 B of commands go down and 40 B of results
+// come back per candidate, through mapped host memory.
+static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals,
+                                   double *objective) {
+    const int B = p->B, m = pm.mem_size;
+    int E = 0;
+    for (int cand : {2, 4, 8}) if (p->geo.maxXb <= 256 * cand) { E = cand; break; }   // doubles per thread of k_lbfgs_pre
+    if (E == 0 || m > 512 || m < 1) return 1;                                  // caller falls back to host vectors
+    hipError_t e;
+    if (p->dv_mem != m) {
+        if ((e = p->d_xp.alloc(p->NX)) != hipSuccess || (e = p->d_gp.alloc(p->NX)) != hipSuccess || (e = p->d_dir.alloc(p->NX)) != hipSuccess ||
+            (e = p->d_S.alloc((size_t)m * B * 256 * E)) != hipSuccess || (e = p->d_Y.alloc((size_t)m * B * 256 * E)) != hipSuccess ||
+            (e = p->d_ys.alloc((size_t)B * m)) != hipSuccess || (e = p->h_cmd.alloc(B)) != hipSuccess || (e = p->h_res.alloc(B)) != hipSuccess)
+            return fail(FRX_ERR_ALLOC, std::string("device-vector L-BFGS buffers: ") + hipGetErrorString(e));
+        // zero padding of the history slices is relied upon by the unconditional 16-byte loads of k_lbfgs_pre
+        if ((e = hipMemset(p->d_S.p, 0, sizeof(double) * (size_t)m * B * 256 * E)) != hipSuccess || (e = hipMemset(p->d_Y.p, 0, sizeof(double) * (size_t)m * B * 256 * E)) != hipSuccess)
+            return fail(FRX_ERR_HIP, hipGetErrorString(e));
+        p->dv_mem = m;
+    }
+    frx::DvLaunch dv;
+    dv.xoff = p->d_xoff.p; dv.x = p->d_x.p; dv.g = p->d_g.p; dv.xp = p->d_xp.p; dv.gp = p->d_gp.p; dv.d = p->d_dir.p;
+    dv.S = p->d_S.p; dv.Y = p->d_Y.p; dv.ys = p->d_ys.p; dv.ld = (size_t)p->NX; dv.m = m; dv.B = B; dv.E = E;
+    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+    HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_ys.p, 0, sizeof(double) * (size_t)B * m, p->stream));
+    std::vector<frx::SolverDV> sv(B);
+    for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, p->h_cmd.p + b);
+    auto wait_stream = [&]() -> hipError_t {
+        for (;;) {
+            hipError_t q = hipStreamQuery(p->stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            __builtin_ia32_pause();
+        }
+    };
+    double t_dev = 0.0, t_host = 0.0;
+    long rounds = 0;
+    const auto t0 = clk::now();
+    for (;;) {
+        bool any_eval = false, any_cmd = false;
+        for (int b = 0; b < B; b++) { any_eval |= (p->h_cmd.p[b].flags & frx::DV_EVAL) != 0; any_cmd |= p->h_cmd.p[b].flags != 0; }
+        if (!any_cmd) break;
+        auto td = clk::now();
+        HIP_TRY((hipError_t)frx::launch_lbfgs_pre(dv, p->h_cmd.p, p->h_res.p, p->stream));
+        if (any_eval) {
+            HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
+            HIP_TRY((hipError_t)frx::launch_lbfgs_post(dv, p->d_f.p, p->h_cmd.p, p->h_res.p, p->stream));
+        }
+        HIP_TRY(wait_stream());
+        t_dev += ms_since(td);
+        auto th = clk::now();
+        for (int b = 0; b < B; b++) {
+            frx::DvCommand &c = p->h_cmd.p[b];
+            const bool evaluated = (c.flags & frx::DV_EVAL) != 0;
+            if (!evaluated) { c.flags = 0; continue; }                         // a RESTORE has been executed
+            sv[b].feed(p->h_res.p[b]);
+        }
+        t_host += ms_since(th);
+        rounds++;
+    }
+    p->stats[0] = ms_since(t0); p->stats[1] = t_dev; p->stats[2] = t_host; p->stats[3] = (double)rounds;
+    HIP_TRY(hipMemcpyAsync(p->h_x.p, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::memcpy(x, p->h_x.p, sizeof(double) * p->NX);
+    for (int b = 0; b < B; b++) {
+        status[b] = sv[b].status();
+        if (iters) iters[b] = sv[b].iterations();
+        if (evals) evals[b] = sv[b].evaluations();
+        if (objective) objective[b] = sv[b].value();
+    }
+    return FRX_OK;
+}
+
+// final generate (CPU.hpp:1258-1263) and the reference's return value (CPU.hpp:1267)
+static int finish_optimize(frx_problem *p, const double *x, double *C, double *T, double *jerk_cost) {
+    int rc;
+    std::vector<double> Tt(p->P), Cc((size_t)p->P * 18);
+    rc = frx_forward(p, x, Tt.data(), Cc.data());
+    if (rc != FRX_OK) return rc;
+    if (T) std::copy(Tt.begin(), Tt.end(), T);
+    if (C) std::copy(Cc.begin(), Cc.end(), C);
+    if (jerk_cost) {
+        for (int b = 0; b < p->B; b++) {
+            double obj = 0.0;                                            // getTrajJerkCost, CPU.hpp:507-520
+            for (int gp = p->poff[b]; gp < p->poff[b + 1]; gp++) {
+                const double *c3 = &Cc[18 * (size_t)gp + 9], *c4 = c3 + 3, *c5 = c3 + 6;
+                const double t1 = Tt[gp], t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+                obj += 36.0 * frx::dot3(c3, c3) * t1 + 144.0 * frx::dot3(c4, c3) * t2 + 192.0 * frx::dot3(c4, c4) * t3 +
+                       240.0 * frx::dot3(c5, c3) * t3 + 720.0 * frx::dot3(c5, c4) * t4 + 720.0 * frx::dot3(c5, c5) * t5;
+            }
+            jerk_cost[b] = obj;
+        }
+    }
+    return FRX_OK;
+}
+
+
 extern "C" {
 
 int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, double *C, double *T, double *jerk_cost,
                  double *objective, int *status, int *iters, int *evals) {
     if (!p || !params || !x || !status) return fail(FRX_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
+    // FRX_LBFGS=host keeps every vector on the host (bit-identical to the reference solver given identical f, g);
+    // the default keeps the vectors on the device and only the line-search decisions on the host.
+    const char *lb_env = std::getenv("FRX_LBFGS");
+    const bool want_device_vectors = !(lb_env && lb_env[0] == 'h') && p->lbfgs_mode != 1;
+    int rc_dv = 1;
+    if (want_device_vectors) {
+        rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective);
+        if (rc_dv < 0) return rc_dv;
+    }
+    if (rc_dv == 0) return finish_optimize(p, x, C, T, jerk_cost);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     int nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)p->B));
     if (const char *ht = std::getenv("FRX_HOST_THREADS")) nt = std::max(1, std::min(std::atoi(ht), p->B));
@@ -686,25 +803,7 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
                          eval_all);
     if (rc != FRX_OK) return rc;
     std::memcpy(x, p->h_x.p, sizeof(double) * p->NX);
-    // final generate (CPU.hpp:1258-1263) and the reference's return value (CPU.hpp:1267)
-    std::vector<double> Tt(p->P), Cc((size_t)p->P * 18);
-    rc = frx_forward(p, x, Tt.data(), Cc.data());
-    if (rc != FRX_OK) return rc;
-    if (T) std::copy(Tt.begin(), Tt.end(), T);
-    if (C) std::copy(Cc.begin(), Cc.end(), C);
-    if (jerk_cost) {
-        for (int b = 0; b < p->B; b++) {
-            double obj = 0.0;                                            // getTrajJerkCost, CPU.hpp:507-520
-            for (int gp = p->poff[b]; gp < p->poff[b + 1]; gp++) {
-                const double *c3 = &Cc[18 * (size_t)gp + 9], *c4 = c3 + 3, *c5 = c3 + 6;
-                const double t1 = Tt[gp], t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
-                obj += 36.0 * frx::dot3(c3, c3) * t1 + 144.0 * frx::dot3(c4, c3) * t2 + 192.0 * frx::dot3(c4, c4) * t3 +
-                       240.0 * frx::dot3(c5, c3) * t3 + 720.0 * frx::dot3(c5, c4) * t4 + 720.0 * frx::dot3(c5, c5) * t5;
-            }
-            jerk_cost[b] = obj;
-        }
-    }
-    return FRX_OK;
+    return finish_optimize(p, x, C, T, jerk_cost);
 }
 
 int frx_optimize_stats(const frx_problem *p, double *out4) {

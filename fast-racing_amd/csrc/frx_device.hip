@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "frx_kernels.hpp"
+#include "frx_lbfgs_kernels.hpp"
 
 namespace frx {
 
@@ -34,6 +35,29 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
     else
         hipLaunchKernelGGL(k_backward, dim3(dp.B), dim3(64), g.lds_bwd, (hipStream_t)stream, dp, x, T, C, band, out20, f, grad, g.maxN,
                            g.maxCN);
+    return (int)hipGetLastError();
+}
+
+
+static DvBuffers to_buffers(const DvLaunch &dv) {
+    DvBuffers b;
+    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.m = dv.m; b.B = dv.B;
+    return b;
+}
+int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream) {
+    const DvBuffers b = to_buffers(dv);
+    const DvCommand *c = (const DvCommand *)cmd; DvResult *r = (DvResult *)res;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dv.E) {
+    case 2: hipLaunchKernelGGL(k_lbfgs_pre<2>, dim3(dv.B), dim3(256), 0, st, b, c, r); break;
+    case 4: hipLaunchKernelGGL(k_lbfgs_pre<4>, dim3(dv.B), dim3(256), 0, st, b, c, r); break;
+    case 8: hipLaunchKernelGGL(k_lbfgs_pre<8>, dim3(dv.B), dim3(256), 0, st, b, c, r); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream) {
+    hipLaunchKernelGGL(k_lbfgs_post, dim3(dv.B), dim3(64), 0, (hipStream_t)stream, to_buffers(dv), f, (const DvCommand *)cmd, (DvResult *)res);
     return (int)hipGetLastError();
 }
 

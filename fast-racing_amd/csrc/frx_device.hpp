@@ -48,4 +48,13 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
                     const double *band, const double *out20, double *f, double *grad, void *stream);
 
+
+// ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
+struct DvBuffers;
+struct DvLaunch {
+    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys; size_t ld; int m, B, E;
+};
+int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream);
+int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream);
+
 } // namespace frx

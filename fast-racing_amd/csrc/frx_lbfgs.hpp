@@ -1,16 +1,26 @@
-// Host L-BFGS as a RESUMABLE state machine.
+// Host L-BFGS as RESUMABLE state machines.
 //
 // The reference's solver is a blocking call with an evaluation callback
 // (lbfgs::lbfgs_optimize + lbfgs_evaluate_t, lbfgs.hpp:1103, :223), which cannot batch: B
 // candidates would need B separate device round trips per step.  Here every candidate owns
-// one Solver object; the driver collects the points of all candidates that are waiting for
-// an objective value, evaluates them in ONE batched device pass, and feeds the values back
-// (SURVEY.md §7.1-6).  Between two evaluations a Solver runs exactly the arithmetic of
-//   lbfgs_optimize ............ lbfgs.hpp:1103-1444
-//   line_search_morethuente ... lbfgs.hpp:730-938   (+ update_trial_interval :520-728)
-//   line_search_backtracking .. lbfgs.hpp:940-1033  (fallback when Moré–Thuente fails, :1271-1282)
-// in the same operation order, so iterates are bit-identical to the blocking solver
-// (tests/test_lbfgs.py checks that against the reference header itself).
+// one solver object; the driver collects the trial points of all candidates that are waiting
+// for an objective value, evaluates them in ONE batched device pass, and feeds the values back
+// (SURVEY.md §7.1-6).
+//
+//   LineSearch  the scalar logic of line_search_morethuente (lbfgs.hpp:730-938, with
+//               update_trial_interval :520-728) and line_search_backtracking (:940-1033), split at the
+//               evaluation so it can be resumed.  It never touches a vector: it consumes
+//               (f, dg = g.d) of a trial step and produces the next step or a verdict.
+//   Solver      host vectors: x, g, d, the (s, y) history and the two-loop recursion live in host
+//               memory and run in exactly the reference's operation order, so its iterates are
+//               bit-identical to lbfgs_optimize (tests/test_lbfgs.py checks that against the
+//               reference header itself).
+//   SolverDV    device vectors: the SAME control flow, but every O(n) operation is a command to
+//               the device (frx_lbfgs_kernels.hpp) and only scalars cross PCIe: per round and candidate
+//               the host sends {flags, step, history slot} and receives {f, g.d, x.x, g.g, g.d_new}.
+//               The decisions (Moré–Thuente / backtracking, convergence and stop tests, error codes)
+//               stay on the host, as in the reference; dot products are summed in a different
+//               (fixed, parallel) order, so iterates agree with Solver to rounding, not bitwise.
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -49,61 +59,108 @@ inline int lbfgs_check(int n, const frx_lbfgs_params &p) {   // lbfgs.hpp:1143-1
     return 0;
 }
 
-class Solver {
+// ---------------------------------------------------------------------------------------------
+// Scalar line-search logic (no vectors).  Protocol:
+//    r = mt_begin(step, f0, dginit)       r != 0: error code, no evaluation wanted
+//    loop:  evaluate f, dg at  x = xp + step()*d ;  r = mt_feed(f, dg)
+//           r == PENDING: another trial at step();  otherwise r = ls (>0 evaluations, <0 error)
+//    same with bt_begin / bt_feed.
+// ---------------------------------------------------------------------------------------------
+class LineSearch {
 public:
-    // x and g are caller-owned storage of n doubles each (the packed, pinned batch arrays):
-    // the solver writes the next trial point into x and expects the gradient at that point in g.
-    void start(int n_, double *x_, double *g_, const frx_lbfgs_params &pm_) {
-        n = n_; x = x_; g = g_; pm = pm_;
-        m = pm.mem_size;
-        ret = lbfgs_check(n, pm);
-        evals = 0; k = 0; fx = 0.0;
-        if (ret != 0) { phase = DONE; return; }
-        xp.assign(n, 0.0); gp.assign(n, 0.0); d.assign(n, 0.0);
-        S.assign((size_t)m * n, 0.0); Y.assign((size_t)m * n, 0.0);
-        alpha.assign(m, 0.0); ysv.assign(m, 0.0);
-        pf.assign(pm.past > 0 ? pm.past : 0, 0.0);
-        phase = WAIT_INITIAL;                 // first evaluation at the start point (lbfgs.hpp:1211)
-    }
-    bool done() const { return phase == DONE; }
-    int status() const { return ret; }
-    int iterations() const { return k; }
-    int evaluations() const { return evals; }
-    double value() const { return fx; }
+    static constexpr int PENDING = 1 << 30;
+    double step() const { return stp; }
 
-    // the objective value at the current x (gradient already in g)
-    void feed(double f) {
-        ++evals;
-        switch (phase) {
-        case WAIT_INITIAL: after_initial(f); break;
-        case WAIT_MT: mt_after_eval(f); break;
-        case WAIT_BT: bt_after_eval(f); break;
-        default: break;
-        }
+    int mt_begin(const frx_lbfgs_params &pm, double step0, double f0, double dginit0) {     // lbfgs.hpp:743-788
+        count = 0; brackt = 0; stage1 = 1; uinfo = 0;
+        stp = step0;
+        if (stp <= 0.) return LBERR_INVALIDPARAMETERS;
+        dginit = dginit0;
+        if (0 < dginit) return LBERR_INCREASEGRADIENT;
+        finit = f0;
+        dgtest = pm.f_dec_coeff * dginit;
+        width = pm.max_step - pm.min_step;
+        prev_width = 2.0 * width;
+        stx = sty = 0.;
+        fxl = fy = finit;
+        dgx = dgy = dginit;
+        mt_propose(pm);
+        return 0;
     }
+    int mt_feed(const frx_lbfgs_params &pm, double f, double dg) {                          // lbfgs.hpp:829-935
+        const double ftest1 = finit + stp * dgtest;
+        ++count;
+        if ((std::isinf(f) || std::isnan(f)) || (brackt && ((stp <= stmin || stmax <= stp) || uinfo != 0))) return LBERR_ROUNDING;
+        if (stp == pm.max_step && f <= ftest1 && dg <= dgtest) return LBERR_MAXIMUMSTEP;
+        if (stp == pm.min_step && (ftest1 < f || dgtest <= dg)) return LBERR_MINIMUMSTEP;
+        if (brackt && (stmax - stmin) <= pm.xtol * stmax) return LBERR_WIDTHTOOSMALL;
+        if (pm.max_linesearch <= count) return LBERR_MAXIMUMLINESEARCH;
+        if (f <= ftest1 && std::fabs(dg) <= pm.s_curv_coeff * (-dginit)) return count;
+        if (stage1 && f <= ftest1 && (pm.f_dec_coeff <= pm.s_curv_coeff ? pm.f_dec_coeff : pm.s_curv_coeff) * dginit <= dg)
+            stage1 = 0;
+        if (stage1 && ftest1 < f && f <= fxl) {
+            double fm = f - stp * dgtest, fxm = fxl - stx * dgtest, fym = fy - sty * dgtest;
+            double dgm = dg - dgtest, dgxm = dgx - dgtest, dgym = dgy - dgtest;
+            uinfo = update_trial(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, stmin, stmax, brackt);
+            fxl = fxm + stx * dgtest;
+            fy = fym + sty * dgtest;
+            dgx = dgxm + dgtest;
+            dgy = dgym + dgtest;
+        } else {
+            double ff = f, dgg = dg;
+            uinfo = update_trial(stx, fxl, dgx, sty, fy, dgy, stp, ff, dgg, stmin, stmax, brackt);
+        }
+        if (brackt) {
+            if (0.66 * prev_width <= std::fabs(sty - stx)) stp = stx + 0.5 * (sty - stx);
+            prev_width = width;
+            width = std::fabs(sty - stx);
+        }
+        mt_propose(pm);
+        return PENDING;
+    }
+
+    int bt_begin(double step0, double f0, double dginit0, const frx_lbfgs_params &pm) {      // lbfgs.hpp:954-974
+        count = 0;
+        stp = step0;
+        if (stp <= 0.) return LBERR_INVALIDPARAMETERS;
+        dginit = dginit0;
+        if (0 < dginit) return LBERR_INCREASEGRADIENT;
+        finit = f0;
+        dgtest = pm.f_dec_coeff * dginit;
+        return 0;
+    }
+    // dg is only consulted when the sufficient-decrease test passes, like the reference (lbfgs.hpp:986-1010)
+    int bt_feed(const frx_lbfgs_params &pm, double f, double dg) {
+        const double dec = 0.5, inc = 2.1;
+        double wd;
+        ++count;
+        if (f > finit + stp * dgtest) wd = dec;
+        else {
+            if (dg < pm.s_curv_coeff * dginit) wd = inc;
+            else if (dg > -pm.s_curv_coeff * dginit) wd = dec;
+            else return count;
+        }
+        if (stp < pm.min_step) return LBERR_MINIMUMSTEP;
+        if (stp > pm.max_step) return LBERR_MAXIMUMSTEP;
+        if (pm.max_linesearch <= count) return LBERR_MAXIMUMLINESEARCH;
+        stp *= wd;
+        return PENDING;
+    }
+    bool bt_needs_dg(double f) const { return !(f > finit + stp * dgtest); }
 
 private:
-    enum Phase { WAIT_INITIAL, WAIT_MT, WAIT_BT, DONE };
-    int n = 0, m = 0;
-    double *x = nullptr, *g = nullptr;
-    frx_lbfgs_params pm;
-    Phase phase = DONE;
-    int ret = 0, k = 0, end = 0, evals = 0;
-    double fx = 0, step = 0, stepp = 0, fp = 0;
-    std::vector<double> xp, gp, d, S, Y, alpha, ysv, pf;
-
-    // Moré–Thuente locals (lbfgs.hpp:743-752)
     int count = 0, brackt = 0, stage1 = 0, uinfo = 0;
-    double stx, fxl, dgx, sty, fy, dgy, finit, dginit, dgtest, width, prev_width, stmin, stmax;
-    double *stp = nullptr;
+    double stp = 0, stx = 0, fxl = 0, dgx = 0, sty = 0, fy = 0, dgy = 0, finit = 0, dginit = 0, dgtest = 0, width = 0, prev_width = 0,
+           stmin = 0, stmax = 0;
 
-    static double vdot(const double *a, const double *b, int n) {
-        double s = 0.;
-        for (int i = 0; i < n; ++i) s += a[i] * b[i];
-        return s;
-    }
-    static void vadd(double *y, const double *v, double c, int n) {
-        for (int i = 0; i < n; ++i) y[i] += c * v[i];
+    void mt_propose(const frx_lbfgs_params &pm) {             // loop head up to the evaluation, lbfgs.hpp:790-826
+        if (brackt) { stmin = stx <= sty ? stx : sty; stmax = stx >= sty ? stx : sty; }
+        else        { stmin = stx; stmax = stp + 4.0 * (stp - stx); }
+        if (stp < pm.min_step) stp = pm.min_step;
+        if (pm.max_step < stp) stp = pm.max_step;
+        if ((brackt && ((stp <= stmin || stmax <= stp) || pm.max_linesearch <= count + 1 || uinfo != 0)) ||
+            (brackt && (stmax - stmin <= pm.xtol * stmax)))
+            stp = stx;
     }
 
     // ---- interpolants, lbfgs.hpp:318-406 ----
@@ -145,7 +202,6 @@ private:
         const double a = u - v;
         return v + dv / (dv - du) * a;
     }
-
     // update_trial_interval, lbfgs.hpp:520-728
     static int update_trial(double &xs, double &fxs, double &dxs, double &ys, double &fys, double &dys,
                             double &t, double &ft, double &dt, double tmin, double tmax, int &br) {
@@ -194,8 +250,80 @@ private:
         t = newt;
         return 0;
     }
+};
 
+// ---------------------------------------------------------------------------------------------
+// Host-vector solver: bit-identical to lbfgs::lbfgs_optimize.
+// ---------------------------------------------------------------------------------------------
+class Solver {
+public:
+    // x and g are caller-owned storage of n doubles each: the solver writes the next trial point into x and
+    // expects the gradient at that point in g.
+    void start(int n_, double *x_, double *g_, const frx_lbfgs_params &pm_) {
+        n = n_; x = x_; g = g_; pm = pm_;
+        m = pm.mem_size;
+        ret = lbfgs_check(n, pm);
+        evals = 0; k = 0; fx = 0.0;
+        if (ret != 0) { phase = DONE; return; }
+        xp.assign(n, 0.0); gp.assign(n, 0.0); d.assign(n, 0.0);
+        S.assign((size_t)m * n, 0.0); Y.assign((size_t)m * n, 0.0);
+        alpha.assign(m, 0.0); ysv.assign(m, 0.0);
+        pf.assign(pm.past > 0 ? pm.past : 0, 0.0);
+        phase = WAIT_INITIAL;                 // first evaluation at the start point (lbfgs.hpp:1211)
+    }
+    bool done() const { return phase == DONE; }
+    int status() const { return ret; }
+    int iterations() const { return k; }
+    int evaluations() const { return evals; }
+    double value() const { return fx; }
+
+    // the objective value at the current x (gradient already in g)
+    void feed(double f) {
+        ++evals;
+        switch (phase) {
+        case WAIT_INITIAL: after_initial(f); break;
+        case WAIT_MT: {
+            fx = f;
+            const double dg = vdot(g, d.data(), n);                      // lbfgs.hpp:830
+            const int r = ls.mt_feed(pm, f, dg);
+            if (r == LineSearch::PENDING) propose(); else linesearch_result(r, true);
+            break;
+        }
+        case WAIT_BT: {
+            fx = f;
+            const double dg = ls.bt_needs_dg(f) ? vdot(g, d.data(), n) : 0.0;   // lbfgs.hpp:993
+            const int r = ls.bt_feed(pm, f, dg);
+            if (r == LineSearch::PENDING) propose(); else linesearch_result(r, false);
+            break;
+        }
+        default: break;
+        }
+    }
+
+private:
+    enum Phase { WAIT_INITIAL, WAIT_MT, WAIT_BT, DONE };
+    int n = 0, m = 0;
+    double *x = nullptr, *g = nullptr;
+    frx_lbfgs_params pm;
+    Phase phase = DONE;
+    int ret = 0, k = 0, end = 0, evals = 0;
+    double fx = 0, step = 0, stepp = 0, fp = 0;
+    std::vector<double> xp, gp, d, S, Y, alpha, ysv, pf;
+    LineSearch ls;
+
+    static double vdot(const double *a, const double *b, int n) {
+        double s = 0.;
+        for (int i = 0; i < n; ++i) s += a[i] * b[i];
+        return s;
+    }
+    static void vadd(double *y, const double *v, double c, int n) {
+        for (int i = 0; i < n; ++i) y[i] += c * v[i];
+    }
     void finish(int code) { ret = code; phase = DONE; }
+    void propose() {                                   // x <- xp + stp * d   (lbfgs.hpp:825-826, 977-978)
+        std::memcpy(x, xp.data(), sizeof(double) * n);
+        vadd(x, d.data(), ls.step(), n);
+    }
 
     // lbfgs.hpp:1211-1246
     void after_initial(double f) {
@@ -210,135 +338,37 @@ private:
         end = 0;
         begin_iteration();
     }
-
     // lbfgs.hpp:1248-1268
     void begin_iteration() {
         std::memcpy(xp.data(), x, sizeof(double) * n);
         std::memcpy(gp.data(), g, sizeof(double) * n);
         stepp = step;
         fp = fx;
-        int r = mt_begin();
-        if (r != 0) linesearch_result(r, true);
-    }
-
-    // ---- Moré–Thuente, lbfgs.hpp:730-938 ----
-    int mt_begin() {
-        count = 0; brackt = 0; stage1 = 1; uinfo = 0;
-        stp = &step;
-        if (*stp <= 0.) return LBERR_INVALIDPARAMETERS;
-        dginit = vdot(gp.data(), d.data(), n);
-        if (0 < dginit) return LBERR_INCREASEGRADIENT;
-        finit = fx;
-        dgtest = pm.f_dec_coeff * dginit;
-        width = pm.max_step - pm.min_step;
-        prev_width = 2.0 * width;
-        stx = sty = 0.;
-        fxl = fy = finit;
-        dgx = dgy = dginit;
-        mt_propose();
-        return 0;
-    }
-    void mt_propose() {                       // loop head up to the evaluation, lbfgs.hpp:790-826
-        if (brackt) { stmin = stx <= sty ? stx : sty; stmax = stx >= sty ? stx : sty; }
-        else        { stmin = stx; stmax = *stp + 4.0 * (*stp - stx); }
-        if (*stp < pm.min_step) *stp = pm.min_step;
-        if (pm.max_step < *stp) *stp = pm.max_step;
-        if ((brackt && ((*stp <= stmin || stmax <= *stp) || pm.max_linesearch <= count + 1 || uinfo != 0)) ||
-            (brackt && (stmax - stmin <= pm.xtol * stmax)))
-            *stp = stx;
-        std::memcpy(x, xp.data(), sizeof(double) * n);
-        vadd(x, d.data(), *stp, n);
+        const int r = ls.mt_begin(pm, step, fx, vdot(gp.data(), d.data(), n));
+        if (r != 0) { linesearch_result(r, true); return; }
         phase = WAIT_MT;
+        propose();
     }
-    void mt_after_eval(double f) {            // lbfgs.hpp:829-935
-        fx = f;
-        double dg = vdot(g, d.data(), n);
-        const double ftest1 = finit + *stp * dgtest;
-        ++count;
-        if ((std::isinf(fx) || std::isnan(fx)) || (brackt && ((*stp <= stmin || stmax <= *stp) || uinfo != 0))) {
-            linesearch_result(LBERR_ROUNDING, true); return;
-        }
-        if (*stp == pm.max_step && fx <= ftest1 && dg <= dgtest) { linesearch_result(LBERR_MAXIMUMSTEP, true); return; }
-        if (*stp == pm.min_step && (ftest1 < fx || dgtest <= dg)) { linesearch_result(LBERR_MINIMUMSTEP, true); return; }
-        if (brackt && (stmax - stmin) <= pm.xtol * stmax) { linesearch_result(LBERR_WIDTHTOOSMALL, true); return; }
-        if (pm.max_linesearch <= count) { linesearch_result(LBERR_MAXIMUMLINESEARCH, true); return; }
-        if (fx <= ftest1 && std::fabs(dg) <= pm.s_curv_coeff * (-dginit)) { linesearch_result(count, true); return; }
-        if (stage1 && fx <= ftest1 &&
-            (pm.f_dec_coeff <= pm.s_curv_coeff ? pm.f_dec_coeff : pm.s_curv_coeff) * dginit <= dg)
-            stage1 = 0;
-        if (stage1 && ftest1 < fx && fx <= fxl) {
-            double fm = fx - *stp * dgtest, fxm = fxl - stx * dgtest, fym = fy - sty * dgtest;
-            double dgm = dg - dgtest, dgxm = dgx - dgtest, dgym = dgy - dgtest;
-            uinfo = update_trial(stx, fxm, dgxm, sty, fym, dgym, *stp, fm, dgm, stmin, stmax, brackt);
-            fxl = fxm + stx * dgtest;
-            fy = fym + sty * dgtest;
-            dgx = dgxm + dgtest;
-            dgy = dgym + dgtest;
-        } else {
-            uinfo = update_trial(stx, fxl, dgx, sty, fy, dgy, *stp, fx, dg, stmin, stmax, brackt);
-        }
-        if (brackt) {
-            if (0.66 * prev_width <= std::fabs(sty - stx)) *stp = stx + 0.5 * (sty - stx);
-            prev_width = width;
-            width = std::fabs(sty - stx);
-        }
-        mt_propose();
-    }
-
-    // ---- backtracking, lbfgs.hpp:940-1033 ----
-    int bt_begin() {
-        count = 0;
-        stp = &step;
-        if (*stp <= 0.) return LBERR_INVALIDPARAMETERS;
-        dginit = vdot(gp.data(), d.data(), n);
-        if (0 < dginit) return LBERR_INCREASEGRADIENT;
-        finit = fx;
-        dgtest = pm.f_dec_coeff * dginit;
-        bt_propose();
-        return 0;
-    }
-    void bt_propose() {
-        std::memcpy(x, xp.data(), sizeof(double) * n);
-        vadd(x, d.data(), *stp, n);
-        phase = WAIT_BT;
-    }
-    void bt_after_eval(double f) {
-        const double dec = 0.5, inc = 2.1;
-        double wd;
-        fx = f;
-        ++count;
-        if (fx > finit + *stp * dgtest) wd = dec;
-        else {
-            const double dg = vdot(g, d.data(), n);
-            if (dg < pm.s_curv_coeff * dginit) wd = inc;
-            else if (dg > -pm.s_curv_coeff * dginit) wd = dec;
-            else { linesearch_result(count, false); return; }
-        }
-        if (*stp < pm.min_step) { linesearch_result(LBERR_MINIMUMSTEP, false); return; }
-        if (*stp > pm.max_step) { linesearch_result(LBERR_MAXIMUMSTEP, false); return; }
-        if (pm.max_linesearch <= count) { linesearch_result(LBERR_MAXIMUMLINESEARCH, false); return; }
-        *stp *= wd;
-        bt_propose();
-    }
-
     // lbfgs.hpp:1270-1293
-    void linesearch_result(int ls, bool from_mt) {
-        if (ls < 0 && from_mt) {
+    void linesearch_result(int lsr, bool from_mt) {
+        step = ls.step();
+        if (lsr < 0 && from_mt) {
             step = stepp;
             fx = fp;
-            int r = bt_begin();
-            if (r != 0) linesearch_result(r, false);
+            const int r = ls.bt_begin(step, fx, vdot(gp.data(), d.data(), n), pm);
+            if (r != 0) { linesearch_result(r, false); return; }
+            phase = WAIT_BT;
+            propose();
             return;
         }
-        if (ls < 0) {
+        if (lsr < 0) {
             std::memcpy(x, xp.data(), sizeof(double) * n);
             std::memcpy(g, gp.data(), sizeof(double) * n);
-            finish(ls);
+            finish(lsr);
             return;
         }
         after_linesearch();
     }
-
     // lbfgs.hpp:1295-1419
     void after_linesearch() {
         double xnorm = std::sqrt(vdot(x, x, n)), gnorm = std::sqrt(vdot(g, g, n));
@@ -379,6 +409,156 @@ private:
         }
         step = 1.0;
         begin_iteration();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Device-vector solver.  One round = the device executes this candidate's command, evaluates the
+// objective at its trial point and returns scalars.
+// ---------------------------------------------------------------------------------------------
+struct DvCommand {           // host -> device, one per candidate per round (mapped host memory)
+    int flags;               // DV_* bits
+    int slot;                // history slot to write (s, y) into (the reference's `end` before it is advanced)
+    int bound;               // number of history pairs in the two-loop recursion: min(m, k)
+    int newest;              // slot index of the newest pair AFTER this advance (= slot)
+    double step;             // trial step: x = xp + step * d
+};
+enum {
+    DV_EVAL = 1,             // this candidate takes part in the evaluation of this round
+    DV_INIT = 2,             // before the trial: d = -g, xp = x, gp = g                          (lbfgs.hpp:1220, 1262-1263)
+    DV_ADVANCE = 4,          // before the trial: history update, two-loop recursion, xp = x, gp = g  (lbfgs.hpp:1354-1411, 1262-1263)
+    DV_TRIAL = 8,            // x = xp + step * d                                                   (lbfgs.hpp:825-826)
+    DV_RESTORE = 16          // x = xp, g = gp: line search failed for good                         (lbfgs.hpp:1287-1288)
+};
+struct DvResult {            // device -> host
+    double f;                // objective at the trial point
+    double dg;               // g . d          (lbfgs.hpp:830)
+    double xx, gg;           // x . x, g . g   (lbfgs.hpp:1296-1297)
+    double dginit;           // gp . d after INIT / ADVANCE (lbfgs.hpp:756): the first trial of the new search runs in the same round
+    double pad[3];
+};
+
+class SolverDV {
+public:
+    void start(int n_, const frx_lbfgs_params &pm_, DvCommand *cmd_) {
+        n = n_; pm = pm_; cmd = cmd_;
+        m = pm.mem_size;
+        ret = lbfgs_check(n, pm);
+        evals = 0; k = 0; fx = 0.0;
+        pf.assign(pm.past > 0 ? pm.past : 0, 0.0);
+        if (ret != 0) { phase = DONE; idle(); return; }
+        phase = WAIT_INITIAL;
+        cmd->flags = DV_EVAL; cmd->step = 0.0; cmd->slot = cmd->bound = cmd->newest = 0;     // evaluate the start point as is
+    }
+    bool done() const { return phase == DONE; }
+    int status() const { return ret; }
+    int iterations() const { return k; }
+    int evaluations() const { return evals; }
+    double value() const { return fx; }
+
+    void feed(const DvResult &r) {
+        ++evals;
+        switch (phase) {
+        case WAIT_INITIAL: {                                           // lbfgs.hpp:1211-1246
+            fx = r.f;
+            if (!pf.empty()) pf[0] = fx;
+            double xnorm = std::sqrt(r.xx), gnorm = std::sqrt(r.gg);
+            if (xnorm < 1.0) xnorm = 1.0;
+            if (gnorm / xnorm <= pm.g_epsilon) { finish(LB_ALREADY_MINIMIZED); return; }
+            step = 1.0 / std::sqrt(r.gg);                              // 1 / |d|, d = -g
+            k = 1; end = 0;
+            stepp = step; fp = fx;
+            // d = -g  =>  gp . d = -(g . g), known without another round trip
+            const int rc = ls.mt_begin(pm, step, fx, -r.gg);
+            if (rc != 0) { linesearch_result(rc, true, -r.gg); return; }
+            phase = WAIT_MT;
+            cmd->flags = DV_EVAL | DV_INIT | DV_TRIAL; cmd->step = ls.step();
+            dginit_cur = -r.gg;
+            break;
+        }
+        case WAIT_MT_FIRST: {                                          // first trial of a new search ran together with the advance
+            dginit_cur = r.dginit;
+            stepp = step; fp = fx;
+            const int rc = ls.mt_begin(pm, step, fx, r.dginit);
+            if (rc != 0) { linesearch_result(rc, true, r.dginit); return; }
+            phase = WAIT_MT;
+        }   // fall through: the trial at step 1.0 has already been evaluated
+        // FALLTHROUGH
+        case WAIT_MT: {
+            const double fprev = fx;
+            fx = r.f;
+            const int rc = ls.mt_feed(pm, r.f, r.dg);
+            (void)fprev;
+            if (rc == LineSearch::PENDING) { cmd->flags = DV_EVAL | DV_TRIAL; cmd->step = ls.step(); }
+            else { xx = r.xx; gg = r.gg; linesearch_result(rc, true, dginit_cur); }
+            break;
+        }
+        case WAIT_BT: {
+            fx = r.f;
+            const int rc = ls.bt_feed(pm, r.f, r.dg);
+            if (rc == LineSearch::PENDING) { cmd->flags = DV_EVAL | DV_TRIAL; cmd->step = ls.step(); }
+            else { xx = r.xx; gg = r.gg; linesearch_result(rc, false, dginit_cur); }
+            break;
+        }
+        default: break;
+        }
+    }
+
+private:
+    enum Phase { WAIT_INITIAL, WAIT_MT_FIRST, WAIT_MT, WAIT_BT, DONE };
+    int n = 0, m = 0;
+    frx_lbfgs_params pm;
+    DvCommand *cmd = nullptr;
+    Phase phase = DONE;
+    int ret = 0, k = 0, end = 0, evals = 0;
+    double fx = 0, step = 0, stepp = 0, fp = 0, xx = 0, gg = 0, dginit_cur = 0;
+    std::vector<double> pf;
+    LineSearch ls;
+
+    void idle() { cmd->flags = 0; cmd->step = 0.0; }
+    void finish(int code) { ret = code; phase = DONE; idle(); }
+
+    // lbfgs.hpp:1270-1293
+    void linesearch_result(int lsr, bool from_mt, double dginit) {
+        step = ls.step();
+        if (lsr < 0 && from_mt) {
+            step = stepp;
+            fx = fp;
+            const int rc = ls.bt_begin(step, fx, dginit, pm);
+            if (rc != 0) { linesearch_result(rc, false, dginit); return; }
+            phase = WAIT_BT;
+            cmd->flags = DV_EVAL | DV_TRIAL; cmd->step = ls.step();
+            return;
+        }
+        if (lsr < 0) {                                                 // revert to the previous point; no further evaluation
+            ret = lsr; phase = DONE;
+            cmd->flags = DV_RESTORE; cmd->step = 0.0;
+            return;
+        }
+        after_linesearch();
+    }
+    // lbfgs.hpp:1295-1419 (scalar part; the vector part is the DV_ADVANCE command)
+    void after_linesearch() {
+        double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg);
+        if (xnorm < 1.0) xnorm = 1.0;
+        if (gnorm / xnorm <= pm.g_epsilon) { finish(LB_CONVERGENCE); return; }
+        if (!pf.empty()) {
+            if (pm.past <= k) {
+                const double rate = (pf[k % pm.past] - fx) / fx;
+                if (std::fabs(rate) < pm.delta) { finish(LB_STOP); return; }
+            }
+            pf[k % pm.past] = fx;
+        }
+        if (pm.max_iterations != 0 && pm.max_iterations < k + 1) { finish(LBERR_MAXIMUMITERATION); return; }
+        const int bound = (m <= k) ? m : k;
+        cmd->slot = end; cmd->bound = bound; cmd->newest = end;
+        ++k;
+        end = (end + 1) % m;
+        step = 1.0;                                                    // lbfgs.hpp:1418
+        cmd->flags = DV_EVAL | DV_ADVANCE | DV_TRIAL; cmd->step = 1.0; // first Moré–Thuente trial is always at min(max(1, min_step), max_step)
+        if (cmd->step < pm.min_step) cmd->step = pm.min_step;
+        if (pm.max_step < cmd->step) cmd->step = pm.max_step;
+        phase = WAIT_MT_FIRST;
     }
 };
 

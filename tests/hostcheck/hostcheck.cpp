@@ -152,3 +152,71 @@ extern "C" void hostcheck_minco_adjoint(int N, const double *T, const double *q,
         }
     for (int k = 1; k < N; k++) for (int x = 0; x < 3; x++) gdQ[3 * (k - 1) + x] += pb[3 * k + x];
 }
+
+// ---- SolverDV (device-vector L-BFGS control logic) driven by a HOST emulation of the device commands ----
+// The emulation executes DV_INIT / DV_ADVANCE / DV_TRIAL / DV_RESTORE with the same sequential loops as the
+// host-vector Solver, so the iterates must be bit-identical to Solver and to the reference lbfgs.hpp: this pins the
+// command protocol (what is sent when, which scalar is consumed when) on a CPU-only box.
+#include <cstring>
+#include "../../fast-racing_amd/csrc/frx_lbfgs.hpp"
+
+extern "C" int hostcheck_lbfgs_dv(int n, double *x, double *fx_out, double (*fn)(void *, const double *, double *, int), void *inst,
+                                  const double *p11, int *iters, int *evals) {
+    frx_lbfgs_params pm;
+    pm.mem_size = (int)p11[0]; pm.g_epsilon = p11[1]; pm.past = (int)p11[2]; pm.delta = p11[3]; pm.max_iterations = (int)p11[4];
+    pm.max_linesearch = (int)p11[5]; pm.min_step = p11[6]; pm.max_step = p11[7]; pm.f_dec_coeff = p11[8]; pm.s_curv_coeff = p11[9];
+    pm.xtol = p11[10];
+    const int m = pm.mem_size;
+    std::vector<double> g(n, 0.0), xp(n, 0.0), gp(n, 0.0), d(n, 0.0), S((size_t)m * n, 0.0), Y((size_t)m * n, 0.0), ysv(m, 0.0), al(m, 0.0);
+    auto dot = [n](const double *a, const double *b) { double s = 0.; for (int i = 0; i < n; ++i) s += a[i] * b[i]; return s; };
+    auto axpy = [n](double *y, const double *v, double c) { for (int i = 0; i < n; ++i) y[i] += c * v[i]; };
+    frx::DvCommand cmd;
+    frx::DvResult res;
+    std::memset(&res, 0, sizeof(res));
+    frx::SolverDV sv;
+    sv.start(n, pm, &cmd);
+    while (cmd.flags != 0) {
+        const frx::DvCommand c = cmd;
+        if (c.flags & frx::DV_RESTORE) { std::memcpy(x, xp.data(), sizeof(double) * n); std::memcpy(g.data(), gp.data(), sizeof(double) * n); cmd.flags = 0; break; }
+        if (c.flags & frx::DV_INIT) {
+            for (int i = 0; i < n; ++i) d[i] = -g[i];
+            xp.assign(x, x + n); gp = g;
+            res.dginit = dot(gp.data(), d.data());
+        }
+        if (c.flags & frx::DV_ADVANCE) {
+            double *se = &S[(size_t)c.slot * n], *ye = &Y[(size_t)c.slot * n];
+            for (int i = 0; i < n; ++i) se[i] = x[i] - xp[i];
+            for (int i = 0; i < n; ++i) ye[i] = g[i] - gp[i];
+            const double ys = dot(ye, se), yy = dot(ye, ye);
+            ysv[c.slot] = ys;
+            for (int i = 0; i < n; ++i) d[i] = -g[i];
+            int j = (c.slot + 1) % m;
+            for (int it = 0; it < c.bound; ++it) {
+                j = (j + m - 1) % m;
+                al[j] = dot(&S[(size_t)j * n], d.data());
+                al[j] /= ysv[j];
+                axpy(d.data(), &Y[(size_t)j * n], -al[j]);
+            }
+            const double h0 = ys / yy;
+            for (int i = 0; i < n; ++i) d[i] *= h0;
+            for (int it = 0; it < c.bound; ++it) {
+                double beta = dot(&Y[(size_t)j * n], d.data());
+                beta /= ysv[j];
+                axpy(d.data(), &S[(size_t)j * n], al[j] - beta);
+                j = (j + 1) % m;
+            }
+            xp.assign(x, x + n); gp = g;
+            res.dginit = dot(gp.data(), d.data());
+        }
+        if (c.flags & frx::DV_TRIAL) { std::memcpy(x, xp.data(), sizeof(double) * n); axpy(x, d.data(), c.step); }
+        if (c.flags & frx::DV_EVAL) {
+            res.f = fn(inst, x, g.data(), n);
+            res.dg = dot(g.data(), d.data()); res.xx = dot(x, x); res.gg = dot(g.data(), g.data());
+            sv.feed(res);
+        }
+    }
+    if (fx_out) *fx_out = sv.value();
+    if (iters) *iters = sv.iterations();
+    if (evals) *evals = sv.evaluations();
+    return sv.status();
+}

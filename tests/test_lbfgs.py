@@ -115,3 +115,27 @@ def test_rosenbrock_and_already_minimized(frx):
     assert frx.lib().frx_lbfgs_minimize_batch(2, x_off, x, f, st, it, ev, C.byref(ps), frx.BATCH_EVAL_FN(cb), None, 1) == 0
     assert st[0] == 0 and np.allclose(x[:2], 1.0, atol=1e-4)
     assert st[1] == 2 and ev[1] == 1                       # LBFGS_ALREADY_MINIMIZED
+
+
+def test_device_vector_protocol_is_bit_identical_on_host_emulation(problems, ob):
+    """SolverDV keeps only scalars + decisions on the host and sends vector commands to the device.  Driven by a host
+    emulation of those commands (tests/hostcheck, same sequential loops as Solver) it must reproduce the reference
+    solver's iterates bit for bit: pins the command protocol without a GPU."""
+    import os, subprocess
+    from conftest import ROOT
+    d = os.path.join(ROOT, "tests", "hostcheck")
+    subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
+    H = C.CDLL(os.path.join(d, "libhostcheck.so"))
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    H.hostcheck_lbfgs_dv.restype = C.c_int
+    H.hostcheck_lbfgs_dv.argtypes = [C.c_int, dp, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R = ob.ref_lbfgs()
+    runner = R.ref_lbfgs_run if R is not None else ob.lib().orc_lbfgs_run
+    for mem, delta, maxit in ((128, 1e-6, 0), (8, 1e-5, 0), (128, 1e-6, 37)):
+        pm = ob.lbfgs_params(mem_size=mem, past=3, g_epsilon=1e-16, min_step=1e-32, delta=delta, max_iterations=maxit)
+        for o in problems:
+            x0 = o.initial_guess()
+            ret, xr, fr, tf, ts, tl = run_trace(runner, o, ob, x0, pm)
+            x = x0.copy(); fx = C.c_double(); it = C.c_int(); ev = C.c_int()
+            rc = H.hostcheck_lbfgs_dv(o.n, x, C.byref(fx), ob.lib().orc_objective_fnptr(), o.h, pm, C.byref(it), C.byref(ev))
+            assert rc == ret and fx.value == fr and np.array_equal(x, xr)
