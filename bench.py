@@ -54,16 +54,21 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
         done = sum(ex.map(lambda b: work(b, reps), range(len(cands))))
     dt = time.perf_counter() - t0
     samples = done * oracles[0].fine_n * (kappa + 1)
-    # one full plan of candidate 0 (stock tolerance) for the plan-ms comparison
+    # one full plan of candidate 0 (stock tolerance), then the whole batch with one candidate per thread
     t0 = time.perf_counter()
     r = oracles[0].optimize(params["opt_rel_tol"])
     plan_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        rs = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"]), oracles))
+    plan_batch_ms = (time.perf_counter() - t0) * 1e3
     return {
         "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "kind": "port",
         "sample": f"{done} objective evaluations (x->f,grad) of the {len(cands)} headline candidates at the bench state, "
                   f"{workers} threads, oracle built -O3 -march=x86-64-v3",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
         "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
+        "plan_ms_batch": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_objective_min": float(min(x["objective"] for x in rs)),
     }
 
 
@@ -152,7 +157,7 @@ def main():
     if not args.no_plan:
         if dist: dist.barrier()
         r = prob.optimize(params["opt_rel_tol"], x0=x0)
-        plan = {"plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
+        plan = {"plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
                 "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min())}
         # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients

@@ -59,7 +59,7 @@ BATCH_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POI
 # every symbol include/frx.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params", "frx_lbfgs_gcopter_params",
-    "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
+    "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
 ]
@@ -83,6 +83,8 @@ def lib():
         L.frx_problem_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
+        L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
+        L.frx_profile_phases.argtypes = [C.c_void_p, _dp, np.ctypeslib.ndpointer(dtype=np.int64, flags='C_CONTIGUOUS')]
         L.frx_problem_totals.argtypes = [C.c_void_p, _ip]
         L.frx_problem_layout.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip]
         L.frx_initial_guess.argtypes = [C.c_void_p, _dp]
@@ -165,6 +167,10 @@ class Problem:
     def set_solver(self, name: str):
         """'knot_pcr' (default) or 'banded_lu' (reference elimination order, cross-check)."""
         _check(lib().frx_problem_set_solver(self.h, {"knot_pcr": 0, "banded_lu": 1}[name]))
+
+    def set_lbfgs_mode(self, name: str):
+        """'device' (default: vectors on the GPU, decisions on the host) or 'host' (reference-exact host vectors)."""
+        _check(lib().frx_problem_set_lbfgs_mode(self.h, {"device": 0, "host": 1}[name]))
 
     def initial_guess(self):
         x = np.zeros(self.NX)

@@ -160,11 +160,13 @@ struct frx_problem {
     frx::DevProblem dp;
     hipStream_t stream = nullptr;
     // device-resident constants
-    DevBuf<int> d_cvoff, d_poff, d_coff, d_xoff, d_boff, d_piece_hbeg, d_piece_K, d_piece_coarse, d_coarse_iv, d_coarse_fbeg, d_wp_vbeg,
+    DevBuf<int> d_cvoff, d_poff, d_coff, d_xoff, d_boff, d_piece_hbeg, d_piece_K, d_piece_coarse, d_piece_iv, d_coarse_iv, d_coarse_fbeg, d_wp_vbeg,
         d_wp_nv, d_wp_xbeg;
     DevBuf<double> d_head, d_tail, d_hblk, d_vrec;
     // device work space
     DevBuf<double> d_x, d_f, d_g, d_T, d_C, d_band, d_out20;
+    DevBuf<long long> d_stamps;
+    DevBuf<double> d_pcrw;
     // pinned staging
     PinBuf<double> h_x, h_f, h_g, h_T, h_C, h_out20;
     // device-vector L-BFGS state (allocated on first use)
@@ -320,7 +322,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     p->poff.assign(B + 1, 0); p->coff.assign(B + 1, 0); p->xoff.assign(B + 1, 0); p->boff.assign(B + 1, 0);
     p->dimT.assign(B, 0);
 
-    std::vector<int> piece_hbeg, piece_K, piece_coarse, coarse_iv, coarse_fbeg, wp_vbeg, wp_nv, wp_xbeg, cvoff(B + 1, 0);
+    std::vector<int> piece_hbeg, piece_K, piece_coarse, piece_iv, coarse_iv, coarse_fbeg, wp_vbeg, wp_nv, wp_xbeg, cvoff(B + 1, 0);
     std::vector<double> hrec, horg, vrec, head(ini_state, ini_state + 9 * (size_t)B), tail(fin_state, fin_state + 9 * (size_t)B);
     int hpoly = 0, vpoly = 0;                     // running polytope indices into h_off / v_off
     for (int b = 0; b < B; b++) {
@@ -392,7 +394,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
                     vrec.insert(vrec.end(), hc.cfgVs[vm].begin(), hc.cfgVs[vm].end());   // waypoint order, contiguous per candidate
                     xcur += nv - 1;
                 }
-                piece_hbeg.push_back(hbeg_dev); piece_K.push_back(K); piece_coarse.push_back(gc0 + i);
+                piece_hbeg.push_back(hbeg_dev); piece_K.push_back(K); piece_coarse.push_back(gc0 + i); piece_iv.push_back(hc.intervals[i]);
                 p->sumKfine += K;
                 offset++;
             }
@@ -435,8 +437,12 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     {
         const size_t nt = ge.knot_threads;
         ge.maxXb = maxXb; ge.maxVb = maxVb;
+        ge.pcr_steps = 0;
+        for (int s = 1; s < p->maxN - 1; s <<= 1) ge.pcr_steps++;
         ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN + maxXb + maxVb);
-        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * (nt / 64) + 2 + maxXb + maxVb);
+        ge.pcr_steps = 0;
+        for (int s = 1; s < p->maxN - 1; s <<= 1) ge.pcr_steps++;
+        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * 4 + 2 + maxXb + maxVb + (size_t)(ge.pcr_steps * 8 + 5) * nt);
     }
     const size_t lds_cap = 160 * 1024;
     if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
@@ -463,7 +469,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     CR((hipError_t)frx::launch_set_limits(p->geo));
     CR(p->d_cvoff.upload(cvoff)); CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
-    CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse));
+    CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse)); CR(p->d_piece_iv.upload(piece_iv));
     CR(p->d_coarse_iv.upload(coarse_iv)); CR(p->d_coarse_fbeg.upload(coarse_fbeg));
     CR(p->d_wp_vbeg.upload(wp_vbeg)); CR(p->d_wp_nv.upload(wp_nv)); CR(p->d_wp_xbeg.upload(wp_xbeg));
     CR(p->d_head.upload(head)); CR(p->d_tail.upload(tail)); {
@@ -480,6 +486,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     } CR(p->d_vrec.upload(vrec));
     CR(p->d_x.alloc(p->NX)); CR(p->d_f.alloc(B)); CR(p->d_g.alloc(p->NX));
     CR(p->d_T.alloc(p->P)); CR(p->d_C.alloc((size_t)p->P * 18)); CR(p->d_band.alloc(p->boff[B])); CR(p->d_out20.alloc((size_t)p->P * 20));
+    CR(p->d_pcrw.alloc((size_t)(p->geo.pcr_steps * 8 + 4) * p->P)); p->geo.pcrw = p->d_pcrw.p;
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
 #undef CR
@@ -498,10 +505,10 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     for (int q = 0; q < 4; q++) d.pc.chi[q] = cfg->penalty_pvtb[q];
     d.cvoff = p->d_cvoff.p; d.poff = p->d_poff.p; d.coff = p->d_coff.p; d.xoff = p->d_xoff.p; d.boff = p->d_boff.p;
     d.headPVA = p->d_head.p; d.tailPVA = p->d_tail.p;
-    d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p;
+    d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p; d.piece_iv = p->d_piece_iv.p;
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
     d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
-    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p;
+    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.stamps = nullptr;
     *out = p;
     return FRX_OK;
 }
@@ -513,12 +520,37 @@ void frx_problem_destroy(frx_problem *p) {
     delete p;
 }
 
+int frx_problem_set_lbfgs_mode(frx_problem *p, int mode) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (mode != FRX_LBFGS_DEVICE_VECTORS && mode != FRX_LBFGS_HOST_VECTORS) return fail(FRX_ERR_INVALID_ARG, "unknown L-BFGS mode");
+    p->lbfgs_mode = mode;
+    return FRX_OK;
+}
+
 int frx_problem_set_solver(frx_problem *p, int solver) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
     if (solver != FRX_SOLVER_KNOT_PCR && solver != FRX_SOLVER_BANDED_LU) return fail(FRX_ERR_INVALID_ARG, "unknown solver id");
     if (solver == FRX_SOLVER_BANDED_LU && !p->banded_ok)
         return fail(FRX_ERR_CAPACITY, "banded-LU kernels need the 6N x 13 band in LDS: too many pieces");
     p->geo.solver = solver;
+    return FRX_OK;
+}
+
+// Diagnostic: one evaluation at x with s_memtime stamps at the phase boundaries of candidate 0's k_forward_knot
+// (slots 0..6) and k_backward_knot (slots 16..24); out32 receives the raw shader-clock stamps.
+int frx_profile_phases(frx_problem *p, const double *x, long long *out32) {
+    if (!p || !x || !out32) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(32));
+    HIP_TRY(hipMemset(p->d_stamps.p, 0, 32 * sizeof(long long)));
+    std::vector<double> f(p->B), g(p->NX);
+    int rc = frx_objective_eval(p, x, f.data(), g.data());          // warm
+    if (rc != FRX_OK) return rc;
+    p->dp.stamps = p->d_stamps.p;
+    rc = frx_objective_eval(p, x, f.data(), g.data());
+    p->dp.stamps = nullptr;
+    if (rc != FRX_OK) return rc;
+    HIP_TRY(hipMemcpy(out32, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     return FRX_OK;
 }
 

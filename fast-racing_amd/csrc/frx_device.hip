@@ -17,7 +17,7 @@ int launch_set_limits(const LaunchGeom &g) {
 }
 int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *band, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)
-        hipLaunchKernelGGL(k_forward_knot, dim3(dp.B), dim3(g.knot_threads), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN, g.maxXb, g.maxVb);
+        hipLaunchKernelGGL(k_forward_knot, dim3(dp.B), dim3(256), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps);
     else
         hipLaunchKernelGGL(k_forward, dim3(dp.B), dim3(64), g.lds_fwd, (hipStream_t)stream, dp, x, T, C, band, g.maxN, g.maxCN);
     return (int)hipGetLastError();
@@ -30,8 +30,8 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
                     const double *band, const double *out20, double *f, double *grad, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)
-        hipLaunchKernelGGL(k_backward_knot, dim3(dp.B), dim3(g.knot_threads), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
-                           grad, g.maxCN, g.maxXb, g.maxVb);
+        hipLaunchKernelGGL(k_backward_knot, dim3(dp.B), dim3(256), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
+                           grad, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps);
     else
         hipLaunchKernelGGL(k_backward, dim3(dp.B), dim3(64), g.lds_bwd, (hipStream_t)stream, dp, x, T, C, band, out20, f, grad, g.maxN,
                            g.maxCN);

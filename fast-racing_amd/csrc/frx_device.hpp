@@ -21,13 +21,14 @@ struct DevProblem {
     const double *headPVA, *tailPVA;          // [B][9] column-major (p|v|a)
     // per fine piece
     const int *piece_hbeg, *piece_K;          // [P] first half-space record / count of the piece's polytope (idxHs expanded)
-    const int *piece_coarse;                  // [P] global coarse index of the piece
+    const int *piece_coarse, *piece_iv;       // [P] global coarse index of the piece; interval count of that coarse piece
     // per coarse piece
     const int *coarse_iv, *coarse_fbeg;       // [Pc] interval count, first fine piece (global)
     // per waypoint (candidate b owns N_b-1, global index = poff[b] - b + i)
     const int *wp_vbeg, *wp_nv, *wp_xbeg;     // first vertex record, vertex count, absolute index of its xi segment in x
     const double *hblk;                       // [P][Kmax+1][4]: {origin xyz, K}, then K x (unit normal, n.(p_k - origin) - margin), zero padded
     const double *vrec;                       // waypoint vertices [..][3] in [v0, v_r - v0] form, waypoint order
+    long long *stamps;                        // optional (null): s_memtime stamps of candidate 0's phases, [2][16] (frx_profile_phases)
 };
 
 enum { SOLVER_KNOT_PCR = 0, SOLVER_BANDED_LU = 1 };
@@ -39,6 +40,8 @@ struct LaunchGeom {
     int knot_threads;                      // workgroup size of the knot kernels: 64 * ceil(maxN / 64)
     size_t lds_kfwd, lds_kbwd;
     int maxXb, maxVb;                      // per-candidate maxima: free variables, waypoint-vertex doubles (3 per vertex)
+    int pcr_steps;                         // ceil(log2(maxN - 1)): reduction steps whose multipliers k_forward_knot saves
+    double *pcrw;                          // [(pcr_steps*8 + 4)][P] saved multipliers + final D^-1 per knot
 };
 
 // all return a hipError_t value as int (0 = hipSuccess); stream is a hipStream_t

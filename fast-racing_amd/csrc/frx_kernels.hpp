@@ -416,17 +416,20 @@ __global__ __launch_bounds__(64) void k_backward(DevProblem dp, const double *__
 // =============================================================================================
 // Knot-form MINCO map (frx_minco.hpp): O(log N) depth instead of five 6N-row sequential sweeps.
 // One workgroup per candidate, thread k = piece k (0..N-1) AND interior knot k (1..N-1).
-// LDS (doubles): rows[2][18][nthr] (SoA, conflict-free) | KP,KV,KA [3][nthr+1] x 3 arrays | Tf[nthr] | Tc[maxCN] | red
+// Block = 256 threads: all of them stage the candidate's x and waypoint polytopes (every global read issued up front),
+// threads < nrow = 64*ceil(maxN/64) own a piece / knot.
+// LDS (doubles): rows[2][18][nrow] (SoA, conflict-free) | KP,KV,KA [3][nrow+1] x 3 arrays | Tf[nrow] | Tc[maxCN] | red | xs | vs
 // =============================================================================================
-#define ROWF(buf, f, t) rowbuf[((buf) * 18 + (f)) * nthr + (t)]
+#define FRX_STAMP(slot) do { if (dp.stamps && b == 0 && k == 0) dp.stamps[slot] = (long long)__builtin_readcyclecounter(); } while (0)
+#define ROWF(buf, f, t) rowbuf[((buf) * 18 + (f)) * nrow + (t)]
 
-__device__ __forceinline__ void row_store(double *rowbuf, int nthr, int buf, int t, const KnotRow &R) {
+__device__ __forceinline__ void row_store(double *rowbuf, int nrow, int buf, int t, const KnotRow &R) {
 #pragma unroll
     for (int i = 0; i < 4; i++) { ROWF(buf, i, t) = R.D[i]; ROWF(buf, 4 + i, t) = R.L[i]; ROWF(buf, 8 + i, t) = R.U[i]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) ROWF(buf, 12 + i, t) = R.r[i];
 }
-__device__ __forceinline__ void row_load(const double *rowbuf, int nthr, int buf, int t, KnotRow &R) {
+__device__ __forceinline__ void row_load(const double *rowbuf, int nrow, int buf, int t, KnotRow &R) {
 #pragma unroll
     for (int i = 0; i < 4; i++) { R.D[i] = ROWF(buf, i, t); R.L[i] = ROWF(buf, 4 + i, t); R.U[i] = ROWF(buf, 8 + i, t); }
 #pragma unroll
@@ -434,42 +437,117 @@ __device__ __forceinline__ void row_load(const double *rowbuf, int nthr, int buf
 }
 
 // Parallel cyclic reduction over knots 1..N-1 (thread k owns knot k); returns this knot's (v, a) solution.
-__device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nthr, int k, int N, KnotRow &me, double *v, double *a) {
+// `save` (optional): per-step multipliers and the final D^-1 of this knot, AoS save[gk * sstride + step*8 + i] and
+// save[gk * sstride + nsteps*8 + i] (sstride = nsteps*8 + 4), for k_backward_knot's right-hand-side-only reduction.
+__device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nrow, int k, int N, KnotRow &me, double *v, double *a,
+                                             double *save, size_t sstride, size_t gk, int nsteps) {
     const bool act = k >= 1 && k <= N - 1;
-    int buf = 0;
-    if (act) row_store(rowbuf, nthr, 0, k, me);
+    int buf = 0, step = 0;
+    if (act) row_store(rowbuf, nrow, 0, k, me);
     __syncthreads();
-    for (int s = 1; s < N - 1; s <<= 1) {
+    for (int s = 1; s < N - 1; s <<= 1, step++) {
         if (act) {
             KnotRow lo, hi, out;
-            if (k - s >= 1) row_load(rowbuf, nthr, buf, k - s, lo); else knot_row_identity(lo);
-            if (k + s <= N - 1) row_load(rowbuf, nthr, buf, k + s, hi); else knot_row_identity(hi);
-            pcr_step(me, lo, hi, out);
+            double al[4], be[4];
+            if (k - s >= 1) row_load(rowbuf, nrow, buf, k - s, lo); else knot_row_identity(lo);
+            if (k + s <= N - 1) row_load(rowbuf, nrow, buf, k + s, hi); else knot_row_identity(hi);
+            pcr_step(me, lo, hi, out, al, be);
             me = out;
-            row_store(rowbuf, nthr, buf ^ 1, k, me);
+            row_store(rowbuf, nrow, buf ^ 1, k, me);
+            if (save) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { save[gk * sstride + step * 8 + i] = al[i]; save[gk * sstride + step * 8 + 4 + i] = be[i]; }
+            }
         }
         buf ^= 1;
         __syncthreads();
     }
-    if (act) pcr_finish(me, v, a);
+    if (act) {
+        pcr_finish(me, v, a);
+        if (save) {
+            double I[4];
+            m2_inv(me.D, I);
+#pragma unroll
+            for (int i = 0; i < 4; i++) save[gk * sstride + nsteps * 8 + i] = I[i];
+        }
+    }
+}
+
+// Right-hand-side-only reduction with the multipliers saved by the forward pass of the same evaluation (K is symmetric:
+// the adjoint system is the same matrix).  r = (rv[3], ra[3]) in, solution out.  LDS: rbuf[2][6][nrow].
+#define RBF(buf, f, t) rbuf[((buf) * 6 + (f)) * nrow + (t)]
+// `pw` = LDS copy [knot][nsteps*8+4 (+1 pad: odd stride, conflict-free)] of this candidate's saved multipliers.
+__device__ __forceinline__ void pcr_apply_wg(double *rbuf, int nrow, int k, int N, double *r, const double *pw, int nsteps) {
+    const bool act = k >= 1 && k <= N - 1;
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) RBF(0, i, k) = r[i];
+    }
+    __syncthreads();
+    int buf = 0, st = 0;
+    for (int s = 1; s < N - 1; s <<= 1, st++) {
+        {
+            if (act) {
+                double ab[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[i] = pw[k * (nsteps * 8 + 5) + st * 8 + i];
+                double rlo[6] = {0, 0, 0, 0, 0, 0}, rhi[6] = {0, 0, 0, 0, 0, 0};
+                if (k - s >= 1) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) rlo[i] = RBF(buf, i, k - s);
+                }
+                if (k + s <= N - 1) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) rhi[i] = RBF(buf, i, k + s);
+                }
+                pcr_rhs_step(r, ab, ab + 4, rlo, rhi);
+#pragma unroll
+                for (int i = 0; i < 6; i++) RBF(buf ^ 1, i, k) = r[i];
+            }
+            buf ^= 1;
+            __syncthreads();
+        }
+    }
+    if (act) {
+        double Dinv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) Dinv[i] = pw[k * (nsteps * 8 + 5) + nsteps * 8 + i];
+#pragma unroll
+        for (int x3 = 0; x3 < 3; x3++) {
+            const double rv = r[x3], ra = r[3 + x3];
+            r[x3] = Dinv[0] * rv + Dinv[1] * ra;
+            r[3 + x3] = Dinv[2] * rv + Dinv[3] * ra;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb) {
+                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
     double *rowbuf = sm;
-    double *KP = rowbuf + (size_t)36 * nthr;          // knot positions  [3][nthr+1]
-    double *KV = KP + 3 * (nthr + 1);
-    double *KA = KV + 3 * (nthr + 1);
-    double *Tf = KA + 3 * (nthr + 1);
-    double *Tc = Tf + nthr;
+    double *KP = rowbuf + (size_t)36 * nrow;          // knot positions  [3][nthr+1]
+    double *KV = KP + 3 * (nrow + 1);
+    double *KA = KV + 3 * (nrow + 1);
+    double *Tf = KA + 3 * (nrow + 1);
+    double *Tc = Tf + nrow;
     double *xs = Tc + maxCN;                          // this candidate's variables (tau, xi), staged once
     double *vs = xs + maxXb;                          // this candidate's waypoint polytopes [v0, edges], waypoint order
-#define KN(arr, axis, idx) arr[(axis) * (nthr + 1) + (idx)]
+#define KN(arr, axis, idx) arr[(axis) * (nrow + 1) + (idx)]
+    FRX_STAMP(0);
+    // Every global read of the kernel is issued here, before the first barrier, so the whole kernel pays ONE memory
+    // latency (loads placed in later phases cannot be hoisted over the barriers by the compiler: measured +4 us).
+    int r_pc = 0, r_piv = 1, r_wnv = 1, r_wvb = 0, r_wxb = 0;
+    double r_bs[6] = {0, 0, 0, 0, 0, 0};
+    if (k < N) { r_pc = dp.piece_coarse[p0 + k]; r_piv = dp.piece_iv[p0 + k]; }
+    if ((k >> 2) < N - 1) { const int gw = p0 - b + (k >> 2); r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }   // quad k>>2 = waypoint
+    if (k < 3) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) { r_bs[q] = dp.headPVA[b * 9 + 3 * q + k]; r_bs[3 + q] = dp.tailPVA[b * 9 + 3 * q + k]; }
+    }
     {   // coalesced staging: every later access is an LDS access (the per-waypoint loops would otherwise serialise
         // one global-memory latency per vertex)
         const int nx = dp.xoff[b + 1] - x0;
@@ -481,6 +559,7 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
         for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
     }
     __syncthreads();
+    FRX_STAMP(1);
 
     // forwardT (CPU.hpp:626-676)
     if (dp.soft) {
@@ -502,33 +581,45 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
     // splitToFineT (CPU.hpp:930-944)
     double hMine = 1.0;
     if (k < N) {
-        const int gc = dp.piece_coarse[p0 + k];
-        hMine = Tc[gc - c0] / dp.coarse_iv[gc];
+        hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
         Tout[p0 + k] = hMine;
     }
-    // forwardP (CPU.hpp:729-747): knot k = waypoint k-1
-    if (k >= 1 && k <= N - 1) {
-        const int gw = p0 - b + (k - 1);
-        const int nv1 = dp.wp_nv[gw] - 1;
-        const double *V = vs + 3 * (dp.wp_vbeg[gw] - dp.cvoff[b]);
-        const double *xi = xs + (dp.wp_xbeg[gw] - x0);
-        double nrm = 0.0;
-        for (int a = 0; a < nv1; a++) nrm += xi[a] * xi[a];
-        const double sc = 2.0 / (1.0 + nrm);
-        double q0 = 0.0, q1 = 0.0, q2 = 0.0;
-        for (int a = 0; a < nv1; a++) {
-            const double r = sc * xi[a], rr = r * r;
-            q0 += V[3 * (a + 1)] * rr; q1 += V[3 * (a + 1) + 1] * rr; q2 += V[3 * (a + 1) + 2] * rr;
+    FRX_STAMP(2);
+    // forwardP (CPU.hpp:729-747): waypoint w (= knot w+1) is handled by a QUAD of lanes, each taking every 4th vertex;
+    // q = v0 + (2/(1+|xi|^2))^2 * sum_a V_a xi_a^2 — one pass over the vertices, quad sums by DPP-class shuffles
+    for (int w0 = 0; w0 < N - 1; w0 += nthr / 4) {
+        const int w = w0 + (k >> 2), sub = k & 3;
+        double nrm = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
+        const bool wact = w < N - 1;
+        const double *V = vs, *xi = xs;
+        int nv1 = 0;
+        if (wact) {
+            int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;                  // prefetched for the first (usually only) pass
+            if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
+            nv1 = wnv - 1;
+            V = vs + 3 * (wvb - dp.cvoff[b]);
+            xi = xs + (wxb - x0);
+            for (int a = sub; a < nv1; a += 4) {
+                const double x2 = xi[a] * xi[a];
+                nrm += x2;
+                q0 += V[3 * (a + 1)] * x2; q1 += V[3 * (a + 1) + 1] * x2; q2 += V[3 * (a + 1) + 2] * x2;
+            }
         }
-        KN(KP, 0, k) = q0 + V[0]; KN(KP, 1, k) = q1 + V[1]; KN(KP, 2, k) = q2 + V[2];
+        nrm += __shfl_xor(nrm, 1, 64); q0 += __shfl_xor(q0, 1, 64); q1 += __shfl_xor(q1, 1, 64); q2 += __shfl_xor(q2, 1, 64);
+        nrm += __shfl_xor(nrm, 2, 64); q0 += __shfl_xor(q0, 2, 64); q1 += __shfl_xor(q1, 2, 64); q2 += __shfl_xor(q2, 2, 64);
+        if (wact && sub == 0) {
+            const double sc = 2.0 / (1.0 + nrm), sc2 = sc * sc;
+            KN(KP, 0, w + 1) = sc2 * q0 + V[0]; KN(KP, 1, w + 1) = sc2 * q1 + V[1]; KN(KP, 2, w + 1) = sc2 * q2 + V[2];
+        }
     }
     if (k < 3) {                                       // fixed head / tail knot states (CPU.hpp:440-442, 497-499)
-        KN(KP, k, 0) = dp.headPVA[b * 9 + k]; KN(KV, k, 0) = dp.headPVA[b * 9 + 3 + k]; KN(KA, k, 0) = dp.headPVA[b * 9 + 6 + k];
-        KN(KP, k, N) = dp.tailPVA[b * 9 + k]; KN(KV, k, N) = dp.tailPVA[b * 9 + 3 + k]; KN(KA, k, N) = dp.tailPVA[b * 9 + 6 + k];
+        KN(KP, k, 0) = r_bs[0]; KN(KV, k, 0) = r_bs[1]; KN(KA, k, 0) = r_bs[2];
+        KN(KP, k, N) = r_bs[3]; KN(KV, k, N) = r_bs[4]; KN(KA, k, N) = r_bs[5];
     }
     __syncthreads();
 
+    FRX_STAMP(3);
     // knot system rows + PCR
     KnotRow me;
     double vk[3] = {0, 0, 0}, ak[3] = {0, 0, 0};
@@ -555,7 +646,9 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
             me.U[0] = me.U[1] = me.U[2] = me.U[3] = 0.0;
         }
     }
-    pcr_solve_wg(rowbuf, nthr, k, N, me, vk, ak);
+    FRX_STAMP(4);
+    pcr_solve_wg(rowbuf, nrow, k, N, me, vk, ak, pcrw, (size_t)(nsteps * 8 + 4), (size_t)(p0 + k), nsteps);
+    FRX_STAMP(5);
     if (k >= 1 && k <= N - 1) {
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) { KN(KV, ax, k) = vk[ax]; KN(KA, ax, k) = ak[ax]; }
@@ -572,26 +665,42 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
             for (int q = 0; q < 6; q++) co[q * 3 + ax] = c[q];
         }
     }
+    FRX_STAMP(6);
 }
 
 __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
-                                double *__restrict__ g, int maxCN, int maxXb, int maxVb) {
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
     double *rowbuf = sm;
-    double *KP = rowbuf + (size_t)36 * nthr;          // reused: knot states, then end-of-piece adjoints, then mu
-    double *KV = KP + 3 * (nthr + 1);
-    double *KA = KV + 3 * (nthr + 1);
-    double *Tf = KA + 3 * (nthr + 1);
-    double *gT = Tf + nthr;
-    double *gCo = gT + nthr;
+    double *KP = rowbuf + (size_t)36 * nrow;          // reused: knot states, then end-of-piece adjoints, then mu
+    double *KV = KP + 3 * (nrow + 1);
+    double *KA = KV + 3 * (nrow + 1);
+    double *Tf = KA + 3 * (nrow + 1);
+    double *gT = Tf + nrow;
+    double *gCo = gT + nrow;
     double *red = gCo + maxCN;                         // [2 * nthr/64] cross-wave partials
     double *xs = red + 2 * (nthr >> 6) + 2;
     double *vs = xs + maxXb;
+    double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by k_forward_knot
+    FRX_STAMP(16);
+    // all global reads up front (see k_forward_knot)
+    double h = 1.0, c[18], cb[18], o0 = 0.0, o1 = 0.0, r_tl[3] = {0, 0, 0};
+    int r_wnv = 1, r_wvb = 0, r_wxb = 0;
+    if (k < N) {
+        h = Tin[p0 + k];
+        const double *ci = Cin + (size_t)(p0 + k) * 18;
+        const double *o = out20 + (size_t)(p0 + k) * 20;
+        o0 = o[0]; o1 = o[1];
+#pragma unroll
+        for (int q = 0; q < 18; q++) { c[q] = ci[q]; cb[q] = o[2 + q]; }
+    }
+    if ((k >> 2) < N - 1) { const int gw = p0 - b + (k >> 2); r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }   // quad k>>2 = waypoint
+    if (k < 3) { r_tl[0] = dp.tailPVA[b * 9 + k]; r_tl[1] = dp.tailPVA[b * 9 + 3 + k]; r_tl[2] = dp.tailPVA[b * 9 + 6 + k]; }
     {
         const int nx = dp.xoff[b + 1] - x0;
         const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
@@ -601,21 +710,27 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
 #pragma unroll 8
         for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
     }
+    {   // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
+        const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
+        const double2 *src = (const double2 *)(pcrw + (size_t)p0 * ws);
+#pragma unroll 8
+        for (int i2 = k; i2 < n2; i2 += nthr) {
+            const double2 v = src[i2];
+            const int e = 2 * i2, kn = e / ws, ff = e - kn * ws;            // ws even: both halves belong to the same knot
+            pw[kn * (ws + 1) + ff] = v.x; pw[kn * (ws + 1) + ff + 1] = v.y;
+        }
+    }
 
+    FRX_STAMP(17);
     // ---- piece-local: load, jerk energy + gradients (CPU.hpp:507-520, 65-95), cbar = d f / d c ----
-    double h = 1.0, c[18], cb[18], gTl = 0.0, costAcc = 0.0;
+    double gTl = 0.0, costAcc = 0.0;
     if (k < N) {
-        h = Tin[p0 + k];
         Tf[k] = h;
-        const double *ci = Cin + (size_t)(p0 + k) * 18;
-        const double *o = out20 + (size_t)(p0 + k) * 20;
-#pragma unroll
-        for (int q = 0; q < 18; q++) { c[q] = ci[q]; cb[q] = o[2 + q]; }
         const double t1 = h, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
         const double *c3 = c + 9, *c4 = c + 12, *c5 = c + 15;
         const double s33 = dot3(c3, c3), s43 = dot3(c4, c3), s44 = dot3(c4, c4), s53 = dot3(c5, c3), s54 = dot3(c5, c4), s55 = dot3(c5, c5);
-        costAcc = o[0] + (36.0 * s33 * t1 + 144.0 * s43 * t2 + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
-        gTl = o[1] + (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2 + 720.0 * s53 * t2 + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
+        costAcc = o0 + (36.0 * s33 * t1 + 144.0 * s43 * t2 + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
+        gTl = o1 + (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2 + 720.0 * s53 * t2 + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             cb[9 + d] += 72.0 * c3[d] * t1 + 144.0 * c4[d] * t2 + 240.0 * c5[d] * t3;
@@ -626,9 +741,10 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) { KN(KP, ax, k) = c[ax]; KN(KV, ax, k) = c[3 + ax]; KN(KA, ax, k) = 2.0 * c[6 + ax]; }
     }
-    if (k < 3) { KN(KP, k, N) = dp.tailPVA[b * 9 + k]; KN(KV, k, N) = dp.tailPVA[b * 9 + 3 + k]; KN(KA, k, N) = dp.tailPVA[b * 9 + 6 + k]; }
+    if (k < 3) { KN(KP, k, N) = r_tl[0]; KN(KV, k, N) = r_tl[1]; KN(KA, k, N) = r_tl[2]; }
     __syncthreads();
 
+    FRX_STAMP(18);
     // ---- Hermite adjoint per piece; end-of-piece parts go to the next knot through LDS ----
     double p1[3], v1[3], a1[3], sP[3] = {0, 0, 0}, sV[3] = {0, 0, 0}, sA[3] = {0, 0, 0}, eP[3], eV[3], eA[3], hb = 0.0;
     if (k < N) {
@@ -652,27 +768,31 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     }
     __syncthreads();
 
-    // ---- mu = K^-1 wbar (same SPD knot matrix, PCR) ----
-    KnotRow me;
+    FRX_STAMP(19);
+    // ---- mu = K^-1 wbar: same SPD knot matrix as the forward pass, whose reduction multipliers are re-used ----
     double muv[3] = {0, 0, 0}, mua[3] = {0, 0, 0}, pbk[3] = {0, 0, 0};
-    if (k >= 1 && k <= N - 1) {
-        knot_row_matrix(Tf[k - 1], h, me);
+    {
+        double rr[6] = {0, 0, 0, 0, 0, 0};
+        if (k >= 1 && k <= N - 1) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) {
-            me.r[ax] = sV[ax] + KN(KV, ax, k);
-            me.r[3 + ax] = sA[ax] + KN(KA, ax, k);
-            pbk[ax] = sP[ax] + KN(KP, ax, k);          // direct d f / d p_k (both adjacent pieces)
+            for (int ax = 0; ax < 3; ax++) {
+                rr[ax] = sV[ax] + KN(KV, ax, k);
+                rr[3 + ax] = sA[ax] + KN(KA, ax, k);
+                pbk[ax] = sP[ax] + KN(KP, ax, k);          // direct d f / d p_k (both adjacent pieces)
+            }
         }
-        if (k == 1) me.L[0] = me.L[1] = me.L[2] = me.L[3] = 0.0;
-        if (k == N - 1) me.U[0] = me.U[1] = me.U[2] = me.U[3] = 0.0;
+    FRX_STAMP(20);
+        pcr_apply_wg(rowbuf, nrow, k, N, rr, pw, nsteps);
+    FRX_STAMP(21);
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { muv[ax] = rr[ax]; mua[ax] = rr[3 + ax]; }
     }
-    pcr_solve_wg(rowbuf, nthr, k, N, me, muv, mua);
     // publish mu (zero at the fixed end knots) — reuse KV/KA
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
         if (k <= N) { KN(KV, ax, k) = (k >= 1 && k <= N - 1) ? muv[ax] : 0.0; KN(KA, ax, k) = (k >= 1 && k <= N - 1) ? mua[ax] : 0.0; }
     }
-    if (k == 0 && N == nthr) {
+    if (k == 0 && N == nrow) {
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) { KN(KV, ax, N) = 0.0; KN(KA, ax, N) = 0.0; }
     }
@@ -698,6 +818,7 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         for (int ax = 0; ax < 3; ax++) gq[ax] = pbk[ax] + KN(KP, ax, k) - dlb[ax];   // -dl of the piece starting here
     }
 
+    FRX_STAMP(22);
     // ---- cost (CPU.hpp:988) and mergeToCoarseGradT (CPU.hpp:946-959) ----
     double sumTc = 0.0;
     for (int i = k; i < cN; i += nthr) {
@@ -719,6 +840,7 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
             f[b] = tc + dp.rho * tt;
         }
     }
+    FRX_STAMP(23);
     // ---- addLayerTGrad (CPU.hpp:816-894) ----
     if (dp.soft) {
         for (int i = k; i < cN; i += nthr) g[x0 + i] = gCo[i] * dT_dtau(xs[i], dp.c2 != 0);
@@ -737,28 +859,43 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
             g[x0 + i] = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
         }
     }
-    // ---- addLayerPGrad (CPU.hpp:897-928): knot k = waypoint k-1 ----
+    // ---- addPropCtoP + addLayerPGrad (CPU.hpp:154-161, 897-928): waypoint w (= knot w+1) on a quad of lanes ----
+    __syncthreads();
     if (k >= 1 && k <= N - 1) {
-        const int gw = p0 - b + (k - 1);
-        const int nv1 = dp.wp_nv[gw] - 1;
-        const double *V = vs + 3 * (dp.wp_vbeg[gw] - dp.cvoff[b]);
-        const int xb = dp.wp_xbeg[gw];
-        const double *xi = xs + (xb - x0);
-        double qn = 0.0;
-        for (int a = 0; a < nv1; a++) qn += xi[a] * xi[a];
-        const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;
-        double gdq = 0.0;
-        for (int a = 0; a < nv1; a++) {
-            const double r = sc * xi[a];
-            const double gdr = (V[3 * (a + 1)] * gq[0] + V[3 * (a + 1) + 1] * gq[1] + V[3 * (a + 1) + 2] * gq[2]) * r * 2.0;
-            gdq += gdr * xi[a];
-        }
-        for (int a = 0; a < nv1; a++) {
-            const double r = sc * xi[a];
-            const double gdr = (V[3 * (a + 1)] * gq[0] + V[3 * (a + 1) + 1] * gq[1] + V[3 * (a + 1) + 2] * gq[2]) * r * 2.0;
-            g[xb + a] = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
-        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) KN(KP, ax, k) = gq[ax];      // d f / d q_k to the quad that owns the waypoint
     }
+    __syncthreads();
+    for (int w0 = 0; w0 < N - 1; w0 += nthr / 4) {
+        const int w = w0 + (k >> 2), sub = k & 3;
+        const bool wact = w < N - 1;
+        const double *V = vs, *xi = xs;
+        int nv1 = 0, xb = 0;
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, qn = 0.0, gdq = 0.0;
+        if (wact) {
+            int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
+            if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
+            nv1 = wnv - 1; xb = wxb;
+            V = vs + 3 * (wvb - dp.cvoff[b]);
+            xi = xs + (xb - x0);
+            g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
+            for (int a = sub; a < nv1; a += 4) qn += xi[a] * xi[a];
+        }
+        qn += __shfl_xor(qn, 1, 64); qn += __shfl_xor(qn, 2, 64);
+        const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;
+        if (wact)
+            for (int a = sub; a < nv1; a += 4) {
+                const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
+                gdq += gdr * xi[a];
+            }
+        gdq += __shfl_xor(gdq, 1, 64); gdq += __shfl_xor(gdq, 2, 64);
+        if (wact)
+            for (int a = sub; a < nv1; a += 4) {
+                const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
+                g[xb + a] = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
+            }
+    }
+    FRX_STAMP(24);
 #undef KN
 }
 #undef ROWF

@@ -65,8 +65,10 @@ FRX_HD void m2_mul(const double *A, const double *B, double *C) {
 
 // One parallel-cyclic-reduction step for row `me` with its neighbours at distance s (`lo` = k-s, `hi` = k+s;
 // pass identity rows beyond the ends).  After ceil(log2(n)) steps with s = 1,2,4,.. every row is decoupled.
-FRX_HD void pcr_step(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, KnotRow &out) {
-    double iLo[4], iHi[4], al[4], be[4], t[4];
+// al = L D_lo^-1 and be = U D_hi^-1 are the only things a further right-hand side needs from this step
+// (pcr_rhs_step): the adjoint solve of the same evaluation re-uses them instead of reducing the matrix again.
+FRX_HD void pcr_step(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, KnotRow &out, double *al, double *be) {
+    double iLo[4], iHi[4], t[4];
     m2_inv(lo.D, iLo);
     m2_inv(hi.D, iHi);
     m2_mul(me.L, iLo, al);                 // alpha = L D_lo^-1   (applied with a minus sign below)
@@ -82,6 +84,18 @@ FRX_HD void pcr_step(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, Kn
     for (int a = 0; a < 3; a++) {
         out.r[a] = me.r[a] - (al[0] * lo.r[a] + al[1] * lo.r[3 + a]) - (be[0] * hi.r[a] + be[1] * hi.r[3 + a]);
         out.r[3 + a] = me.r[3 + a] - (al[2] * lo.r[a] + al[3] * lo.r[3 + a]) - (be[2] * hi.r[a] + be[3] * hi.r[3 + a]);
+    }
+}
+FRX_HD void pcr_step(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, KnotRow &out) {
+    double al[4], be[4];
+    pcr_step(me, lo, hi, out, al, be);
+}
+// right-hand-side part of a step alone: r (2 x 3 axes) of this row and of its two neighbours
+FRX_HD void pcr_rhs_step(double *r, const double *al, const double *be, const double *rlo, const double *rhi) {
+    for (int a = 0; a < 3; a++) {
+        const double r0 = r[a] - (al[0] * rlo[a] + al[1] * rlo[3 + a]) - (be[0] * rhi[a] + be[1] * rhi[3 + a]);
+        const double r1 = r[3 + a] - (al[2] * rlo[a] + al[3] * rlo[3 + a]) - (be[2] * rhi[a] + be[3] * rhi[3 + a]);
+        r[a] = r0; r[3 + a] = r1;
     }
 }
 // decoupled row: w = D^-1 r  -> (v[3], a[3])

@@ -117,6 +117,17 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
 /* Replaces ~cuda_computer / kill_kernel (cc.cu:44-49, 566-579; GPU.hpp:907-909). */
 void frx_problem_destroy(frx_problem *p);
 
+/* Where the O(n) state of L-BFGS lives during frx_optimize.  In both modes every decision (Moré–Thuente / backtracking
+ * line search, convergence and stop tests, error codes: lbfgs.hpp:730-1033, 1295-1352) is taken on the host.
+ *   FRX_LBFGS_DEVICE_VECTORS (default) x, g, d, the (s,y) history and the two-loop recursion (lbfgs.hpp:1354-1411) stay on the
+ *                            device; per round and candidate 32 B of command go down and 40 B of scalars come back.
+ *   FRX_LBFGS_HOST_VECTORS   the vectors live on the host and run in the reference's exact operation order (bit-identical
+ *                            iterates given identical f, g); the gradient crosses PCIe every round.
+ * The environment variable FRX_LBFGS=host|device overrides the default. */
+#define FRX_LBFGS_DEVICE_VECTORS 0
+#define FRX_LBFGS_HOST_VECTORS 1
+int frx_problem_set_lbfgs_mode(frx_problem *p, int mode);
+
 /* How the MINCO map (q,T)->c and its adjoint are evaluated on the device.  Both compute the same spline:
  *   FRX_SOLVER_KNOT_PCR  (default) quintic-Hermite knot form, SPD 2x2-block tridiagonal system in the knot (v,a),
  *                        parallel cyclic reduction: O(log N) depth (fast-racing_amd/csrc/frx_minco.hpp)
@@ -125,6 +136,10 @@ void frx_problem_destroy(frx_problem *p);
 #define FRX_SOLVER_KNOT_PCR 0
 #define FRX_SOLVER_BANDED_LU 1
 int frx_problem_set_solver(frx_problem *p, int solver);
+
+/* Diagnostic: runs one evaluation at x and returns shader-clock stamps taken at the phase boundaries of candidate 0's
+ * k_forward_knot (out32[0..6]) and k_backward_knot (out32[16..24]). */
+int frx_profile_phases(frx_problem *p, const double *x, long long *out32);
 
 /* Totals: out6 = {B, total fine pieces, total coarse pieces, total free variables, max half-spaces per piece,
  * sum over fine pieces of their half-space count}. */
