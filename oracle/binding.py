@@ -106,6 +106,88 @@ def ref_lbfgs():
     return _ref_lbfgs
 
 
+_ref_gcopter = None
+
+
+def ref_gcopter():
+    """oracle/_ref/libref_gcopter.so = the reference's own CPU path (se3gcopter_cpu.hpp, trajectory.hpp, geoutils.hpp,
+    sdlp.hpp, quickhull.hpp, lbfgs.hpp) compiled where it lies against oracle/eigen_shim; None if absent."""
+    global _ref_gcopter
+    if _ref_gcopter is None:
+        path = os.path.join(HERE, "_ref", "libref_gcopter.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_create.restype = C.c_void_p
+        R.ref_create.argtypes = [C.POINTER(Config), _dp, _dp, C.c_int, _ip, _dp, _ip, _dp, C.c_int]
+        R.ref_destroy.argtypes = [C.c_void_p]
+        R.ref_dims.argtypes = [C.c_void_p, _ip]
+        R.ref_vpoly.restype = C.c_int
+        R.ref_vpoly.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        R.ref_initial_guess.argtypes = [C.c_void_p, _dp]
+        R.ref_objective.restype = C.c_double
+        R.ref_objective.argtypes = [C.c_void_p, _dp, _dp]
+        R.ref_forward.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        R.ref_penalty.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        R.ref_optimize.restype = C.c_double
+        R.ref_optimize.argtypes = [C.c_void_p, C.c_double, _dp, _dp]
+        _ref_gcopter = R
+    return _ref_gcopter
+
+
+class Reference:
+    """The reference's SE3GCOPTER itself (compiled from /root/reference against the Eigen shim)."""
+
+    def __init__(self, cand, params: dict, override_vs: bool = True, **override):
+        R = ref_gcopter()
+        if R is None:
+            raise RuntimeError("oracle/_ref/libref_gcopter.so not built")
+        self.R = R
+        self.cfg = Config.from_params(params, **override)
+        h_off, h_rec, v_off, v_rec = cand.packed()
+        ini = np.ascontiguousarray(cand.ini_state.T.reshape(-1)); fin = np.ascontiguousarray(cand.fin_state.T.reshape(-1))
+        self.h = R.ref_create(C.byref(self.cfg), ini, fin, cand.coarse_n, h_off, h_rec, v_off, v_rec, int(override_vs))
+        if not self.h:
+            raise RuntimeError("reference setup failed (empty polytope, or vertex counts differ from the supplied V-polytopes)")
+        d = np.zeros(4, dtype=np.int32)
+        R.ref_dims(self.h, d)
+        self.coarse_n, self.fine_n, self.dim_t, self.dim_p = (int(v) for v in d)
+        self.n = self.dim_t + self.dim_p
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.R.ref_destroy(self.h); self.h = None
+
+    def vpoly(self, m):
+        nv = self.R.ref_vpoly(self.h, m, None, 0)
+        out = np.zeros(3 * nv)
+        self.R.ref_vpoly(self.h, m, out.ctypes.data, nv)
+        return out.reshape(nv, 3).T.copy()
+
+    def initial_guess(self):
+        x = np.zeros(self.n); self.R.ref_initial_guess(self.h, x); return x
+
+    def objective(self, x):
+        g = np.zeros(self.n)
+        f = self.R.ref_objective(self.h, np.ascontiguousarray(x, dtype=np.float64), g)
+        return f, g
+
+    def forward(self, x):
+        T = np.zeros(self.fine_n); Cf = np.zeros(18 * self.fine_n)
+        self.R.ref_forward(self.h, np.ascontiguousarray(x, dtype=np.float64), T, Cf)
+        return T, Cf.reshape(-1, 3)
+
+    def penalty(self, T, Cf):
+        cost = np.zeros(1); gdT = np.zeros(self.fine_n); gdC = np.zeros(18 * self.fine_n)
+        self.R.ref_penalty(self.h, np.ascontiguousarray(T, dtype=np.float64), np.ascontiguousarray(Cf, dtype=np.float64).reshape(-1), cost, gdT, gdC)
+        return float(cost[0]), gdT, gdC.reshape(-1, 3)
+
+    def optimize(self, rel_cost_tol):
+        Cf = np.zeros(18 * self.fine_n); T = np.zeros(self.fine_n)
+        jc = self.R.ref_optimize(self.h, rel_cost_tol, Cf, T)
+        return dict(jerk_cost=jc, C=Cf.reshape(-1, 3), T=T)
+
+
 def use_reference_lbfgs(enable: bool) -> bool:
     """Make the oracle's optimize()/backwardP run on the reference's own L-BFGS (oracle/_ref)."""
     R = ref_lbfgs() if enable else None

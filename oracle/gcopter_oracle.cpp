@@ -3,13 +3,19 @@
 // the product (fast-racing_amd/csrc) never links, includes or calls anything in oracle/.
 //
 // PARITY PIN: the reference holds no tests, golden vectors or fixtures for plan_manage
-//  and its CPU path needs Eigen, which is absent here.  This file is a
-// plain-C++ restatement (no Eigen) that follows the reference line by line; each function
-// cites the lines it restates.  It is pinned (a) against the reference's own L-BFGS header
-// compiled where it lies (oracle/_ref, tests/test_lbfgs.py), (b) when oracle/_ref/libref_gcopter.so
-// could be built (reference CPU path + a minimal Eigen-API shim), against the reference's
-// own objective, and (c) by the self-checks of SURVEY.md §8c (finite differences, dense
-// linear algebra, spline invariants) in tests/test_oracle.py.
+// (SURVEY.md §4, §8c).  This file is a plain-C++ restatement (no Eigen) that follows the
+// reference line by line; each function cites the lines it restates.  It is PINNED against
+// outputs of the reference itself run in this container:
+//  (a) oracle/_ref/libref_gcopter.so = the reference's CPU path (se3gcopter_cpu.hpp, trajectory.hpp,
+//      geoutils.hpp, sdlp.hpp, quickhull.hpp, lbfgs.hpp) compiled UNMODIFIED where it lies, against
+//      oracle/eigen_shim (a minimal stand-in for the Eigen API those headers use — Eigen is not
+//      installed); tests/test_reference_pin.py: initial guess, forward map, penalty integrator and the
+//      full L-BFGS callback agree to 1e-15 ... 1e-10; the committed fixtures tests/golden/*.npz carry
+//      that library's outputs (ref_* arrays) to the GPU box;
+//  (b) oracle/_ref/libref_lbfgs.so = the reference's lbfgs.hpp alone: iterates bit-identical
+//      (tests/test_lbfgs.py);
+//  (c) the self-checks of SURVEY.md §8c (finite differences, dense linear algebra, spline
+//      invariants) in tests/test_oracle.py.
 //
 // reference files (relative to /root/reference/src/plan_manage/include/se3gcopter/):
 //   CPU.hpp  = se3gcopter_cpu.hpp      traj.hpp = trajectory.hpp      lbfgs.hpp

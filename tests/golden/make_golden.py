@@ -1,9 +1,11 @@
 """Generates tests/golden/*.npz: small seeded problems with the CPU oracle's outputs, so that
   - the oracle is guarded against silent regressions (tests/test_golden.py, CPU),
   - the GPU path is compared against committed numbers as well as against the live oracle.
-The reference has no fixtures of its own for this path and cannot be built here (no Eigen),
-so these vectors come from the line-by-line restatement in oracle/gcopter_oracle.cpp, whose L-BFGS is pinned
-bit-for-bit to the reference's lbfgs.hpp (tests/test_lbfgs.py).  Run from the repo root:
+The reference has no fixtures of its own for this path.  The `ref_*` arrays are OUTPUTS OF THE REFERENCE
+ITSELF: its CPU path (se3gcopter_cpu.hpp, trajectory.hpp, lbfgs.hpp, ...) compiled unmodified from /root/reference against
+oracle/eigen_shim (oracle/_ref/libref_gcopter.so), run on these inputs in this container.  The other arrays come from the
+restatement in oracle/gcopter_oracle.cpp (which tests/test_reference_pin.py pins to the same library).  /root/reference
+does not exist on the GPU box, which is why the vectors are committed.  Run from the repo root:
     python tests/golden/make_golden.py
 """
 import os
@@ -38,6 +40,15 @@ def build(name):
         f, g = o.objective(x); fs.append(f); gs.append(g)
         T, P, Cf = o.forward(x); Ts.append(T); Cs.append(Cf)
         c, gt, gc = o.penalty(T, Cf); pc.append(c); pt.append(gt); pg.append(gc)
+    if ob.ref_gcopter() is not None:
+        R = ob.Reference(cand, sc.ZHANGJIAJIE, override_vs=True, qd_intervals=kappa, **over)
+        rf, rg, rT, rC, rpc, rpt, rpg = [], [], [], [], [], [], []
+        for x in xs:
+            f, g = R.objective(x); rf.append(f); rg.append(g)
+            T, Cf = R.forward(x); rT.append(T); rC.append(Cf)
+            c, gt, gc = R.penalty(T, Cf); rpc.append(c); rpt.append(gt); rpg.append(gc)
+        out.update(ref_x0=R.initial_guess(), ref_f=np.array(rf), ref_g=np.array(rg), ref_T=np.array(rT), ref_C=np.array(rC),
+                   ref_pen_cost=np.array(rpc), ref_pen_gdT=np.array(rpt), ref_pen_gdC=np.array(rpg))
     r = o.optimize(1e-6)
     out.update(f=np.array(fs), g=np.array(gs), T=np.array(Ts), C=np.array(Cs), pen_cost=np.array(pc), pen_gdT=np.array(pt),
                pen_gdC=np.array(pg), opt_x=r["x"], opt_C=r["C"], opt_T=r["T"], opt_obj=np.array(r["objective"]),

@@ -45,6 +45,13 @@ def test_oracle_reproduces_golden(path, sc, ob):
         assert rel(T, d["T"][s]) < 1e-14 and rel(Cf, d["C"][s]) < 1e-11
         c, gt, gc = o.penalty(T, Cf)
         assert abs(c - d["pen_cost"][s]) <= 1e-12 * max(abs(d["pen_cost"][s]), 1e-300)
+    if "ref_f" in d:                                     # the reference's own outputs (oracle/_ref run at fixture time)
+        assert rel(o.initial_guess(), d["ref_x0"]) < 1e-13
+        for s, x in enumerate(d["x"]):
+            f, g = o.objective(x)
+            assert abs(f - d["ref_f"][s]) <= 1e-12 * abs(d["ref_f"][s]) and rel(g, d["ref_g"][s], abs(f)) < 1e-9
+            T, P, Cf = o.forward(x)
+            assert rel(Cf, d["ref_C"][s]) < 1e-10
     r = o.optimize(1e-6)
     # same compiler, same flags -> the very same iterate path
     assert r["iters"] == int(d["opt_iters"]) and r["status"] == int(d["opt_status"])
@@ -68,6 +75,13 @@ def test_device_reproduces_golden(path, frx, sc):
             cost, gdT, gdC = prob.penalty(d["T"][s], d["C"][s])
             assert abs(cost[0] - d["pen_cost"][s]) <= 1e-9 * max(abs(d["pen_cost"][s]), 1e-300)
             assert rel(gdT, d["pen_gdT"][s]) < 1e-9 and rel(gdC, d["pen_gdC"][s]) < 1e-9
+            if "ref_f" in d:                             # against the REFERENCE's own numbers
+                assert abs(f[0] - d["ref_f"][s]) <= 1e-9 * abs(d["ref_f"][s])
+                assert rel(g, d["ref_g"][s], abs(d["ref_f"][s])) < 1e-9
+                assert rel(Cf, d["ref_C"][s]) < 1e-7
+                cost, gdT, gdC = prob.penalty(d["ref_T"][s], d["ref_C"][s])
+                assert abs(cost[0] - d["ref_pen_cost"][s]) <= 1e-9 * max(abs(d["ref_pen_cost"][s]), 1e-300)
+                assert rel(gdT, d["ref_pen_gdT"][s]) < 1e-9 and rel(gdC, d["ref_pen_gdC"][s]) < 1e-9
         # optimised coefficients: device map at the golden minimiser (the 1e-6 contract, lock-step form)
         T, Cf = prob.forward(d["opt_x"])
         assert rel(Cf, d["opt_C"]) < 1e-6 and rel(T, d["opt_T"]) < 1e-12
