@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--config", default="headline", help="scenario.CONFIGS key (bench workload = headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plan", action="store_true")
+    ap.add_argument("--large-batch", type=int, default=1024, help="candidates of the extra large-batch k_penalty measurement (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -152,6 +153,33 @@ def main():
     pen_us = e0.elapsed_time(e1) * 1e3 / reps
     alg_bytes = prob.algorithmic_bytes()
     achieved = alg_bytes / (pen_us * 1e-6) / 1e9
+    # HBM traffic per launch of k_penalty from the committed PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # in separate runs, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): profiles/r01_pmc_headline.json
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_headline.json")
+    if os.path.exists(pmc_file) and args.config == "headline":
+        pj = json.load(open(pmc_file))
+        traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_pmc_headline.json"
+
+    # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
+    # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
+    large = None
+    if args.large_batch > 0 and rank == 0:
+        rep = max(1, args.large_batch // B)
+        big = frx.Problem(cands * rep, params, device=local_rank, qd_intervals=kappa)
+        Tb = torch.from_numpy(np.tile(T_h, rep)).cuda(); Cb = torch.from_numpy(np.tile(C_h.reshape(-1), rep)).cuda()
+        ob_ = torch.zeros(big.P * 20, dtype=torch.float64, device="cuda")
+        for _ in range(5):
+            big.penalty_device(Tb.data_ptr(), Cb.data_ptr(), ob_.data_ptr(), stream)
+        e0.record()
+        for _ in range(30):
+            big.penalty_device(Tb.data_ptr(), Cb.data_ptr(), ob_.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 30
+        large = {"candidates": big.B, "avg_kernel_us": us, "achieved": big.algorithmic_bytes() / (us * 1e-6) / 1e9, "unit": "GB/s",
+                 "frac": big.algorithmic_bytes() / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_samples_per_s": big.samples() / (us * 1e-6)}
+        big.close(); del Tb, Cb, ob_
 
     plan = {}
     if not args.no_plan:
@@ -183,8 +211,9 @@ def main():
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "frx::k_penalty", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_kernel_us": pen_us, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_kernel_us": pen_us, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
+                         "traffic_source": traffic_src, "large_batch": large},
             "cpu_baseline": cpu,
         }
         out.update(plan)
