@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
+    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample",
 ]
 
 _lib = None
@@ -81,6 +82,11 @@ def lib():
         L.frx_lbfgs_default_params.argtypes = [C.POINTER(LbfgsParams)]
         L.frx_lbfgs_gcopter_params.argtypes = [C.POINTER(LbfgsParams), C.c_double]
         L.frx_problem_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
+        L.frx_problem_create_from_h.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_int, _ip, _dp, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
+        L.frx_enumerate_vertices.argtypes = [C.c_int, _dp, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        _up = np.ctypeslib.ndpointer(dtype=np.uint32, flags='C_CONTIGUOUS')
+        L.frx_traj_to_msg.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up]
+        L.frx_msg_sample.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _up, C.c_double, _dp, _dp, _dp, _dp]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -137,17 +143,45 @@ def pack_batch(cands):
             np.array(v_off, dtype=np.int32), np.concatenate(v_rec).astype(np.float64))
 
 
+def enumerate_vertices(hpoly: np.ndarray) -> np.ndarray:
+    """Vertices (3 x nv) of a 6 x K H-polytope through the library (frx_enumerate_vertices)."""
+    rec = np.ascontiguousarray(hpoly.T.reshape(-1), dtype=np.float64)
+    nv = C.c_int()
+    _check(lib().frx_enumerate_vertices(hpoly.shape[1], rec, None, 0, C.byref(nv)))
+    out = np.zeros(3 * nv.value)
+    _check(lib().frx_enumerate_vertices(hpoly.shape[1], rec, out.ctypes.data, nv.value, C.byref(nv)))
+    return out.reshape(-1, 3).T.copy()
+
+
+def traj_to_msg(T, Cf):
+    """PolynomialTrajectory array fields of one trajectory: (coef_x, coef_y, coef_z, time, order)."""
+    n = len(T)
+    cx = np.zeros(6 * n); cy = np.zeros(6 * n); cz = np.zeros(6 * n); tm = np.zeros(n); od = np.zeros(n, np.uint32)
+    _check(lib().frx_traj_to_msg(n, np.ascontiguousarray(T, dtype=np.float64), np.ascontiguousarray(Cf, dtype=np.float64).reshape(-1), cx, cy, cz, tm, od))
+    return cx, cy, cz, tm, od
+
+
+def msg_sample(msg, t: float):
+    cx, cy, cz, tm, od = msg
+    p = np.zeros(3); v = np.zeros(3); a = np.zeros(3); j = np.zeros(3)
+    _check(lib().frx_msg_sample(len(tm), cx, cy, cz, tm, od, float(t), p, v, a, j))
+    return p, v, a, j
+
+
 class Problem:
     """A batch of candidate trajectories resident on one MI355X: the SE3GCOPTER::setup / optimize
     pair (CPU.hpp:1076, :1230) behind the C ABI."""
 
-    def __init__(self, cands, params: dict, device: int = 0, **override):
+    def __init__(self, cands, params: dict, device: int = 0, enumerate_v: bool = False, **override):
         self.cfg = FrxConfig.from_params(params, **override)
         self.kappa = int(self.cfg.qd_intervals)
         coarse_n, ini, fin, h_off, h_rec, v_off, v_rec = pack_batch(cands)
         h = C.c_void_p()
-        _check(lib().frx_problem_create(C.byref(self.cfg), device, len(cands), coarse_n, ini, fin, h_off, h_rec, v_off, v_rec,
-                                        C.byref(h)))
+        if enumerate_v:      # V-polytopes from the library's own H->V enumeration (frx_problem_create_from_h)
+            _check(lib().frx_problem_create_from_h(C.byref(self.cfg), device, len(cands), coarse_n, ini, fin, h_off, h_rec, C.byref(h)))
+        else:
+            _check(lib().frx_problem_create(C.byref(self.cfg), device, len(cands), coarse_n, ini, fin, h_off, h_rec, v_off, v_rec,
+                                            C.byref(h)))
         self.h = h
         t = np.zeros(6, dtype=np.int32)
         _check(lib().frx_problem_totals(self.h, t))

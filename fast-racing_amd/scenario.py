@@ -159,7 +159,7 @@ def _triples(K: int) -> np.ndarray:
 def enumerate_vertices(hpoly: np.ndarray, tol: float = 1e-9, quant: float = 1e-7) -> np.ndarray:
     """Vertices (3 x nv) of {x : n_k·(x − p_k) ≤ 0} by solving every plane triple (Cramer),
     keeping the feasible solutions, de-duplicating on a `quant` grid and sorting
-    lexicographically (so v0 and the vertex order are deterministic)."""
+    lexicographically by grid key (so v0 and the vertex order are deterministic)."""
     n = hpoly[:3].T / np.linalg.norm(hpoly[:3], axis=0)[:, None]      # K x 3 unit normals
     dd = np.einsum("kd,kd->k", n, hpoly[3:].T)                         # K offsets: n·x ≤ d
     tri = _triples(n.shape[0])
@@ -175,8 +175,9 @@ def enumerate_vertices(hpoly: np.ndarray, tol: float = 1e-9, quant: float = 1e-7
         return np.zeros((3, 0))
     key = np.round(x / quant).astype(np.int64)
     _, first = np.unique(key, axis=0, return_index=True)
-    x = x[np.sort(first)]
-    order = np.lexsort((x[:, 2], x[:, 1], x[:, 0]))
+    first = np.sort(first)
+    x, key = x[first], key[first]
+    order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))             # on the grid keys: immune to last-bit noise in ties
     return x[order].T.copy()
 
 

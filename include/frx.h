@@ -114,6 +114,29 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
                        const int *h_off, const double *h_rec,
                        const int *v_off, const double *v_rec,
                        frx_problem **out);
+/*
+ * Same, but the V-polytopes are enumerated here from the H-polytopes (cells and consecutive overlaps), replacing
+ * SE3GCOPTER::extractVs -> geoutils::enumerateVs (CPU.hpp:1031-1074, geoutils.hpp:43-149): the caller passes exactly what
+ * MavGlobalPlanner::plan passes to setup (MinCoPlan_CPU.cpp:93-123).  Vertices are ordered lexicographically (the
+ * reference's order depends on a process-global RNG; any fixed order parameterises the same polytope).
+ * Fails with FRX_ERR_EMPTY_POLYTOPE when a cell or an overlap has no interior (setup() == false, CPU.hpp:1118-1121).
+ */
+int frx_problem_create_from_h(const frx_config *cfg, int device, int B, const int *coarse_n,
+                              const double *ini_state, const double *fin_state,
+                              const int *h_off, const double *h_rec, frx_problem **out);
+/* Vertices (3 doubles each, lexicographic order) of one H-polytope given as K records (outer normal, point). */
+int frx_enumerate_vertices(int K, const double *h_rec, double *v_out, int cap, int *nv);
+
+/* Result wire format.  frx_traj_to_msg fills the array fields of quadrotor_msgs/PolynomialTrajectory the way
+ * MavGlobalPlanner::traj2msg does (se3_planner.cpp:31-58): per piece 6 duration-normalised coefficients per axis, highest
+ * power first (Piece::normalizePosCoeffMat, trajectory.hpp:131-141), time[] = durations, order[] = 5 (num_order = 5,
+ * mag_coeff = 1, action = ACTION_ADD are constants of that function).  frx_msg_sample evaluates such a message at time t
+ * after its start exactly like traj_server (traj_server.cpp:406-456): position, velocity, acceleration, jerk. */
+int frx_traj_to_msg(int n_pieces, const double *T, const double *C, double *coef_x, double *coef_y, double *coef_z,
+                    double *time, unsigned *order);
+int frx_msg_sample(int n_segment, const double *coef_x, const double *coef_y, const double *coef_z, const double *time,
+                   const unsigned *order, double t, double *pos, double *vel, double *acc, double *jerk);
+
 /* Replaces ~cuda_computer / kill_kernel (cc.cu:44-49, 566-579; GPU.hpp:907-909). */
 void frx_problem_destroy(frx_problem *p);
 

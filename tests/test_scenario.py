@@ -14,7 +14,8 @@ def test_generator_is_deterministic_and_well_formed(sc):
             n = h[:3] / np.linalg.norm(h[:3], axis=0)
             sd = np.einsum("dk,dkv->kv", n, v[:, None, :] - h[3:, :, None])
             assert sd.max() < 1e-7
-        assert np.all(np.lexsort((v[2], v[1], v[0])) == np.arange(v.shape[1]))   # lexicographic order, v0 first
+        kq = np.round(v / 1e-7)                             # lexicographic order of the grid keys, v0 first
+        assert np.all(np.lexsort((kq[2], kq[1], kq[0])) == np.arange(v.shape[1]))
 
 
 def test_perturbed_candidates_differ_and_nominal_is_shared(sc):
