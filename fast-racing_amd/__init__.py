@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
-    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample",
+    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def lib():
         _up = np.ctypeslib.ndpointer(dtype=np.uint32, flags='C_CONTIGUOUS')
         L.frx_traj_to_msg.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up]
         L.frx_msg_sample.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _up, C.c_double, _dp, _dp, _dp, _dp]
+        L.frx_dv_selftest.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -151,6 +152,14 @@ def enumerate_vertices(hpoly: np.ndarray) -> np.ndarray:
     out = np.zeros(3 * nv.value)
     _check(lib().frx_enumerate_vertices(hpoly.shape[1], rec, out.ctypes.data, nv.value, C.byref(nv)))
     return out.reshape(-1, 3).T.copy()
+
+
+def dv_selftest(n, B=4, m=128, iters=140, geom=None, seed=0, device=0):
+    """(worst relative error of the device search direction vs a host two-loop recursion, mean us of the last launches)."""
+    err, us = C.c_double(), C.c_double()
+    gp = (C.c_int * 4)(*geom) if geom else None
+    _check(lib().frx_dv_selftest(device, n, B, m, iters, gp, seed, C.byref(err), C.byref(us)))
+    return err.value, us.value
 
 
 def traj_to_msg(T, Cf):

@@ -170,10 +170,10 @@ struct frx_problem {
     // pinned staging
     PinBuf<double> h_x, h_f, h_g, h_T, h_C, h_out20;
     // device-vector L-BFGS state (allocated on first use)
-    DevBuf<double> d_xp, d_gp, d_dir, d_S, d_Y, d_ys;
+    DevBuf<double> d_xp, d_gp, d_dir, d_S, d_Y, d_ys, d_gt;
     PinBuf<frx::DvCommand> h_cmd;
     PinBuf<frx::DvResult> h_res;
-    int dv_mem = 0;
+    int dv_mem = 0; size_t dv_hs = 0;
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -554,6 +554,92 @@ int frx_profile_phases(frx_problem *p, const double *x, long long *out32) {
     return FRX_OK;
 }
 
+// Diagnostic (tests, tuning): drives k_lbfgs_pre alone.  `iters` successive accepted steps on random (x, g) sequences of
+// length n for B candidates; after each the device search direction is compared with a plain host two-loop recursion over
+// the same history (lbfgs.hpp:1381-1411, in the reference's order).  Returns the worst relative error (max-norm) and the
+// mean duration in us of the last min(iters, 32) launches.  geom4 = {E, W, PF, BLK} or null for the default choice.
+int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err, double *avg_us) {
+    if (n < 1 || B < 1 || m < 1 || m > 512 || iters < 1 || !max_rel_err || !avg_us) return fail(FRX_ERR_INVALID_ARG, "bad selftest argument");
+    HIP_TRY(hipSetDevice(device));
+    int E = 0, W = 0, PF = 0, BLK = 4;
+    frx::dv_geometry(n, &E, &W, &PF);
+    if (geom4) { E = geom4[0]; W = geom4[1]; PF = geom4[2]; BLK = geom4[3]; }
+    if (E == 0 || n > 64 * W * E) return fail(FRX_ERR_CAPACITY, "vector too long for k_lbfgs_pre");
+    const size_t HS = (size_t)64 * W * E, NX = (size_t)n * B;
+    DevBuf<double> dx, dg, dxp, dgp, dd, dS, dY, dys, dgt; DevBuf<int> dxoff;
+    PinBuf<frx::DvCommand> cmd; PinBuf<frx::DvResult> res;
+    hipError_t e;
+    if ((e = dx.alloc(NX)) || (e = dg.alloc(NX)) || (e = dxp.alloc(NX)) || (e = dgp.alloc(NX)) || (e = dd.alloc(NX)) || (e = dS.alloc(m * B * HS)) ||
+        (e = dY.alloc(m * B * HS)) || (e = dys.alloc((size_t)B * m)) || (e = dgt.alloc((size_t)B * m * 4)) || (e = dxoff.alloc(B + 1)) || (e = cmd.alloc(B)) || (e = res.alloc(B)))
+        return fail(FRX_ERR_ALLOC, hipGetErrorString(e));
+    HIP_TRY(hipMemset(dS.p, 0, sizeof(double) * m * B * HS)); HIP_TRY(hipMemset(dY.p, 0, sizeof(double) * m * B * HS));
+    HIP_TRY(hipMemset(dys.p, 0, sizeof(double) * B * m)); HIP_TRY(hipMemset(dgt.p, 0, sizeof(double) * B * m * 4));
+    std::vector<int> xoff(B + 1);
+    for (int b = 0; b <= B; b++) xoff[b] = b * n;
+    HIP_TRY(hipMemcpy(dxoff.p, xoff.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice));
+    frx::DvLaunch dv;
+    dv.xoff = dxoff.p; dv.x = dx.p; dv.g = dg.p; dv.xp = dxp.p; dv.gp = dgp.p; dv.d = dd.p; dv.S = dS.p; dv.Y = dY.p; dv.ys = dys.p; dv.gt = dgt.p;
+    dv.ld = NX; dv.m = m; dv.B = B; dv.E = E; dv.W = W; dv.PF = PF; dv.BLK = BLK;
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (seed + 1);
+    auto rnd = [&]() { st += 0x9E3779B97F4A7C15ull; unsigned long long z = st; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; };
+    std::vector<double> x(NX), g(NX), xp(NX), gp(NX), dref(n), ddev(NX);
+    std::vector<std::vector<double>> S(B * (size_t)m, std::vector<double>(n)), Y(B * (size_t)m, std::vector<double>(n));
+    std::vector<double> ysv((size_t)B * m), alpha(m);
+    for (size_t i = 0; i < NX; i++) { x[i] = rnd(); g[i] = rnd(); }
+    HIP_TRY(hipMemcpy(dx.p, x.data(), sizeof(double) * NX, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dg.p, g.data(), sizeof(double) * NX, hipMemcpyHostToDevice));
+    for (int b = 0; b < B; b++) { cmd.p[b].flags = frx::DV_INIT; cmd.p[b].slot = cmd.p[b].bound = cmd.p[b].newest = 0; cmd.p[b].step = 0.0; }
+    if (frx::launch_lbfgs_pre(dv, cmd.p, res.p, nullptr)) return fail(FRX_ERR_HIP, "k_lbfgs_pre launch (geometry not instantiated?)");
+    HIP_TRY(hipDeviceSynchronize());
+    xp = x; gp = g;
+    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    double worst = 0.0, us_sum = 0.0; int us_n = 0, end = 0;
+    for (int k = 1; k <= iters; k++) {
+        // the new accepted point: x moves by a random step that correlates with the gradient change, so y.s > 0 mostly
+        for (size_t i = 0; i < NX; i++) { const double sx = 0.1 * rnd(); x[i] = xp[i] + sx; g[i] = gp[i] + 3.0 * sx + 0.05 * rnd(); }
+        HIP_TRY(hipMemcpy(dx.p, x.data(), sizeof(double) * NX, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dg.p, g.data(), sizeof(double) * NX, hipMemcpyHostToDevice));
+        const int bound = m <= k ? m : k;
+        for (int b = 0; b < B; b++) { cmd.p[b].flags = frx::DV_ADVANCE; cmd.p[b].slot = end; cmd.p[b].bound = bound; cmd.p[b].newest = end; cmd.p[b].step = 0.0; }
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        if (frx::launch_lbfgs_pre(dv, cmd.p, res.p, nullptr)) return fail(FRX_ERR_HIP, "k_lbfgs_pre launch");
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (k > iters - 32) { us_sum += 1e3 * ms; us_n++; }
+        HIP_TRY(hipMemcpy(ddev.data(), dd.p, sizeof(double) * NX, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; b++) {
+            double *sx = S[(size_t)b * m + end].data(), *yx = Y[(size_t)b * m + end].data();
+            double ys = 0.0, yy = 0.0;
+            for (int i = 0; i < n; i++) { sx[i] = x[b * (size_t)n + i] - xp[b * (size_t)n + i]; yx[i] = g[b * (size_t)n + i] - gp[b * (size_t)n + i]; ys += yx[i] * sx[i]; yy += yx[i] * yx[i]; }
+            ysv[(size_t)b * m + end] = ys;
+            for (int i = 0; i < n; i++) dref[i] = -g[b * (size_t)n + i];
+            int j = (end + 1) % m;
+            for (int i = 0; i < bound; i++) {
+                j = (j + m - 1) % m;
+                const double *sj = S[(size_t)b * m + j].data(), *yj = Y[(size_t)b * m + j].data();
+                double a = 0.0; for (int q = 0; q < n; q++) a += sj[q] * dref[q];
+                a /= ysv[(size_t)b * m + j]; alpha[j] = a;
+                for (int q = 0; q < n; q++) dref[q] -= a * yj[q];
+            }
+            for (int q = 0; q < n; q++) dref[q] *= ys / yy;
+            for (int i = 0; i < bound; i++) {
+                const double *sj = S[(size_t)b * m + j].data(), *yj = Y[(size_t)b * m + j].data();
+                double be = 0.0; for (int q = 0; q < n; q++) be += yj[q] * dref[q];
+                be /= ysv[(size_t)b * m + j];
+                for (int q = 0; q < n; q++) dref[q] += (alpha[j] - be) * sj[q];
+                j = (j + 1) % m;
+            }
+            double num = 0.0, den = 0.0, dgr = 0.0;
+            for (int q = 0; q < n; q++) { num = std::max(num, std::fabs(dref[q] - ddev[b * (size_t)n + q])); den = std::max(den, std::fabs(dref[q])); dgr += dref[q] * g[b * (size_t)n + q]; }
+            worst = std::max(worst, num / den);
+            worst = std::max(worst, std::fabs(res.p[b].dginit - dgr) / std::max(std::fabs(dgr), 1e-300));
+        }
+        xp = x; gp = g; end = (end + 1) % m;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *max_rel_err = worst; *avg_us = us_n ? us_sum / us_n : 0.0;
+    return FRX_OK;
+}
+
 int frx_problem_totals(const frx_problem *p, int *out6) {
     if (!p || !out6) return fail(FRX_ERR_INVALID_ARG, "null argument");
     out6[0] = p->B; out6[1] = p->P; out6[2] = p->Pc; out6[3] = p->NX; out6[4] = p->Kmax; out6[5] = p->sumKfine;
@@ -689,26 +775,33 @@ static int finish_optimize(frx_problem *p, const double *x, double *C, double *T
 static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals,
                                    double *objective) {
     const int B = p->B, m = pm.mem_size;
-    int E = 0;
-    for (int cand : {2, 4, 8}) if (p->geo.maxXb <= 256 * cand) { E = cand; break; }   // doubles per thread of k_lbfgs_pre
+    // k_lbfgs_pre geometry (frx::dv_geometry).  FRX_DV_GEOM=E,W,PF,BLK overrides (experiments).
+    int E = 0, W = 0, PF = 0, BLK = 4;
+    frx::dv_geometry(p->geo.maxXb, &E, &W, &PF);
+    if (const char *gs = std::getenv("FRX_DV_GEOM")) {
+        int e, w, pf, blk;
+        if (std::sscanf(gs, "%d,%d,%d,%d", &e, &w, &pf, &blk) == 4 && p->geo.maxXb <= 64 * w * e) { E = e; W = w; PF = pf; BLK = blk; }
+    }
     if (E == 0 || m > 512 || m < 1) return 1;                                  // caller falls back to host vectors
+    const size_t HS = (size_t)64 * W * E;
     hipError_t e;
-    if (p->dv_mem != m) {
+    if (p->dv_mem != m || p->dv_hs != HS) {
         if ((e = p->d_xp.alloc(p->NX)) != hipSuccess || (e = p->d_gp.alloc(p->NX)) != hipSuccess || (e = p->d_dir.alloc(p->NX)) != hipSuccess ||
-            (e = p->d_S.alloc((size_t)m * B * 256 * E)) != hipSuccess || (e = p->d_Y.alloc((size_t)m * B * 256 * E)) != hipSuccess ||
-            (e = p->d_ys.alloc((size_t)B * m)) != hipSuccess || (e = p->h_cmd.alloc(B)) != hipSuccess || (e = p->h_res.alloc(B)) != hipSuccess)
+            (e = p->d_S.alloc((size_t)m * B * HS)) != hipSuccess || (e = p->d_Y.alloc((size_t)m * B * HS)) != hipSuccess ||
+            (e = p->d_ys.alloc((size_t)B * m)) != hipSuccess || (e = p->d_gt.alloc((size_t)B * m * 4)) != hipSuccess || (e = p->h_cmd.alloc(B)) != hipSuccess || (e = p->h_res.alloc(B)) != hipSuccess)
             return fail(FRX_ERR_ALLOC, std::string("device-vector L-BFGS buffers: ") + hipGetErrorString(e));
         // zero padding of the history slices is relied upon by the unconditional 16-byte loads of k_lbfgs_pre
-        if ((e = hipMemset(p->d_S.p, 0, sizeof(double) * (size_t)m * B * 256 * E)) != hipSuccess || (e = hipMemset(p->d_Y.p, 0, sizeof(double) * (size_t)m * B * 256 * E)) != hipSuccess)
+        if ((e = hipMemset(p->d_S.p, 0, sizeof(double) * (size_t)m * B * HS)) != hipSuccess || (e = hipMemset(p->d_Y.p, 0, sizeof(double) * (size_t)m * B * HS)) != hipSuccess)
             return fail(FRX_ERR_HIP, hipGetErrorString(e));
-        p->dv_mem = m;
+        p->dv_mem = m; p->dv_hs = HS;
     }
     frx::DvLaunch dv;
     dv.xoff = p->d_xoff.p; dv.x = p->d_x.p; dv.g = p->d_g.p; dv.xp = p->d_xp.p; dv.gp = p->d_gp.p; dv.d = p->d_dir.p;
-    dv.S = p->d_S.p; dv.Y = p->d_Y.p; dv.ys = p->d_ys.p; dv.ld = (size_t)p->NX; dv.m = m; dv.B = B; dv.E = E;
+    dv.S = p->d_S.p; dv.Y = p->d_Y.p; dv.ys = p->d_ys.p; dv.gt = p->d_gt.p; dv.ld = (size_t)p->NX; dv.m = m; dv.B = B; dv.E = E; dv.W = W; dv.PF = PF; dv.BLK = BLK;
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_ys.p, 0, sizeof(double) * (size_t)B * m, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_gt.p, 0, sizeof(double) * (size_t)B * m * 4, p->stream));
     std::vector<frx::SolverDV> sv(B);
     for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, p->h_cmd.p + b);
     auto wait_stream = [&]() -> hipError_t {

@@ -41,19 +41,22 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
 
 static DvBuffers to_buffers(const DvLaunch &dv) {
     DvBuffers b;
-    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.m = dv.m; b.B = dv.B;
+    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.gt = dv.gt; b.m = dv.m; b.B = dv.B;
     return b;
 }
 int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream) {
     const DvBuffers b = to_buffers(dv);
     const DvCommand *c = (const DvCommand *)cmd; DvResult *r = (DvResult *)res;
     hipStream_t st = (hipStream_t)stream;
-    switch (dv.E) {
-    case 2: hipLaunchKernelGGL(k_lbfgs_pre<2>, dim3(dv.B), dim3(256), 0, st, b, c, r); break;
-    case 4: hipLaunchKernelGGL(k_lbfgs_pre<4>, dim3(dv.B), dim3(256), 0, st, b, c, r); break;
-    case 8: hipLaunchKernelGGL(k_lbfgs_pre<8>, dim3(dv.B), dim3(256), 0, st, b, c, r); break;
+#define FRX_PRE(E_, W_, PF_, BLK_) case ((E_ * 16 + W_) * 64 + PF_) * 8 + BLK_: hipLaunchKernelGGL((k_lbfgs_pre<E_, W_, PF_, BLK_>), dim3(dv.B), dim3(64 * W_), 0, st, b, c, r); break;
+    switch (((dv.E * 16 + dv.W) * 64 + dv.PF) * 8 + dv.BLK) {
+    FRX_PRE(2, 1, 16, 4) FRX_PRE(2, 2, 16, 4) FRX_PRE(2, 3, 16, 4) FRX_PRE(2, 4, 16, 4) FRX_PRE(2, 5, 16, 4) FRX_PRE(2, 6, 16, 4) FRX_PRE(2, 7, 16, 4) FRX_PRE(2, 8, 16, 4)
+    FRX_PRE(4, 1, 8, 4) FRX_PRE(4, 2, 8, 4) FRX_PRE(4, 3, 8, 4) FRX_PRE(4, 4, 8, 4) FRX_PRE(4, 5, 8, 4) FRX_PRE(4, 6, 8, 4) FRX_PRE(4, 7, 8, 4) FRX_PRE(4, 8, 8, 4)
+    FRX_PRE(8, 1, 4, 4) FRX_PRE(8, 2, 4, 4) FRX_PRE(8, 3, 4, 4) FRX_PRE(8, 4, 4, 4) FRX_PRE(8, 5, 4, 4) FRX_PRE(8, 6, 4, 4) FRX_PRE(8, 7, 4, 4) FRX_PRE(8, 8, 4, 4)
+    FRX_PRE(4, 3, 8, 1) FRX_PRE(4, 3, 8, 2) FRX_PRE(2, 6, 16, 1)     // experiments (FRX_DV_GEOM)
     default: return (int)hipErrorInvalidValue;
     }
+#undef FRX_PRE
     return (int)hipGetLastError();
 }
 int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream) {

@@ -1,7 +1,7 @@
 // Device side of the device-vector L-BFGS (SolverDV in frx_lbfgs.hpp): everything O(n) of
 // lbfgs::lbfgs_optimize (lbfgs.hpp:1103-1444) — trial point x = xp + step*d, the dot products the line
 // search and the convergence tests need, the (s, y) history and the two-loop recursion — runs here, one
-// WAVE per candidate, the search direction resident in registers (E elements per lane, n <= 64 E).
+// WORKGROUP per candidate, the search direction resident in registers (E elements per thread, n <= 64 W E).
 // Dot products are reduced with DPP row operations in a fixed order (deterministic run to run).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,32 +32,38 @@ struct DvBuffers {
     const int *xoff;          // [B+1]
     double *x, *g;            // packed evaluation input / output (the objective kernels read x, write g)
     double *xp, *gp, *d;      // packed
-    double *S, *Y;            // [m][B][256*E]  history: row = slot, candidate slices zero-padded to 256*E doubles, so every
-                              // thread can issue unconditional 16-byte loads (thread t owns elements 2*(t + 256*q) + {0,1})
+    double *S, *Y;            // [B][m][TPB*E]  history: row = slot, rows zero-padded to TPB*E doubles, so every
+                              // thread can issue unconditional 16-byte loads (thread t owns elements 2*(t + TPB*q) + {0,1})
     double *ys;               // [B][m]   y.s per slot
+    double *gt;               // [B][m][4] cross products s_j . y_{j+d}, d = 1..3 (entry 3 unused), see k_lbfgs_pre
     int m, B;
 };
 
-// One 256-thread workgroup (4 waves) per candidate; E = doubles per THREAD (even), n <= 256*E.
+// One workgroup of W waves (TPB = 64 W threads) per candidate; E = doubles per THREAD (even), n <= TPB*E.  The host picks
+// the (E, W) with the smallest padded slice TPB*E >= n: the recursion is bound by what ONE CU can stream (4 m history rows
+// per advance), so padding is paid for in time (n ~ 700 at the headline size: 3 waves x 4 doubles = 768, not 1024).
 // Why 4 waves with a barrier per step rather than 1 wave: the 2*bound steps of the two-loop recursion are strictly
 // sequential and each consumes two fresh history rows (16 KB at n ~ 1000), so the rows have to be requested ~1.5 us
 // (= 8-12 steps) ahead.  A wave's outstanding-load counter holds 63; with a quarter of the vector per wave a row
 // costs each wave 2*E/2 loads, so 8 rows ahead fit, and the look-ahead buffers are 8 x 2 x E doubles of registers.
-template <int E>
-__global__ __launch_bounds__(256) void k_lbfgs_pre(DvBuffers bf, const DvCommand *__restrict__ cmd, DvResult *__restrict__ res) {
+template <int E, int W, int PF, int BLK>
+__global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvCommand *__restrict__ cmd, DvResult *__restrict__ res) {
     constexpr int Q = E / 2;                       // double2 elements per thread
-    constexpr int HS = 256 * E;                    // padded candidate slice of a history row, doubles
-    __shared__ double rhoS[512], alS[512], part[2][4];
+    constexpr int TPB = 64 * W;
+    constexpr int HS = TPB * E;                    // padded candidate slice of a history row, doubles
+    constexpr int TAB = 512 + 2 * 16;              // ages -pad .. V1-1, pad < PF <= 16
+    __shared__ double rhoA[TAB], alA[TAB], GA[BLK > 1 ? 4 * TAB : 1], part[2][8][6];
+    __shared__ int voff[2 * TAB];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const DvCommand c = cmd[b];
     if (!(c.flags & (DV_INIT | DV_ADVANCE | DV_TRIAL | DV_RESTORE))) return;
     const int base = bf.xoff[b], n = bf.xoff[b + 1] - base;
     double *x = bf.x + base, *g = bf.g + base, *xp = bf.xp + base, *gp = bf.gp + base, *d = bf.d + base;
-    // packed vectors: element i = 2*(t + 256*q) + h; clamp the index so loads are unconditional, select afterwards
+    // packed vectors: element i = 2*(t + TPB*q) + h; clamp the index so loads are unconditional, select afterwards
     int idx[E];
     bool ok[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) { const int i = 2 * (t + 256 * (e >> 1)) + (e & 1); ok[e] = i < n; idx[e] = ok[e] ? i : n - 1; }
+    for (int e = 0; e < E; e++) { const int i = 2 * (t + TPB * (e >> 1)) + (e & 1); ok[e] = i < n; idx[e] = ok[e] ? i : n - 1; }
     auto load_vec = [&](const double *v, double *out) {
         double tmp[E];
 #pragma unroll
@@ -70,17 +76,24 @@ __global__ __launch_bounds__(256) void k_lbfgs_pre(DvBuffers bf, const DvCommand
         for (int e = 0; e < E; e++) if (ok[e]) v[idx[e]] = in[e];
     };
     int parity = 0;
-    // block-wide sum in a fixed order: DPP inside each wave, the four wave totals added in wave order by every thread
-    auto block_sum = [&](double v) {
-        const double w = wave_sum_dpp(v);
-        if (lane == 0) part[parity][wave] = w;
-        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the history rows requested PF steps
-        // ahead, and turn the pipeline back into one memory latency per step
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const double r = ((part[parity][0] + part[parity][1]) + part[parity][2]) + part[parity][3];
+    // block-wide sum in a fixed order: DPP inside each wave, the W wave totals added in wave order by every thread
+    // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the history rows requested PF visits
+    // ahead, and turn the pipeline back into one memory latency per step
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto block_sum_n = [&](double *v, int nv) {                         // nv <= 5 sums at the price of one barrier, in place
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (k < nv) { const double w = wave_sum_dpp(v[k]); if (lane == 0) part[parity][wave][k] = w; }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (k < nv) {
+            double r = part[parity][0][k];
+#pragma unroll
+            for (int w = 1; w < W; w++) r += part[parity][w][k];
+            v[k] = r;
+        }
         parity ^= 1;
-        return r;
     };
+    auto block_sum = [&](double v) { block_sum_n(&v, 1); return v; };
 
     if (c.flags & DV_RESTORE) {                                        // lbfgs.hpp:1287-1288
         double tmp[E];
@@ -98,89 +111,142 @@ __global__ __launch_bounds__(256) void k_lbfgs_pre(DvBuffers bf, const DvCommand
         store_vec(xp, xv); store_vec(gp, gv); store_vec(d, dv);
         dginit = block_sum(acc);
     } else if (c.flags & DV_ADVANCE) {                                 // lbfgs.hpp:1354-1411
+        // Two-loop recursion, BLK pairs per reduction.  Sequentially, alpha_j needs s_j . q_j with q_j = q - sum_{newer i} alpha_i y_i;
+        // for the pairs of one block that is  s_j . q  -  sum_i alpha_i (s_j . y_i)  with q taken at the block start, and the cross
+        // products s_j . y_{j+d}, d = 1..BLK-1, do not depend on q: they are computed once, when pair j+d is stored (table gt).  The
+        // same table serves the second loop (y_{j+d} . r picks up (alpha_j - beta_j) y_{j+d} . s_j).  So a block costs ONE block-wide
+        // reduction + barrier instead of BLK, and no extra pass over the history.
+        //
+        // The loops are bound by how many instructions ONE wave has to issue per pair (every wave runs the whole serial chain), so
+        // everything indexable is tabulated up front: pairs are addressed by AGE (0 = newest ... last = oldest), the per-pair scalars
+        // (1/(y.s), cross products, alpha) live in LDS by age, and the byte offset of every row VISIT is precomputed.  Visits [0, V1)
+        // walk down the ages (V1 = bound rounded up to PF), visits [V1, 2 V1) walk back up; visits past the ends re-read an end row
+        // and are neutralised by a zero 1/(y.s).  Visit v lives in buffer v % PF and is requested PF visits ahead, unconditionally
+        // (a conditional reload makes the compiler wait for the load at once).
         const int m = bf.m;
-        const size_t rowstride = (size_t)bf.B * HS;                    // doubles between consecutive slots
-        double *Sb = bf.S + (size_t)b * HS, *Yb = bf.Y + (size_t)b * HS;
-        double *ysrow = bf.ys + (size_t)b * m;
-        for (int j = t; j < m; j += 256) { const double v = ysrow[j]; rhoS[j] = v != 0.0 ? 1.0 / v : 0.0; }
-        double a_ys = 0.0, a_yy = 0.0;
-        {
-            double xv[E], gv[E], tmp[E], sv[E], yv[E];
-            load_vec(x, xv); load_vec(g, gv);
-            load_vec(xp, tmp);
-#pragma unroll
-            for (int e = 0; e < E; e++) sv[e] = xv[e] - tmp[e];         // s = x - xp
-            load_vec(gp, tmp);
-#pragma unroll
-            for (int e = 0; e < E; e++) { yv[e] = gv[e] - tmp[e]; a_ys += yv[e] * sv[e]; a_yy += yv[e] * yv[e]; dv[e] = -gv[e]; }
-            store_vec(xp, xv); store_vec(gp, gv);                       // the accepted point becomes the base of the next search
-            double2 *Sw = (double2 *)(Sb + (size_t)c.slot * rowstride), *Yw = (double2 *)(Yb + (size_t)c.slot * rowstride);
-#pragma unroll
-            for (int q = 0; q < Q; q++) { Sw[t + 256 * q] = make_double2(sv[2 * q], sv[2 * q + 1]); Yw[t + 256 * q] = make_double2(yv[2 * q], yv[2 * q + 1]); }
+        double *Sb = bf.S + (size_t)b * m * HS, *Yb = bf.Y + (size_t)b * m * HS;      // this candidate's [m][HS] history blocks
+        double *ysrow = bf.ys + (size_t)b * m, *gtrow = bf.gt + (size_t)b * m * 4;
+        const int jnew = c.slot, last = c.bound - 1;                   // newest pair; older pairs are jnew-1, jnew-2, ... (mod m)
+        const int V1 = ((c.bound + PF - 1) / PF) * PF, pad = V1 - c.bound;               // table index = age + pad
+        auto row_of_age = [&](int a) { int j = jnew - a; return j < 0 ? j + m : j; };
+        for (int i = t; i < V1 + pad; i += TPB) {                      // ages -pad .. V1-1
+            const int a = i - pad;
+            const bool real = a >= 1 && a <= last;                     // age 0 is the pair formed below
+            const int j = row_of_age(real ? a : 0);
+            const double v = real ? ysrow[j] : 0.0;
+            rhoA[i] = v != 0.0 ? 1.0 / v : 0.0;
+            alA[i] = 0.0;
+            if (BLK > 1) { GA[4 * i] = real ? gtrow[4 * j] : 0.0; GA[4 * i + 1] = real ? gtrow[4 * j + 1] : 0.0; GA[4 * i + 2] = real ? gtrow[4 * j + 2] : 0.0; }
         }
-        const double ys = block_sum(a_ys), yy = block_sum(a_yy);
-        if (t == 0) { rhoS[c.slot] = 1.0 / ys; ysrow[c.slot] = ys; }
-        __syncthreads();
-        constexpr int PF = E <= 4 ? 8 : 4;
+        for (int v = t; v < 2 * V1 + PF; v += TPB) {
+            const int a = v < V1 ? min(v, last) : max(last - (v - V1), 0);
+            voff[v] = row_of_age(a) * (int)(HS * sizeof(double));
+        }
+        lds_barrier();
         double sb[PF][E], yb[PF][E];
-        const int jnew = c.slot;                                       // newest pair; older pairs are jnew-1, jnew-2, ... (mod m)
-        auto row_of_down = [&](int it) { int j = jnew - it; return j < 0 ? j + m : j; };            // first loop: newest -> oldest
-        auto load_row = [&](int u, int j) {
-            const double2 *Sj = (const double2 *)(Sb + (size_t)j * rowstride), *Yj = (const double2 *)(Yb + (size_t)j * rowstride);
+        const int toff = t * (int)sizeof(double2);
+        auto load_row = [&](int u, int v) {                           // buffer u <- row of visit v
+            const int off = voff[v] + toff;
+            const double2 *Sj = (const double2 *)((const char *)Sb + off), *Yj = (const double2 *)((const char *)Yb + off);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const double2 a = Sj[t + 256 * q], bq = Yj[t + 256 * q];
+                const double2 a = Sj[TPB * q], bq = Yj[TPB * q];
                 sb[u][2 * q] = a.x; sb[u][2 * q + 1] = a.y; yb[u][2 * q] = bq.x; yb[u][2 * q + 1] = bq.y;
             }
         };
-        // the pair written above is read back by other threads' loads only through the same thread's own elements
-        // (thread t reads exactly what thread t wrote), so no device-scope fence is needed before the first loop
-        // Branch-free groups of PF steps (loads unconditional, row index clamped into the valid range): a conditional
-        // reload would make the compiler merge old/new buffer registers and wait for the load it has just issued.
-        const int last = c.bound - 1, nfull = (c.bound / PF) * PF;
-        auto step_down = [&](int it, int u, bool refill) {
-            const int j = row_of_down(it);
-            double acc = 0.0;
 #pragma unroll
-            for (int e = 0; e < E; e++) acc += sb[u][e] * dv[e];
-            const double a = block_sum(acc) * rhoS[j];                 // alpha_j = (s_j . q) / (y_j . s_j)
-            if (t == 0) alS[j] = a;
+        for (int u = 1; u < PF; u++) load_row(u, u);                   // visit 0 is the pair formed below, kept in registers
+        double hd[5] = {0.0, 0.0, 0.0, 0.0, 0.0};                      // y.s, y.y, and s_{age d} . y_new for d = 1..3
+        {
+            double xv[E], gv[E], tmp[E];
+            load_vec(x, xv); load_vec(g, gv);
+            load_vec(xp, tmp);
 #pragma unroll
-            for (int e = 0; e < E; e++) dv[e] -= a * yb[u][e];
-            if (refill) load_row(u, row_of_down(min(it + PF, last)));
-        };
+            for (int e = 0; e < E; e++) sb[0][e] = xv[e] - tmp[e];     // s = x - xp
+            load_vec(gp, tmp);
 #pragma unroll
-        for (int u = 0; u < PF; u++) load_row(u, row_of_down(min(u, last)));
-        for (int it0 = 0; it0 < nfull; it0 += PF) {
+            for (int e = 0; e < E; e++) { yb[0][e] = gv[e] - tmp[e]; hd[0] += yb[0][e] * sb[0][e]; hd[1] += yb[0][e] * yb[0][e]; dv[e] = -gv[e]; }
+            store_vec(xp, xv); store_vec(gp, gv);                       // the accepted point becomes the base of the next search
+            double2 *Sw = (double2 *)(Sb + (size_t)jnew * HS), *Yw = (double2 *)(Yb + (size_t)jnew * HS);
 #pragma unroll
-            for (int u = 0; u < PF; u++) step_down(it0 + u, u, true);
+            for (int q = 0; q < Q; q++) { Sw[t + TPB * q] = make_double2(sb[0][2 * q], sb[0][2 * q + 1]); Yw[t + TPB * q] = make_double2(yb[0][2 * q], yb[0][2 * q + 1]); }
+            if (BLK > 1) {
+#pragma unroll
+                for (int d = 1; d < 4 && d < PF; d++)
+#pragma unroll
+                    for (int e = 0; e < E; e++) hd[1 + d] += sb[d][e] * yb[0][e];
+            }
         }
+        block_sum_n(hd, BLK > 1 ? 5 : 2);
+        const double ys = hd[0], yy = hd[1];
+        if (t == 0) {
+            rhoA[pad] = 1.0 / ys; ysrow[jnew] = ys;
+            if (BLK > 1)
+                for (int d = 1; d < 4 && d <= last; d++) { GA[4 * (pad + d) + d - 1] = hd[1 + d]; gtrow[4 * row_of_age(d) + d - 1] = hd[1 + d]; }
+        }
+        lds_barrier();
+        for (int v0 = 0; v0 < V1; v0 += PF) {
 #pragma unroll
-        for (int u = 0; u < PF; u++) if (nfull + u < c.bound) step_down(nfull + u, u, false);
-        __syncthreads();
+            for (int ub = 0; ub < PF; ub += BLK) {                     // one block: visits v0+ub .. +BLK-1 = ages, buffers ub ..
+                const int ia = pad + v0 + ub;                          // table index of the block's first (newest) pair
+                double raw[BLK], al[BLK];
+#pragma unroll
+                for (int k = 0; k < BLK; k++) {
+                    raw[k] = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; e++) raw[k] += sb[ub + k][e] * dv[e];
+                }
+                block_sum_n(raw, BLK);
+#pragma unroll
+                for (int k = 0; k < BLK; k++) {                        // alpha = (s . q) / (y . s)
+                    double a = raw[k];
+#pragma unroll
+                    for (int i = 0; i < k; i++) a -= al[i] * GA[4 * (ia + k) + (k - i - 1)];   // pair i of the block is k-i newer than pair k
+                    al[k] = a * rhoA[ia + k];
+                }
+                if (t == 0) {
+#pragma unroll
+                    for (int k = 0; k < BLK; k++) alA[ia + k] = al[k];
+                }
+#pragma unroll
+                for (int k = 0; k < BLK; k++)
+#pragma unroll
+                    for (int e = 0; e < E; e++) dv[e] -= al[k] * yb[ub + k][e];
+#pragma unroll
+                for (int k = 0; k < BLK; k++) load_row(ub + k, v0 + ub + k + PF);
+            }
+        }
+        lds_barrier();                                                 // alA complete before the second loop reads it
         const double h0 = ys / yy;
 #pragma unroll
         for (int e = 0; e < E; e++) dv[e] *= h0;
-        const int jold = row_of_down(c.bound - 1);                     // oldest pair in use
-        auto row_of_up = [&](int it) { int j = jold + it; return j >= m ? j - m : j; };              // second loop: oldest -> newest
-        auto step_up = [&](int it, int u, bool refill) {
-            const int j = row_of_up(it);
-            double acc = 0.0;
+        for (int v0 = 0; v0 < V1; v0 += PF) {
 #pragma unroll
-            for (int e = 0; e < E; e++) acc += yb[u][e] * dv[e];
-            const double coef = alS[j] - block_sum(acc) * rhoS[j];     // alpha_j - beta_j
+            for (int ub = 0; ub < PF; ub += BLK) {
+                const int ia = pad + last - (v0 + ub);                 // table index of the block's first (oldest) pair; the next is ia-1
+                double raw[BLK], cf[BLK];
 #pragma unroll
-            for (int e = 0; e < E; e++) dv[e] += coef * sb[u][e];
-            if (refill) load_row(u, row_of_up(min(it + PF, last)));
-        };
+                for (int k = 0; k < BLK; k++) {
+                    raw[k] = 0.0;
 #pragma unroll
-        for (int u = 0; u < PF; u++) load_row(u, row_of_up(min(u, last)));
-        for (int it0 = 0; it0 < nfull; it0 += PF) {
+                    for (int e = 0; e < E; e++) raw[k] += yb[ub + k][e] * dv[e];
+                }
+                block_sum_n(raw, BLK);
 #pragma unroll
-            for (int u = 0; u < PF; u++) step_up(it0 + u, u, true);
+                for (int k = 0; k < BLK; k++) {                        // beta = (y . r) / (y . s);  r += (alpha - beta) s
+                    double bsum = raw[k];
+#pragma unroll
+                    for (int i = 0; i < k; i++) bsum += cf[i] * GA[4 * (ia - i) + (k - i - 1)];   // pair k of the block is k-i newer than pair i
+                    cf[k] = alA[ia - k] - bsum * rhoA[ia - k];
+                }
+#pragma unroll
+                for (int k = 0; k < BLK; k++)
+#pragma unroll
+                    for (int e = 0; e < E; e++) dv[e] += cf[k] * sb[ub + k][e];
+#pragma unroll
+                for (int k = 0; k < BLK; k++) load_row(ub + k, min(V1 + v0 + ub + k + PF, 2 * V1 + PF - 1));
+            }
         }
-#pragma unroll
-        for (int u = 0; u < PF; u++) if (nfull + u < c.bound) step_up(nfull + u, u, false);
         double gv[E], acc = 0.0;
         load_vec(g, gv);
 #pragma unroll

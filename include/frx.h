@@ -137,6 +137,11 @@ int frx_traj_to_msg(int n_pieces, const double *T, const double *C, double *coef
 int frx_msg_sample(int n_segment, const double *coef_x, const double *coef_y, const double *coef_z, const double *time,
                    const unsigned *order, double t, double *pos, double *vel, double *acc, double *jerk);
 
+/* Diagnostic: k_lbfgs_pre (device two-loop recursion) against a host two-loop recursion on random histories, and its
+ * duration.  geom4 = {doubles/thread, waves, look-ahead rows, pairs per reduction} or NULL for the library's choice. */
+int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err,
+                    double *avg_us);
+
 /* Replaces ~cuda_computer / kill_kernel (cc.cu:44-49, 566-579; GPU.hpp:907-909). */
 void frx_problem_destroy(frx_problem *p);
 

@@ -282,3 +282,17 @@ def test_capacity_and_argument_errors(frx, sc):
     with pytest.raises(frx.FrxError):
         p.set_solver("banded_lu") if p.P > 170 else (_ for _ in ()).throw(frx.FrxError("skip"))
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,iters,geom", [
+    (700, 128, 140, None),                 # headline size: 3 waves x 4 doubles, wraps the 128-slot history
+    (700, 5, 23, None),                    # history shorter than the look-ahead, many wrap-arounds
+    (700, 7, 9, (4, 3, 8, 1)),             # one pair per reduction (the reference's sequential order)
+    (37, 3, 8, None), (129, 6, 15, None), (1500, 9, 12, None), (2048, 4, 6, None),
+])
+def test_device_two_loop_recursion_matches_host(frx, n, m, iters, geom):
+    """k_lbfgs_pre (blocked two-loop recursion, history in HBM) vs a host two-loop recursion on the same random history."""
+    err, us = frx.dv_selftest(n, B=3, m=m, iters=iters, geom=geom, seed=n + m)
+    print(f"n={n} m={m}: worst rel err {err:.2e}, {us:.1f} us/advance")
+    assert err < 1e-9
