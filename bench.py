@@ -152,6 +152,7 @@ def main():
     torch.cuda.synchronize()
     pen_us = e0.elapsed_time(e1) * 1e3 / reps
     alg_bytes = prob.algorithmic_bytes()
+    pairs_per_step = (kappa + 1) * prob.sum_K                        # sum over pieces of (kappa+1) K_i (secondary metric)
     achieved = alg_bytes / (pen_us * 1e-6) / 1e9
     # HBM traffic per launch of k_penalty from the committed PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # in separate runs, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): profiles/r01_pmc_headline.json
@@ -160,6 +161,16 @@ def main():
     if os.path.exists(pmc_file) and args.config == "headline":
         pj = json.load(open(pmc_file))
         traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_pmc_headline.json"
+
+    # VALU utilisation of the same kernel from the committed counter pass (scripts/gpu_pmc_valu.sh): the path is FP64-issue
+    # bound, not HBM bound (SURVEY.md 8d asks for the FP64 VALU fraction next to the HBM one)
+    valu = None
+    valu_file = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
+    if os.path.exists(valu_file) and args.config == "headline":
+        vj = json.load(open(valu_file))["launch_classes"]
+        cls = sorted(vj.items(), key=lambda kv: kv[1]["SQ_WAVES"])
+        valu = {"source": "profiles/r01_pmc_valu.json", "headline_valu_busy": cls[0][1]["valu_busy_frac"],
+                "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"], "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"]}
 
     # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
     # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
@@ -184,8 +195,18 @@ def main():
     plan = {}
     if not args.no_plan:
         if dist: dist.barrier()
+        # setup-equivalent host work (SE3GCOPTER::setup incl. H->V enumeration, CPU.hpp:1076-1186, and the first half of optimize:
+        # setInitial/backwardT/backwardP, CPU.hpp:1237-1240), timed on a second handle built from the H-polytopes alone
+        t_s = time.perf_counter()
+        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True)
+        t_setup = (time.perf_counter() - t_s) * 1e3
+        t_s = time.perf_counter()
+        p2.initial_guess()
+        t_guess = (time.perf_counter() - t_s) * 1e3
+        p2.close()
         r = prob.optimize(params["opt_rel_tol"], x0=x0)
-        plan = {"plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
+        plan = {"plan_setup_ms": t_setup, "plan_initial_guess_ms": t_guess, "plan_ms_with_setup": r["ms_total"] + t_setup + t_guess,
+                "plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
                 "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min())}
         # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
@@ -213,7 +234,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "frx::k_penalty", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_kernel_us": pen_us, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
-                         "traffic_source": traffic_src, "large_batch": large},
+                         "traffic_source": traffic_src, "large_batch": large, "valu": valu,
+                         "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)},
             "cpu_baseline": cpu,
         }
         out.update(plan)
