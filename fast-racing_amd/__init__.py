@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
-    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest",
+    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate",
 ]
 
 _lib = None
@@ -88,6 +88,9 @@ def lib():
         L.frx_traj_to_msg.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up]
         L.frx_msg_sample.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _up, C.c_double, _dp, _dp, _dp, _dp]
         L.frx_dv_selftest.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.frx_line_segment_dilate.argtypes = [_dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.frx_corridor_generate.argtypes = [C.c_int, _dp, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, BLOCKED_FN, C.c_void_p, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int), _ip, _dp]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -140,8 +143,9 @@ def pack_batch(cands):
             h_off.append(h_off[-1] + h.shape[1]); h_rec.append(h.T.reshape(-1))
         for v in c.v_polys:
             v_off.append(v_off[-1] + v.shape[1]); v_rec.append(v.T.reshape(-1))
+    v_all = np.concatenate(v_rec).astype(np.float64) if v_rec else np.zeros(0)      # no vertices: frx_problem_create_from_h
     return (coarse_n, ini, fin, np.array(h_off, dtype=np.int32), np.concatenate(h_rec).astype(np.float64),
-            np.array(v_off, dtype=np.int32), np.concatenate(v_rec).astype(np.float64))
+            np.array(v_off, dtype=np.int32), v_all)
 
 
 def enumerate_vertices(hpoly: np.ndarray) -> np.ndarray:
@@ -152,6 +156,31 @@ def enumerate_vertices(hpoly: np.ndarray) -> np.ndarray:
     out = np.zeros(3 * nv.value)
     _check(lib().frx_enumerate_vertices(hpoly.shape[1], rec, out.ctypes.data, nv.value, C.byref(nv)))
     return out.reshape(-1, 3).T.copy()
+
+
+BLOCKED_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def line_segment_dilate(p1, p2, bbox, obs, offset: float = 0.0):
+    """Corridor cell of one segment (frx_line_segment_dilate): (H 6 x K as [n; p] columns, ellipsoid C 3x3, centre d)."""
+    p1 = np.ascontiguousarray(p1, dtype=np.float64); p2 = np.ascontiguousarray(p2, dtype=np.float64); bbox = np.ascontiguousarray(bbox, dtype=np.float64)
+    obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+    n = C.c_int()
+    op = obs.ctypes.data if len(obs) else None
+    _check(lib().frx_line_segment_dilate(p1, p2, bbox, len(obs), op, offset, 0, C.byref(n), None, None, None))
+    rec = np.zeros(6 * n.value); Cm = np.zeros(9); d = np.zeros(3)
+    _check(lib().frx_line_segment_dilate(p1, p2, bbox, len(obs), op, offset, n.value, C.byref(n), rec.ctypes.data, Cm.ctypes.data, d.ctypes.data))
+    return rec.reshape(-1, 6).T.copy(), Cm.reshape(3, 3), d
+
+
+def corridor_generate(path, obs, bbox, map_height: float, max_seg: float = 4.0, blocked=None, cap_polys: int = 4096, cap_planes: int = 1 << 18):
+    """Greedy safe-flight corridor along `path` (n x 3) in the point cloud `obs` (frx_corridor_generate): list of 6 x K_i arrays."""
+    path = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, 3); obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+    cb = BLOCKED_FN(lambda a, b, u: int(bool(blocked(np.array(a[:3]), np.array(b[:3]))))) if blocked else C.cast(None, BLOCKED_FN)
+    n = C.c_int(); h_off = np.zeros(cap_polys + 1, dtype=np.int32); h_rec = np.zeros(6 * cap_planes)
+    _check(lib().frx_corridor_generate(len(path), path.reshape(-1), len(obs), obs.ctypes.data if len(obs) else None, np.ascontiguousarray(bbox, dtype=np.float64),
+                                       map_height, max_seg, cb, None, cap_polys, cap_planes, C.byref(n), h_off, h_rec))
+    return [h_rec[6 * h_off[k]:6 * h_off[k + 1]].reshape(-1, 6).T.copy() for k in range(n.value)]
 
 
 def dv_selftest(n, B=4, m=128, iters=140, geom=None, seed=0, device=0):

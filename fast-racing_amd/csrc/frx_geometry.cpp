@@ -2,6 +2,10 @@
 //   f1  H -> V vertex enumeration of the corridor cells and their consecutive overlaps, so that V-polytopes need not be
 //       supplied by the caller (reference: SE3GCOPTER::extractVs -> geoutils::enumerateVs, se3gcopter_cpu.hpp:1031-1074,
 //       geoutils.hpp:43-149: Seidel LP interior point + polar-dual quickhull + quantised de-duplication);
+//   f2  safe-flight-corridor generation: a line segment of the front-end path is inflated into the largest obstacle-free
+//       ellipsoid, obstacle points become tangent half-spaces, a local bounding box closes the cell (decomp_util:
+//       line_segment.h:31-35,47-85,136-214, decomp_base.h:35-83, ellipsoid.h:19-61), and cells are chained greedily along the
+//       path (MavGlobalPlanner::plan, MinCoPlan_CPU.cpp:37-105);
 //   f3  the result wire format: Trajectory -> quadrotor_msgs/PolynomialTrajectory fields (MavGlobalPlanner::traj2msg,
 //       se3_planner.cpp:31-58, with Piece::normalizePosCoeffMat, trajectory.hpp:131-141) and the consumer's sampling of it
 //       (traj_server.cpp:406-456).
@@ -13,6 +17,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../include/frx.h"
@@ -61,6 +66,189 @@ int enumerate(int K, const double *h, std::vector<std::array<double, 3>> &out, d
 }
 
 } // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// f2: corridor cells
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr double kDecompEps = 1e-10;                               // decomp_basis/data_type.h:129
+
+struct V3 { double x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+struct M3 { double m[3][3]; };
+inline V3 mul(const M3 &A, V3 v) { return {A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z, A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z, A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z}; }
+inline V3 mulT(const M3 &A, V3 v) { return {A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z, A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z, A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z}; }
+inline M3 mul(const M3 &A, const M3 &B) {
+    M3 C;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return C;
+}
+inline M3 transpose(const M3 &A) { M3 T; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T.m[i][j] = A.m[j][i]; return T; }
+inline M3 inverse(const M3 &A) {
+    auto cof = [&](int i, int j) { const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3; return A.m[i1][j1] * A.m[i2][j2] - A.m[i1][j2] * A.m[i2][j1]; };
+    const double det = cof(0, 0) * A.m[0][0] + cof(1, 0) * A.m[1][0] + cof(2, 0) * A.m[2][0];
+    M3 I;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I.m[j][i] = cof(i, j) / det;
+    return I;
+}
+// rotation that takes e_x to the direction of v with zero roll: R = Rz(yaw) Ry(pitch)   (geometric_utils.h:27-35)
+inline M3 rotation_from_direction(V3 v) {
+    const double pitch = std::atan2(-v.z, std::hypot(v.x, v.y)), yaw = std::atan2(v.y, v.x);
+    const double cp = std::cos(pitch), sp = std::sin(pitch), cy = std::cos(yaw), sy = std::sin(yaw);
+    return M3{{{cy * cp, -sy, cy * sp}, {sy * cp, cy, sy * sp}, {-sp, 0.0, cp}}};
+}
+inline M3 roll_about_x(double roll) { const double c = std::cos(roll), s = std::sin(roll); return M3{{{1.0, 0.0, 0.0}, {0.0, c, -s}, {0.0, s, c}}}; }
+
+struct Plane { V3 n, p; };                                         // outside is n . (x - p) > 0
+struct Ellipsoid3 {
+    M3 C, Cinv; V3 d;                                              // { C u + d : |u| <= 1 }
+    void set_shape(const M3 &R, double a0, double a1, double a2) {
+        const M3 D{{{a0, 0.0, 0.0}, {0.0, a1, 0.0}, {0.0, 0.0, a2}}};
+        C = mul(mul(R, D), transpose(R));
+        Cinv = inverse(C);
+    }
+    double dist(V3 pt) const { return norm(mul(Cinv, pt - d)); }   // ellipsoid.h:19-21
+    int closest(const std::vector<V3> &pts) const {                // ellipsoid.h:39-50: first of the minima
+        int best = -1; double dmin = std::numeric_limits<double>::max();
+        for (size_t i = 0; i < pts.size(); i++) { const double di = dist(pts[i]); if (di < dmin) { dmin = di; best = (int)i; } }
+        return best;
+    }
+};
+
+void local_bbox_planes(V3 p1, V3 p2, const double *bbox, std::vector<Plane> &out) {          // line_segment.h:47-85
+    if (std::sqrt(bbox[0] * bbox[0] + bbox[1] * bbox[1] + bbox[2] * bbox[2]) == 0.0) return;
+    V3 dir = p2 - p1; dir = dir * (1.0 / norm(dir));
+    V3 h{dir.y, -dir.x, 0.0};
+    if (norm(h) == 0.0) h = V3{-1.0, 0.0, 0.0};
+    h = h * (1.0 / norm(h));
+    out.push_back({h, p1 + h * bbox[1]}); out.push_back({h * -1.0, p1 - h * bbox[1]});
+    out.push_back({dir, p2 + dir * bbox[0]}); out.push_back({dir * -1.0, p1 - dir * bbox[0]});
+    const V3 v{dir.y * h.z - dir.z * h.y, dir.z * h.x - dir.x * h.z, dir.x * h.y - dir.y * h.x};
+    out.push_back({v, p1 + v * bbox[2]}); out.push_back({v * -1.0, p1 - v * bbox[2]});
+}
+inline bool inside_planes(const std::vector<Plane> &pl, V3 pt) {    // polyhedron.h: Polyhedron::inside
+    for (const auto &h : pl) if (dot(h.n, pt - h.p) > kDecompEps) return false;
+    return true;
+}
+
+// LineSegment3D::dilate (line_segment.h:31-35): ellipsoid, tangent half-spaces, local bounding box
+void dilate_segment(V3 p1, V3 p2, const double *bbox, const std::vector<V3> &cloud, double offset, std::vector<Plane> &planes, Ellipsoid3 &E) {
+    std::vector<Plane> box;
+    local_bbox_planes(p1, p2, bbox, box);
+    std::vector<V3> obs;                                           // decomp_base.h:35-40: only the points inside the local box count
+    for (const V3 &q : cloud) if (inside_planes(box, q)) obs.push_back(q);
+
+    // --- find_ellipsoid (line_segment.h:136-214)
+    const double f = norm(p1 - p2) / 2;
+    double a0 = f + offset, a1 = f, a2 = f;
+    if (a0 > 0) { const double ratio = a1 / a0; a0 *= ratio; a1 *= ratio; a2 *= ratio; }       // (C scaled alike)
+    const M3 Ri = rotation_from_direction(p2 - p1);
+    E.d = (p1 + p2) * 0.5;
+    E.set_shape(Ri, a0, a1, a2);
+    std::vector<V3> in0;
+    for (const V3 &q : obs) if (E.dist(q) <= 1) in0.push_back(q);
+    M3 Rf = Ri;
+    std::vector<V3> live = in0, next;
+    while (!live.empty()) {                                        // shrink the two short axes together, rolled towards the closest point
+        const V3 pw = live[E.closest(live)];
+        V3 p = mulT(Ri, pw - E.d);
+        Rf = mul(Ri, roll_about_x(std::atan2(p.z, p.y)));
+        p = mulT(Rf, pw - E.d);
+        if (p.x < a0) a1 = std::fabs(p.y) / std::sqrt(1 - (p.x / a0) * (p.x / a0));
+        E.set_shape(Rf, a0, a1, a1);
+        next.clear();
+        for (const V3 &q : live) if (1 - E.dist(q) > kDecompEps) next.push_back(q);
+        live.swap(next);
+    }
+    E.set_shape(Rf, a0, a1, a2);                                   // the third axis starts again from its old length
+    live.clear();
+    for (const V3 &q : in0) if (E.dist(q) <= 1) live.push_back(q);
+    while (!live.empty()) {
+        const V3 pw = live[E.closest(live)];
+        const V3 p = mulT(Rf, pw - E.d);
+        const double dd = 1 - (p.x / a0) * (p.x / a0) - (p.y / a1) * (p.y / a1);
+        if (dd > kDecompEps) a2 = std::fabs(p.z) / std::sqrt(dd);
+        E.set_shape(Rf, a0, a1, a2);
+        next.clear();
+        for (const V3 &q : live) if (1 - E.dist(q) > kDecompEps) next.push_back(q);
+        live.swap(next);
+    }
+    // --- find_polyhedron (decomp_base.h:63-83): the tangent plane at the closest point cuts away everything behind it
+    planes.clear();
+    live = obs;
+    const M3 Q = mul(E.Cinv, transpose(E.Cinv));
+    while (!live.empty()) {
+        const V3 c = live[E.closest(live)];
+        V3 n = mul(Q, c - E.d); n = n * (1.0 / norm(n));           // ellipsoid.h:53-58
+        planes.push_back({n, c});
+        next.clear();
+        for (const V3 &q : live) if (dot(n, q - c) < 0) next.push_back(q);
+        live.swap(next);
+    }
+    planes.insert(planes.end(), box.begin(), box.end());
+}
+
+} // namespace
+
+extern "C" {
+
+int frx_line_segment_dilate(const double *p1, const double *p2, const double *bbox, int n_obs, const double *obs, double offset, int cap,
+                            int *n_planes, double *h_rec, double *ell_C, double *ell_d) {
+    if (!p1 || !p2 || !bbox || n_obs < 0 || (n_obs && !obs) || !n_planes) return FRX_ERR_INVALID_ARG;
+    std::vector<V3> cloud(n_obs);
+    for (int i = 0; i < n_obs; i++) cloud[i] = V3{obs[3 * i], obs[3 * i + 1], obs[3 * i + 2]};
+    std::vector<Plane> pl; Ellipsoid3 E;
+    dilate_segment(V3{p1[0], p1[1], p1[2]}, V3{p2[0], p2[1], p2[2]}, bbox, cloud, offset, pl, E);
+    *n_planes = (int)pl.size();
+    if (h_rec) {
+        if (cap < (int)pl.size()) return FRX_ERR_CAPACITY;
+        for (size_t k = 0; k < pl.size(); k++) { double *r = h_rec + 6 * k; r[0] = pl[k].n.x; r[1] = pl[k].n.y; r[2] = pl[k].n.z; r[3] = pl[k].p.x; r[4] = pl[k].p.y; r[5] = pl[k].p.z; }
+    }
+    if (ell_C) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ell_C[3 * i + j] = E.C.m[i][j];
+    if (ell_d) { ell_d[0] = E.d.x; ell_d[1] = E.d.y; ell_d[2] = E.d.z; }
+    return FRX_OK;
+}
+
+int frx_corridor_generate(int n_path, const double *path, int n_obs, const double *obs, const double *bbox, double map_height, double max_seg,
+                          frx_blocked_fn blocked, void *user, int cap_polys, int cap_planes, int *n_polys, int *h_off, double *h_rec) {
+    if (n_path < 2 || !path || !bbox || n_obs < 0 || (n_obs && !obs) || !n_polys || !h_off || !h_rec || cap_polys < 1) return FRX_ERR_INVALID_ARG;
+    std::vector<V3> cloud(n_obs);
+    for (int i = 0; i < n_obs; i++) cloud[i] = V3{obs[3 * i], obs[3 * i + 1], obs[3 * i + 2]};
+    auto P = [&](int i) { return V3{path[3 * i], path[3 * i + 1], path[3 * i + 2]}; };
+    std::vector<Plane> pl; Ellipsoid3 E;
+    int np = 0, used = 0;
+    h_off[0] = 0;
+    for (int i = 0; i < n_path - 1;) {                             // MinCoPlan_CPU.cpp:44-83
+        int k;
+        for (k = i + 1; k < n_path; k++) {                         // the farthest point still visible from path[i] and closer than max_seg
+            const bool hit = blocked ? blocked(path + 3 * i, path + 3 * k, user) != 0 : false;
+            if (hit || norm(P(i) - P(k)) >= max_seg) { k--; break; }
+        }
+        if (k < i + 1) k = i + 1;
+        if (k >= n_path) k = n_path - 1;
+        dilate_segment(P(i), P(k), bbox, cloud, 0.0, pl, E);
+        int j;
+        for (j = k; j < n_path; j++) if (!inside_planes(pl, P(j))) break;    // how far the path stays inside this cell (tested before
+        j--;                                                                 // the floor / ceiling planes are added, as in the reference)
+        pl.push_back({V3{0.0, 0.0, 1.0}, V3{0.0, 0.0, map_height}});         // MinCoPlan_CPU.cpp:85-91
+        pl.push_back({V3{0.0, 0.0, -1.0}, V3{0.0, 0.0, 0.0}});
+        if (np >= cap_polys || used + (int)pl.size() > cap_planes) return FRX_ERR_CAPACITY;
+        for (const Plane &h : pl) { double *r = h_rec + 6 * (size_t)used++; r[0] = h.n.x; r[1] = h.n.y; r[2] = h.n.z; r[3] = h.p.x; r[4] = h.p.y; r[5] = h.p.z; }
+        h_off[++np] = used;
+        if (j >= n_path - 1) break;
+        const int wp = (1 * i + 4 * j) / 5;                        // restart 4/5 of the way to where the path leaves the cell
+        i = wp > i ? wp : i + 1;                                   // (the reference would not advance, i.e. hang, when wp == i)
+    }
+    *n_polys = np;
+    return FRX_OK;
+}
+
+} // extern "C"
 
 extern "C" {
 

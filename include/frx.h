@@ -127,6 +127,23 @@ int frx_problem_create_from_h(const frx_config *cfg, int device, int B, const in
 /* Vertices (3 doubles each, lexicographic order) of one H-polytope given as K records (outer normal, point). */
 int frx_enumerate_vertices(int K, const double *h_rec, double *v_out, int cap, int *nv);
 
+/* Safe-flight-corridor generation, the step upstream of frx_problem_create_from_h.
+ * frx_line_segment_dilate = LineSegment3D::dilate(offset) (decomp_util/line_segment.h:31-35 with find_ellipsoid :136-214,
+ * DecompBase::find_polyhedron decomp_base.h:63-83, add_local_bbox line_segment.h:47-85, obstacle filter decomp_base.h:35-40):
+ * the cell of segment p1-p2 in the point cloud obs[3 n_obs] as (normal, point) records in the reference's order (planes tangent at
+ * points that lie ON the final ellipsoid tie at distance 1 and rounding orders them), optionally
+ * the inflated ellipsoid (C row-major 3x3, centre d).  Pass h_rec = NULL to query *n_planes.
+ * frx_corridor_generate = the corridor loop of MavGlobalPlanner::plan (MinCoPlan_CPU.cpp:37-105): cells chained greedily along
+ * path[3 n_path] (segments shorter than max_seg = 4 m and not `blocked`, restart at 4/5 of the in-cell span), floor and ceiling
+ * planes z in [0, map_height] appended; output in the CSR layout frx_problem_create takes.  `blocked` replaces
+ * MapUtil::isBlocked (map_util.h:417) and may be NULL (nothing blocks). */
+typedef int (*frx_blocked_fn)(const double *a, const double *b, void *user);
+int frx_line_segment_dilate(const double *p1, const double *p2, const double *bbox, int n_obs, const double *obs, double offset,
+                            int cap, int *n_planes, double *h_rec, double *ell_C, double *ell_d);
+int frx_corridor_generate(int n_path, const double *path, int n_obs, const double *obs, const double *bbox, double map_height,
+                          double max_seg, frx_blocked_fn blocked, void *user, int cap_polys, int cap_planes, int *n_polys,
+                          int *h_off, double *h_rec);
+
 /* Result wire format.  frx_traj_to_msg fills the array fields of quadrotor_msgs/PolynomialTrajectory the way
  * MavGlobalPlanner::traj2msg does (se3_planner.cpp:31-58): per piece 6 duration-normalised coefficients per axis, highest
  * power first (Piece::normalizePosCoeffMat, trajectory.hpp:131-141), time[] = durations, order[] = 5 (num_order = 5,

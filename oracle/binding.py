@@ -304,3 +304,67 @@ class Oracle:
         ret = lib().orc_optimize(self.h, rel_cost_tol, max_iterations, x, int(x0 is not None), Cf, T, C.byref(jc), C.byref(fo),
                                  C.byref(ne), C.byref(ni))
         return dict(status=ret, x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc.value, objective=fo.value, evals=ne.value, iters=ni.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# corridor generation: the reference's decomp_util compiled as it is, and the corridor loop restated
+# ---------------------------------------------------------------------------------------------------------------------
+_ref_decomp = None
+
+
+def ref_decomp():
+    """oracle/_ref/libref_decomp.so = the reference's decomp_util (line_segment.h, decomp_base.h, ellipsoid.h, polyhedron.h,
+    ellipsoid_decomp.h) compiled where it lies against oracle/eigen_shim; None if absent."""
+    global _ref_decomp
+    if _ref_decomp is None:
+        path = os.path.join(HERE, "_ref", "libref_decomp.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_line_segment_dilate.argtypes = [_dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp]
+        R.ref_decomp_dilate.argtypes = [_dp, _dp, _dp, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), _dp]
+        R.ref_poly_inside.argtypes = [C.c_int, _dp, _dp]
+        _ref_decomp = R
+    return _ref_decomp
+
+
+def ref_line_segment_dilate(p1, p2, bbox, obs, offset=0.0, cap=4096):
+    """LineSegment3D::dilate of the reference: (H 6 x K, ellipsoid C, d)."""
+    R = ref_decomp()
+    obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+    n = C.c_int(); rec = np.zeros(6 * cap); Cm = np.zeros(9); d = np.zeros(3)
+    rc = R.ref_line_segment_dilate(np.ascontiguousarray(p1, dtype=np.float64), np.ascontiguousarray(p2, dtype=np.float64), np.ascontiguousarray(bbox, dtype=np.float64),
+                                   len(obs), obs.ctypes.data if len(obs) else None, offset, cap, C.byref(n), rec, Cm, d)
+    assert rc == 0
+    return rec[:6 * n.value].reshape(-1, 6).T.copy(), Cm.reshape(3, 3), d
+
+
+def corridor_oracle(path, obs, bbox, map_height, max_seg=4.0, blocked=None, dilate=None):
+    """Restatement of the corridor loop of MavGlobalPlanner::plan (MinCoPlan_CPU.cpp:37-105) around a `dilate(p1, p2) -> H`
+    callable (by default the reference's own EllipsoidDecomp3D through libref_decomp.so): list of 6 x K_i arrays."""
+    path = np.asarray(path, dtype=np.float64).reshape(-1, 3)
+    if dilate is None:
+        dilate = lambda a, b: ref_line_segment_dilate(a, b, bbox, obs)[0]
+    polys, n, i = [], len(path), 0
+    while i < n - 1:                                                     # :44
+        k = i + 1
+        while k < n:                                                     # :47-52
+            if (blocked is not None and blocked(path[i], path[k])) or np.linalg.norm(path[i] - path[k]) >= max_seg:
+                k -= 1
+                break
+            k += 1
+        if k < i + 1: k = i + 1                                          # :53-55
+        if k >= n: k = n - 1                                             # :56
+        H = dilate(path[i], path[k])                                     # :57-62
+        j = k
+        while j < n:                                                     # :67-75  Polyhedron::inside, 1e-10 slack
+            sd = np.einsum("dk,dk->k", H[:3], path[j][:, None] - H[3:])
+            if np.any(sd > 1e-10): break
+            j += 1
+        j -= 1
+        zp = np.array([[0.0, 0.0, 1.0, 0.0, 0.0, map_height], [0.0, 0.0, -1.0, 0.0, 0.0, 0.0]]).T     # :85-91
+        polys.append(np.concatenate([H, zp], axis=1))
+        if j >= n - 1: break                                             # :77-79
+        wp = (1 * i + 4 * j) // 5                                        # :81-82 (integer arithmetic)
+        i = wp if wp > i else i + 1                                      # the reference does not advance when wp == i
+    return polys

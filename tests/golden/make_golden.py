@@ -57,7 +57,35 @@ def build(name):
     return out
 
 
+def build_corridor(seed):
+    """Corridor fixture: cells by the REFERENCE's decomp_util (oracle/_ref/libref_decomp.so) inside the oracle's restatement
+    of the corridor loop of MavGlobalPlanner::plan, on a synthetic front-end path and point cloud."""
+    rng = np.random.default_rng(seed)
+    gates = sc.make_gates(sc.SplitMix64(seed), 4)
+    wps = np.vstack([[0.0, 0.0, 1.0], gates, gates[-1] + [0.0, 15.0, 0.0]])
+    path = [wps[0]]
+    for a, b in zip(wps[:-1], wps[1:]):
+        m = int(np.ceil(np.linalg.norm(b - a) / 0.5))
+        path += [a + (b - a) * (t / m) for t in range(1, m + 1)]
+    path = np.array(path)
+    obs = []
+    while len(obs) < 500:
+        q = path[rng.integers(len(path))] + rng.normal(0, 3.0, 3)
+        if 0.0 < q[2] < 3.0 and np.min(np.linalg.norm(path - q, axis=1)) > 0.6:
+            obs.append(q)
+    obs = np.array(obs); bbox = np.array([4.0, 4.0, 2.5])
+    polys = ob.corridor_oracle(path, obs, bbox, 3.0)
+    h_off = np.cumsum([0] + [h.shape[1] for h in polys]).astype(np.int32)
+    return dict(path=path, obs=obs, bbox=bbox, map_height=np.array(3.0), h_off=h_off, h_rec=np.concatenate([h.T.reshape(-1) for h in polys]))
+
+
 if __name__ == "__main__":
+    if ob.ref_decomp() is not None:
+        d = build_corridor(5)
+        np.savez_compressed(os.path.join(os.path.dirname(__file__), "corridor_seed5.npz"), **d)
+        print("corridor_seed5:", len(d["h_off"]) - 1, "cells,", int(d["h_off"][-1]), "half-spaces")
+    if "--corridor-only" in sys.argv:
+        sys.exit(0)
     for name in CASES:
         d = build(name)
         np.savez_compressed(os.path.join(os.path.dirname(__file__), name + ".npz"), **d)

@@ -72,3 +72,118 @@ def test_create_from_h_equals_create_with_supplied_vertices(frx, sc):
     fa, ga = a.objective(xa); fb, gb = b.objective(xa)
     assert np.all(np.abs(fa - fb) <= 1e-9 * np.abs(fa)) and np.abs(ga - gb).max() <= 1e-9 * np.abs(ga).max()
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f2: corridor generation
+# ---------------------------------------------------------------------------------------------------------------------
+def _canon(H):
+    """half-spaces in a canonical order: the reference's order among planes tangent at points that all lie ON the final
+    ellipsoid (distance 1 +- 1 ulp each, e.g. the two contact points that fixed its short axes) is decided by rounding"""
+    key = np.round(H / 1e-6).astype(np.int64)
+    return H[:, np.lexsort(key[::-1])]
+
+
+def _cloud(rng, p1, p2, n, spread=3.0, clear=0.35):
+    """random obstacle points around segment p1-p2, none closer than `clear` to the segment"""
+    pts = []
+    d = p2 - p1; L = np.linalg.norm(d); u = d / L
+    while len(pts) < n:
+        q = p1 + u * rng.uniform(-2.0, L + 2.0) + rng.normal(0, spread, 3)
+        t = np.clip((q - p1) @ u, 0, L)
+        if np.linalg.norm(q - (p1 + t * u)) > clear:
+            pts.append(q)
+    return np.array(pts)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_line_segment_cell_matches_reference_decomp(frx, ob, seed):
+    """frx_line_segment_dilate vs the reference's LineSegment3D::dilate (compiled from its own headers): same half-spaces in
+    the same order, same ellipsoid."""
+    if ob.ref_decomp() is None:
+        pytest.skip("oracle/_ref/libref_decomp.so not built (reference tree absent)")
+    rng = np.random.default_rng(100 + seed)
+    p1 = rng.uniform(-5, 5, 3); p2 = p1 + rng.normal(0, 1, 3) * np.array([3.0, 3.0, 0.6])
+    if seed == 3: p2 = p1 + np.array([0.0, 0.0, 2.0])            # vertical segment: the degenerate branch of add_local_bbox
+    n = [0, 1, 5, 40, 200, 1000][seed % 6]
+    obs = _cloud(rng, p1, p2, n) if n else np.zeros((0, 3))
+    bbox = np.array([4.0, 4.0, 2.5]) if seed != 7 else np.zeros(3)
+    H, Cm, d = frx.line_segment_dilate(p1, p2, bbox, obs)
+    Hr, Cr, dr = ob.ref_line_segment_dilate(p1, p2, bbox, obs)
+    assert H.shape == Hr.shape
+    assert np.abs(_canon(H) - _canon(Hr)).max() < 1e-9 and np.abs(Cm - Cr).max() < 1e-9 and np.abs(d - dr).max() < 1e-12
+    # every obstacle inside the local box is outside (or on) some tangent plane; the segment itself is inside the cell
+    for q in (p1, p2, 0.5 * (p1 + p2)):
+        assert np.all(np.einsum("dk,dk->k", H[:3], q[:, None] - H[3:]) <= 1e-9)
+
+
+def _scene(sc, seed, n_gates=4, n_obs=600):
+    rng = np.random.default_rng(seed)
+    g = sc.SplitMix64(seed)
+    gates = sc.make_gates(g, n_gates)
+    wps = np.vstack([[0.0, 0.0, 1.0], gates, gates[-1] + [0.0, 15.0, 0.0]])
+    path = [wps[0]]
+    for a, b in zip(wps[:-1], wps[1:]):                           # dense front-end-like path, 0.5 m spacing
+        m = int(np.ceil(np.linalg.norm(b - a) / 0.5))
+        path += [a + (b - a) * (t / m) for t in range(1, m + 1)]
+    path = np.array(path)
+    obs = []
+    while len(obs) < n_obs:
+        q = path[rng.integers(len(path))] + rng.normal(0, 3.0, 3)
+        if 0.0 < q[2] < 3.0 and np.min(np.linalg.norm(path - q, axis=1)) > 0.6:
+            obs.append(q)
+    return path, np.array(obs)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_corridor_matches_oracle_loop_around_reference_cells(frx, sc, ob, seed):
+    if ob.ref_decomp() is None:
+        pytest.skip("oracle/_ref/libref_decomp.so not built (reference tree absent)")
+    path, obs = _scene(sc, seed)
+    bbox = np.array(sc.ZHANGJIAJIE.get("polyhedron_box", [4.0, 4.0, 2.5]), dtype=float)
+    blocked = (lambda a, b: bool(np.linalg.norm(a - b) > 3.0 and (int(a[1]) + int(b[1])) % 7 == 0)) if seed == 3 else None
+    got = frx.corridor_generate(path, obs, bbox, 3.0, blocked=blocked)
+    want = ob.corridor_oracle(path, obs, bbox, 3.0, blocked=blocked)
+    assert len(got) == len(want) and len(got) >= 4
+    for H, Hw in zip(got, want):
+        assert H.shape == Hw.shape and np.abs(_canon(H) - _canon(Hw)).max() < 1e-9
+    # the corridor is usable: consecutive cells overlap with interior, and the whole path is covered
+    for H0, H1 in zip(got[:-1], got[1:]):
+        assert frx.enumerate_vertices(np.concatenate([H0, H1], axis=1)).shape[1] >= 4
+    for q in path:
+        assert any(np.all(np.einsum("dk,dk->k", H[:3], q[:, None] - H[3:]) <= 1e-9) for H in got)
+
+
+def test_corridor_golden(frx):
+    """committed fixture made with the reference's decomp_util (tests/golden/make_golden.py): runs without the reference tree"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "corridor_seed5.npz"))
+    got = frx.corridor_generate(z["path"], z["obs"], z["bbox"], float(z["map_height"]))
+    assert len(got) == len(z["h_off"]) - 1
+    for k, H in enumerate(got):
+        Hw = z["h_rec"][6 * z["h_off"][k]:6 * z["h_off"][k + 1]].reshape(-1, 6).T
+        assert H.shape == Hw.shape and np.abs(_canon(H) - _canon(Hw)).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_path_to_plan_through_the_library(frx, sc):
+    """front-end path + point cloud -> corridor (f2) -> vertices (f1) -> optimiser -> message (f3), all through the C ABI"""
+    path, obs = _scene(sc, 11, n_gates=3, n_obs=400)
+    polys = frx.corridor_generate(path, obs, np.array([4.0, 4.0, 2.5]), 3.0)
+    ini = np.zeros((3, 3)); ini[:, 0] = path[0]
+    fin = np.zeros((3, 3)); fin[:, 0] = path[-1]
+    cand = sc.Candidate(ini_state=ini, fin_state=fin, h_polys=polys, v_polys=[], gates=np.zeros((0, 3)))
+    prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=8, enumerate_v=True)
+    r = prob.optimize(1e-5, max_iterations=400)
+    assert r["status"][0] >= 0 or r["iters"][0] == 400
+    T = r["T"][:prob.P]; Cf = r["C"][:6 * prob.P]
+    msg = frx.traj_to_msg(T, Cf)
+    p0, v0, _, _ = frx.msg_sample(msg, 0.0)
+    pe, ve, _, _ = frx.msg_sample(msg, float(T.sum()))
+    assert np.abs(p0 - path[0]).max() < 1e-6 and np.abs(pe - path[-1]).max() < 1e-6 and np.abs(v0).max() < 1e-6 and np.abs(ve).max() < 1e-6
+    # the optimised trajectory stays inside the corridor it was given (sampled; margin of the penalty's soft constraint)
+    edges = np.concatenate([[0.0], np.cumsum(T)])
+    for t in np.linspace(0, edges[-1], 200):
+        p, _, _, _ = frx.msg_sample(msg, float(t))
+        assert any(np.all(np.einsum("dk,dk->k", H[:3], p[:, None] - H[3:]) <= 0.3) for H in polys)
+    prob.close()
