@@ -174,6 +174,8 @@ struct frx_problem {
     PinBuf<frx::DvCommand> h_cmd;
     PinBuf<frx::DvResult> h_res;
     int dv_mem = 0; size_t dv_hs = 0;
+    // line-search tap of k_backward_knot (set only while optimize_device_vectors runs)
+    const double *tap_d = nullptr; const void *tap_cmd = nullptr; void *tap_res = nullptr;
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -278,7 +280,7 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
-    return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st);
+    return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st, p->tap_d, p->tap_cmd, p->tap_res);
 }
 
 } // namespace
@@ -442,7 +444,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN + maxXb + maxVb);
         ge.pcr_steps = 0;
         for (int s = 1; s < p->maxN - 1; s <<= 1) ge.pcr_steps++;
-        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * 4 + 2 + maxXb + maxVb + (size_t)(ge.pcr_steps * 8 + 5) * nt);
+        ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * 4 + 2 + 2 * maxXb + maxVb + (size_t)(ge.pcr_steps * 8 + 5) * nt);
     }
     const size_t lds_cap = 160 * 1024;
     if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
@@ -812,6 +814,11 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
             __builtin_ia32_pause();
         }
     };
+    // with the knot/PCR kernels the reductions the line search needs ride on k_backward_knot (LineSearchTap); the banded-LU
+    // kernels keep the separate k_lbfgs_post
+    const bool fused_post = p->geo.solver == frx::SOLVER_KNOT_PCR;
+    struct TapGuard { frx_problem *q; ~TapGuard() { q->tap_d = nullptr; q->tap_cmd = nullptr; q->tap_res = nullptr; } } tap_guard{p};
+    if (fused_post) { p->tap_d = p->d_dir.p; p->tap_cmd = p->h_cmd.p; p->tap_res = p->h_res.p; }
     double t_dev = 0.0, t_host = 0.0;
     long rounds = 0;
     const auto t0 = clk::now();
@@ -823,7 +830,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         HIP_TRY((hipError_t)frx::launch_lbfgs_pre(dv, p->h_cmd.p, p->h_res.p, p->stream));
         if (any_eval) {
             HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
-            HIP_TRY((hipError_t)frx::launch_lbfgs_post(dv, p->d_f.p, p->h_cmd.p, p->h_res.p, p->stream));
+            if (!fused_post) HIP_TRY((hipError_t)frx::launch_lbfgs_post(dv, p->d_f.p, p->h_cmd.p, p->h_res.p, p->stream));
         }
         HIP_TRY(wait_stream());
         t_dev += ms_since(td);

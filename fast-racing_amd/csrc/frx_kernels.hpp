@@ -21,8 +21,15 @@
 
 #include "frx_device.hpp"
 #include "frx_minco.hpp"
+#include "frx_lbfgs.hpp"
 
 namespace frx {
+
+// Optional epilogue of k_backward_knot for the device-vector L-BFGS: with d (the search direction) given, the kernel also
+// reduces g.d, x.x and g.g of candidates whose command carries DV_EVAL and writes the round's DvResult, which saves the
+// separate k_lbfgs_post launch (~5 us + a launch gap per round).  d == nullptr: plain objective evaluation.
+struct LineSearchTap { const double *d; const DvCommand *cmd; DvResult *res; };
+
 
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -670,7 +677,8 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
 
 __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
-                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps) {
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
+                                LineSearchTap tap) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
@@ -687,6 +695,9 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     double *xs = red + 2 * (nthr >> 6) + 2;
     double *vs = xs + maxXb;
     double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by k_forward_knot
+    double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
+    const bool tapped = tap.d != nullptr && (tap.cmd[b].flags & DV_EVAL);
+    double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
     FRX_STAMP(16);
     // all global reads up front (see k_forward_knot)
     double h = 1.0, c[18], cb[18], o0 = 0.0, o1 = 0.0, r_tl[3] = {0, 0, 0};
@@ -709,6 +720,10 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         for (int i = k; i < nx; i += nthr) xs[i] = x[x0 + i];
 #pragma unroll 8
         for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
+        if (tapped) {
+#pragma unroll 8
+            for (int i = k; i < nx; i += nthr) dsv[i] = tap.d[x0 + i];
+        }
     }
     {   // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
         const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
 
     FRX_STAMP(22);
     // ---- cost (CPU.hpp:988) and mergeToCoarseGradT (CPU.hpp:946-959) ----
-    double sumTc = 0.0;
+    double sumTc = 0.0, fval = 0.0;
     for (int i = k; i < cN; i += nthr) {
         const int gc = c0 + i;
         const int iv = dp.coarse_iv[gc], fb = dp.coarse_fbeg[gc] - p0;
@@ -837,13 +852,18 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         if (k == 0) {
             double tc = 0.0, tt = 0.0;
             for (int i = 0; i < nw; i++) { tc += red[i]; tt += red[nw + i]; }
-            f[b] = tc + dp.rho * tt;
+            fval = tc + dp.rho * tt;
+            f[b] = fval;
         }
     }
     FRX_STAMP(23);
     // ---- addLayerTGrad (CPU.hpp:816-894) ----
     if (dp.soft) {
-        for (int i = k; i < cN; i += nthr) g[x0 + i] = gCo[i] * dT_dtau(xs[i], dp.c2 != 0);
+        for (int i = k; i < cN; i += nthr) {
+            const double gi = gCo[i] * dT_dtau(xs[i], dp.c2 != 0);
+            g[x0 + i] = gi;
+            if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
+        }
     } else if (k == 0) {
         const int Ms1 = cN - 1;
         const double gTail = dp.sumT * gCo[Ms1];
@@ -856,7 +876,9 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         const double den = expTauSum + 1.0;
         for (int i = 0; i < Ms1; i++) {
             const double de = dT_dtau(xs[i], dp.c2 != 0);
-            g[x0 + i] = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
+            const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
+            g[x0 + i] = gi;
+            if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
         }
     }
     // ---- addPropCtoP + addLayerPGrad (CPU.hpp:154-161, 897-928): waypoint w (= knot w+1) on a quad of lanes ----
@@ -892,8 +914,25 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         if (wact)
             for (int a = sub; a < nv1; a += 4) {
                 const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
-                g[xb + a] = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
+                const double gi = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
+                g[xb + a] = gi;
+                if (tapped) { t_dg += gi * dsv[xb - x0 + a]; t_xx += xi[a] * xi[a]; t_gg += gi * gi; }
             }
+    }
+    // ---- line-search tap: what lbfgs.hpp:830 (g.d) and :1296-1297 (|x|, |g|) need, reduced here instead of in a separate launch ----
+    if (tap.d != nullptr) {                                           // uniform over the grid
+        const double w0 = wave_sum(t_dg), w1 = wave_sum(t_xx), w2 = wave_sum(t_gg);
+        const int nw = nthr >> 6, w = k >> 6;
+        __syncthreads();                                              // red[] was last read for f[b]
+        double *red3 = rowbuf;                                        // row buffer is dead by now
+        if ((k & 63) == 0) { red3[w] = w0; red3[nw + w] = w1; red3[2 * nw + w] = w2; }
+        __syncthreads();
+        if (k == 0 && tapped) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
+            DvResult *r = tap.res + b;
+            r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2;
+        }
     }
     FRX_STAMP(24);
 #undef KN
