@@ -296,3 +296,42 @@ def test_device_two_loop_recursion_matches_host(frx, n, m, iters, geom):
     err, us = frx.dv_selftest(n, B=3, m=m, iters=iters, geom=geom, seed=n + m)
     print(f"n={n} m={m}: worst rel err {err:.2e}, {us:.1f} us/advance")
     assert err < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["plumbing", "synthetic8", "headline"])
+def test_baseline_configs_objective_parity(frx, sc, ob, config):
+    """BASELINE.json configs[0..2] at their full sizes: batched objective and gradient against the oracle, candidate by
+    candidate, at the reference's initial guess and at the iterate after 40 oracle iterations."""
+    B, N, gates, kappa = sc.CONFIGS[config]
+    cands = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    oracles = [ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=kappa) for c in cands]
+    for o in oracles: o.set_abscissa_mode(False)
+    x0s = [o.initial_guess() for o in oracles]
+    for xs in (x0s, [o.optimize(1e-6, max_iterations=40, x0=x0)["x"] for o, x0 in zip(oracles, x0s)]):
+        f, g = prob.objective(np.concatenate(xs))
+        worst_f = worst_g = 0.0
+        for b, o in enumerate(oracles):
+            f_ref, g_ref = o.objective(xs[b])
+            worst_f = max(worst_f, abs(f[b] - f_ref) / abs(f_ref))
+            worst_g = max(worst_g, np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max() / max(np.abs(g_ref).max(), abs(f_ref)))
+        print(f"{config}: B={B} N={N} kappa={kappa}: worst rel err f {worst_f:.2e} grad {worst_g:.2e}")
+        assert worst_f < PER_EVAL_TOL and worst_g < PER_EVAL_TOL
+    prob.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["knot_pcr", "banded_lu"])
+def test_soft_time_exponential_diffeomorphism(frx, sc, ob, solver):
+    """UseC2Diffeo = false: T = exp(tau) (CPU.hpp:639-641 else-branch) with the soft total-time term"""
+    cands, prob, oracles = make(frx, sc, ob, 2, 16, 4, 8, c2_diffeo=0)
+    prob.set_solver(solver)
+    for s in range(3):
+        xs = [iterates(o)[s] for o in oracles]
+        f, g = prob.objective(np.concatenate(xs))
+        for b, o in enumerate(oracles):
+            f_ref, g_ref = o.objective(xs[b])
+            assert abs(f[b] - f_ref) <= PER_EVAL_TOL * abs(f_ref)
+            assert np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max() <= PER_EVAL_TOL * max(np.abs(g_ref).max(), abs(f_ref))
+    prob.close()
