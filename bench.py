@@ -94,11 +94,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available() or frx.lib().frx_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (libfrx has no CPU fallback)")
+    # test knobs (not used by the driver): FRX_BENCH_DEVICE pins every rank to one device and FRX_BENCH_BACKEND=gloo replaces RCCL,
+    # so that the N > 1 control flow can be exercised on a 1-GPU box
+    if os.environ.get("FRX_BENCH_DEVICE"):
+        local_rank = int(os.environ["FRX_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("FRX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     B, N, gates, kappa = sc.CONFIGS[args.config]
     if args.config in ("perturbed256", "montecarlo4096"): B //= 8          # these two are quoted over 8 GPUs (BASELINE.json configs[3], [4])
@@ -212,6 +220,10 @@ def main():
         t_guess = (time.perf_counter() - t_s) * 1e3
         p2.close()
         r = prob.optimize(params["opt_rel_tol"], x0=x0)
+        if dist:                                                         # the job's plan time is the slowest rank's
+            tm = torch.tensor([r["ms_total"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            r["ms_total"] = float(tm.item())
         plan = {"plan_setup_ms": t_setup, "plan_initial_guess_ms": t_guess, "plan_ms_with_setup": r["ms_total"] + t_setup + t_guess,
                 "plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
