@@ -29,11 +29,11 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
 }
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
                     const double *band, const double *out20, double *f, double *grad, void *stream, const double *tap_d, const void *tap_cmd,
-                    void *tap_res) {
+                    void *tap_res, unsigned *tap_arrive, volatile unsigned *tap_flag, unsigned tap_round) {
     if (g.solver == SOLVER_KNOT_PCR)
         hipLaunchKernelGGL(k_backward_knot, dim3(dp.B), dim3(256), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
                            grad, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps,
-                           LineSearchTap{tap_d, (const DvCommand *)tap_cmd, (DvResult *)tap_res});
+                           LineSearchTap{tap_d, (const DvCommand *)tap_cmd, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round});
     else
         hipLaunchKernelGGL(k_backward, dim3(dp.B), dim3(64), g.lds_bwd, (hipStream_t)stream, dp, x, T, C, band, out20, f, grad, g.maxN,
                            g.maxCN);

@@ -50,7 +50,8 @@ int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, d
 int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, const double *C, double *out20, void *stream);
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
                     const double *band, const double *out20, double *f, double *grad, void *stream,
-                    const double *tap_d = nullptr, const void *tap_cmd = nullptr, void *tap_res = nullptr);
+                    const double *tap_d = nullptr, const void *tap_cmd = nullptr, void *tap_res = nullptr,
+                    unsigned *tap_arrive = nullptr, volatile unsigned *tap_flag = nullptr, unsigned tap_round = 0);
 
 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----

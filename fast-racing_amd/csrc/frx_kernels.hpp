@@ -28,7 +28,10 @@ namespace frx {
 // Optional epilogue of k_backward_knot for the device-vector L-BFGS: with d (the search direction) given, the kernel also
 // reduces g.d, x.x and g.g of candidates whose command carries DV_EVAL and writes the round's DvResult, which saves the
 // separate k_lbfgs_post launch (~5 us + a launch gap per round).  d == nullptr: plain objective evaluation.
-struct LineSearchTap { const double *d; const DvCommand *cmd; DvResult *res; };
+// `arrive`/`flag`/`round`: completion mailbox.  Every workgroup bumps the device counter after its result is visible system-wide;
+// the one that brings it to B * round writes `round` into a word of mapped host memory, on which the host spins instead of
+// polling the stream through the driver (the reference's cuda_computer signals completion the same way, cc.cu:384-405, 537-547).
+struct LineSearchTap { const double *d; const DvCommand *cmd; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; };
 
 
 
@@ -452,6 +455,8 @@ __device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nrow, int k, in
     int buf = 0, step = 0;
     if (act) row_store(rowbuf, nrow, 0, k, me);
     __syncthreads();
+    // Inside the loop the barrier only has to order LDS traffic.  __syncthreads() also waits for vmcnt(0), and on gfx9 the
+    // multiplier stores below count in vmcnt: every step would wait for its stores to be acknowledged by L2.
     for (int s = 1; s < N - 1; s <<= 1, step++) {
         if (act) {
             KnotRow lo, hi, out;
@@ -467,7 +472,7 @@ __device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nrow, int k, in
             }
         }
         buf ^= 1;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (act) {
         pcr_finish(me, v, a);
@@ -932,6 +937,10 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
             for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
             DvResult *r = tap.res + b;
             r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2;
+        }
+        if (k == 0 && tap.arrive) {
+            __threadfence_system();
+            if (atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) { *tap.flag = tap.round; __threadfence_system(); }
         }
     }
     FRX_STAMP(24);
