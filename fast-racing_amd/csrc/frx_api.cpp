@@ -175,9 +175,9 @@ struct frx_problem {
     PinBuf<frx::DvResult> h_res;
     int dv_mem = 0; size_t dv_hs = 0;
     // line-search tap of k_backward_knot (set only while optimize_device_vectors runs)
-    const double *tap_d = nullptr; const void *tap_cmd = nullptr; void *tap_res = nullptr;
+    const double *tap_d = nullptr; const int *tap_flags = nullptr; void *tap_res = nullptr;
     unsigned *tap_arrive = nullptr; volatile unsigned *tap_flag = nullptr; unsigned tap_round = 0;
-    DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag;
+    DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags;
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -282,7 +282,7 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
-    return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st, p->tap_d, p->tap_cmd, p->tap_res, p->tap_arrive, p->tap_flag, p->tap_round);
+    return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st, p->tap_d, p->tap_flags, p->tap_res, p->tap_arrive, p->tap_flag, p->tap_round);
 }
 
 } // namespace
@@ -819,10 +819,14 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     // with the knot/PCR kernels the reductions the line search needs ride on k_backward_knot (LineSearchTap); the banded-LU
     // kernels keep the separate k_lbfgs_post
     const bool fused_post = p->geo.solver == frx::SOLVER_KNOT_PCR;
-    struct TapGuard { frx_problem *q; ~TapGuard() { q->tap_d = nullptr; q->tap_cmd = nullptr; q->tap_res = nullptr; q->tap_arrive = nullptr; q->tap_flag = nullptr; } } tap_guard{p};
+    struct TapGuard { frx_problem *q; ~TapGuard() { q->tap_d = nullptr; q->tap_flags = nullptr; q->tap_res = nullptr; q->tap_arrive = nullptr; q->tap_flag = nullptr; } } tap_guard{p};
     const char *mb_env = std::getenv("FRX_MAILBOX");
     const bool mailbox = fused_post && !(mb_env && mb_env[0] == '0');
-    if (fused_post) { p->tap_d = p->d_dir.p; p->tap_cmd = p->h_cmd.p; p->tap_res = p->h_res.p; }
+    if (fused_post) {
+        if (!p->d_flags.p && (e = p->d_flags.alloc(B)) != hipSuccess) return fail(FRX_ERR_ALLOC, hipGetErrorString(e));
+        dv.dflags = p->d_flags.p;
+        p->tap_d = p->d_dir.p; p->tap_flags = p->d_flags.p; p->tap_res = p->h_res.p;
+    }
     if (mailbox) {
         if (!p->d_arrive.p && ((e = p->d_arrive.alloc(1)) != hipSuccess || (e = p->h_flag.alloc(1)) != hipSuccess)) return fail(FRX_ERR_ALLOC, hipGetErrorString(e));
         HIP_TRY(hipMemsetAsync(p->d_arrive.p, 0, sizeof(unsigned), p->stream));

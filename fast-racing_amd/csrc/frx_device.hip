@@ -28,12 +28,12 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
     return (int)hipGetLastError();
 }
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
-                    const double *band, const double *out20, double *f, double *grad, void *stream, const double *tap_d, const void *tap_cmd,
+                    const double *band, const double *out20, double *f, double *grad, void *stream, const double *tap_d, const int *tap_flags,
                     void *tap_res, unsigned *tap_arrive, volatile unsigned *tap_flag, unsigned tap_round) {
     if (g.solver == SOLVER_KNOT_PCR)
         hipLaunchKernelGGL(k_backward_knot, dim3(dp.B), dim3(256), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
                            grad, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps,
-                           LineSearchTap{tap_d, (const DvCommand *)tap_cmd, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round});
+                           LineSearchTap{tap_d, tap_flags, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round});
     else
         hipLaunchKernelGGL(k_backward, dim3(dp.B), dim3(64), g.lds_bwd, (hipStream_t)stream, dp, x, T, C, band, out20, f, grad, g.maxN,
                            g.maxCN);
@@ -43,7 +43,7 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
 
 static DvBuffers to_buffers(const DvLaunch &dv) {
     DvBuffers b;
-    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.gt = dv.gt; b.m = dv.m; b.B = dv.B;
+    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.gt = dv.gt; b.dflags = dv.dflags; b.m = dv.m; b.B = dv.B;
     return b;
 }
 int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream) {

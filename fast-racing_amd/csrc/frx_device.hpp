@@ -50,14 +50,14 @@ int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, d
 int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, const double *C, double *out20, void *stream);
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
                     const double *band, const double *out20, double *f, double *grad, void *stream,
-                    const double *tap_d = nullptr, const void *tap_cmd = nullptr, void *tap_res = nullptr,
+                    const double *tap_d = nullptr, const int *tap_flags = nullptr, void *tap_res = nullptr,
                     unsigned *tap_arrive = nullptr, volatile unsigned *tap_flag = nullptr, unsigned tap_round = 0);
 
 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;
 struct DvLaunch {
-    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; size_t ld; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
+    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; int *dflags = nullptr; size_t ld; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
 };
 // E doubles per thread x W waves: the smallest padded row 64*W*E that holds n; among equal rows the one with FEWER waves
 // (every wave runs the whole serial chain of the recursion; measured 76 vs 87 us per advance for 3x4 vs 6x2 at n = 704).

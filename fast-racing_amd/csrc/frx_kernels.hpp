@@ -26,12 +26,13 @@
 namespace frx {
 
 // Optional epilogue of k_backward_knot for the device-vector L-BFGS: with d (the search direction) given, the kernel also
-// reduces g.d, x.x and g.g of candidates whose command carries DV_EVAL and writes the round's DvResult, which saves the
-// separate k_lbfgs_post launch (~5 us + a launch gap per round).  d == nullptr: plain objective evaluation.
+// reduces g.d, x.x and g.g and, for candidates whose command carries DV_EVAL, writes the round's DvResult, which saves the
+// separate k_lbfgs_post launch.  `flags` is the device copy of the commands' flags that k_lbfgs_pre leaves behind (reading the
+// command itself would put a PCIe round trip in front of the kernel).  d == nullptr: plain objective evaluation.
 // `arrive`/`flag`/`round`: completion mailbox.  Every workgroup bumps the device counter after its result is visible system-wide;
 // the one that brings it to B * round writes `round` into a word of mapped host memory, on which the host spins instead of
 // polling the stream through the driver (the reference's cuda_computer signals completion the same way, cc.cu:384-405, 537-547).
-struct LineSearchTap { const double *d; const DvCommand *cmd; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; };
+struct LineSearchTap { const double *d; const int *flags; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; };
 
 
 
@@ -701,7 +702,8 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     double *vs = xs + maxXb;
     double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by k_forward_knot
     double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
-    const bool tapped = tap.d != nullptr && (tap.cmd[b].flags & DV_EVAL);
+    const bool tapped = tap.d != nullptr;
+    const int tap_flags = tapped ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
     double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
     FRX_STAMP(16);
     // all global reads up front (see k_forward_knot)
@@ -932,15 +934,15 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         double *red3 = rowbuf;                                        // row buffer is dead by now
         if ((k & 63) == 0) { red3[w] = w0; red3[nw + w] = w1; red3[2 * nw + w] = w2; }
         __syncthreads();
-        if (k == 0 && tapped) {
+        if (k == 0 && (tap_flags & DV_EVAL)) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
             DvResult *r = tap.res + b;
             r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2;
         }
         if (k == 0 && tap.arrive) {
-            __threadfence_system();
-            if (atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) { *tap.flag = tap.round; __threadfence_system(); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the result above is visible before the count moves
+            if (atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
         }
     }
     FRX_STAMP(24);
