@@ -21,5 +21,24 @@ int main() {
     std::vector<std::vector<frx_amd::PieceOut>> trajs;
     double jc = opt.optimize(trajs, 1e-6);
     std::printf("jerk cost %.6f, %zu pieces, duration %.4f, status %d\n", jc, trajs[0].size(), trajs[0][0].duration, opt.status()[0]);
-    return (trajs[0].size() == 1 && std::isfinite(jc) && opt.status()[0] >= 0) ? 0 : 1;
+    if (!(trajs[0].size() == 1 && std::isfinite(jc) && opt.status()[0] >= 0)) return 1;
+
+    // the reference's own call shape (MinCoPlan_CPU.cpp:114-124): H-polytopes only, a Trajectory back; two cells
+    frx_amd::SE3GCOPTER opt2;
+    std::vector<std::vector<double>> hPolys(2);
+    for (int cellI = 0; cellI < 2; cellI++)
+        for (int k = 0; k < 6; k++) {
+            for (int d = 0; d < 3; d++) hPolys[cellI].push_back(n[k][d]);
+            for (int d = 0; d < 3; d++) hPolys[cellI].push_back(p[k][d] + (d == 1 ? 6.0 * cellI : 0.0));      // second box shifted 6 m along y
+        }
+    double fin2[9] = {0, 10, 1, 0, 0, 0, 0, 0, 0}, ini2[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0};
+    if (!opt2.setup(1000.0, 0.0, ini2, fin2, hPolys, INFINITY, 8, 0.5, 0.15, 0.08, 14.0, 5.0, 12.0, 3.8, 9.81, w, true)) { std::printf("setup(H) failed: %s\n", opt2.last_error().c_str()); return 1; }
+    frx_amd::Trajectory traj;
+    const double jc2 = opt2.optimize(traj, 1e-6);
+    double p0[3], pe[3], ve[3];
+    traj.getPos(0.0, p0); traj.getPos(traj.getTotalDuration(), pe); traj.getVel(traj.getTotalDuration(), ve);
+    const frx_amd::Trajectory::Msg msg = traj.toMsg();
+    std::printf("H-only setup: jerk cost %.6f, %d pieces, total %.4f s, end (%.6f %.6f %.6f), msg %u segments\n", jc2, traj.getPieceNum(), traj.getTotalDuration(), pe[0], pe[1], pe[2], msg.num_segment);
+    const bool ends = std::fabs(p0[1]) < 1e-9 && std::fabs(pe[1] - 10.0) < 1e-9 && std::fabs(pe[2] - 1.0) < 1e-9 && std::fabs(ve[1]) < 1e-9;
+    return (traj.getPieceNum() == 2 && ends && msg.coef_x.size() == 12 && std::isfinite(jc2)) ? 0 : 1;
 }
