@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
-    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate",
+    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates",
 ]
 
 _lib = None
@@ -91,6 +91,7 @@ def lib():
         L.frx_line_segment_dilate.argtypes = [_dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
         L.frx_corridor_generate.argtypes = [C.c_int, _dp, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, BLOCKED_FN, C.c_void_p, C.c_int, C.c_int,
                                             C.POINTER(C.c_int), _ip, _dp]
+        L.frx_traj_max_rates.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -189,6 +190,13 @@ def dv_selftest(n, B=4, m=128, iters=140, geom=None, seed=0, device=0):
     gp = (C.c_int * 4)(*geom) if geom else None
     _check(lib().frx_dv_selftest(device, n, B, m, iters, gp, seed, C.byref(err), C.byref(us)))
     return err.value, us.value
+
+
+def traj_max_rates(T, Cf):
+    """(max |v|, max |a|) per piece (frx_traj_max_rates)."""
+    n = len(T); mv = np.zeros(n); ma = np.zeros(n)
+    _check(lib().frx_traj_max_rates(n, np.ascontiguousarray(T, dtype=np.float64), np.ascontiguousarray(Cf, dtype=np.float64).reshape(-1), mv, ma))
+    return mv, ma
 
 
 def traj_to_msg(T, Cf):

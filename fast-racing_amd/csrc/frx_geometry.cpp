@@ -250,6 +250,92 @@ int frx_corridor_generate(int n_path, const double *path, int n_obs, const doubl
 
 } // extern "C"
 
+// ---------------------------------------------------------------------------------------------------------------------
+// f3: post-checks — largest speed and largest acceleration magnitude of every piece (Piece::getMaxVelRate / getMaxAccRate,
+// trajectory.hpp:177-273).  The reference normalises time to [0, 1], forms d/dtau |v|^2 (degree 7; degree 5 for |a|^2) and
+// isolates its roots with Sturm sequences (root_finder.hpp); here the roots are bracketed by the roots of the derivative,
+// recursively from degree 1 upwards, and refined by bisection — every sign change of the polynomial on [0, 1] is found, which is
+// all a maximum needs (a root of even multiplicity is an inflection of |v|^2, not an extremum).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+inline double horner(const double *c, int deg, double x) {          // c[0] x^deg + ... + c[deg]
+    double v = c[0];
+    for (int i = 1; i <= deg; i++) v = v * x + c[i];
+    return v;
+}
+// all sign-change roots of c (highest power first, degree deg) in [0, 1], ascending
+void roots_unit(const double *c, int deg, std::vector<double> &out) {
+    out.clear();
+    while (deg > 0 && c[0] == 0.0) { c++; deg--; }
+    if (deg <= 0) return;
+    if (deg == 1) { const double r = -c[1] / c[0]; if (r >= 0.0 && r <= 1.0) out.push_back(r); return; }
+    double dc[8];
+    for (int i = 0; i < deg; i++) dc[i] = c[i] * (deg - i);
+    std::vector<double> crit;
+    roots_unit(dc, deg - 1, crit);
+    std::vector<double> pts{0.0};
+    pts.insert(pts.end(), crit.begin(), crit.end());
+    pts.push_back(1.0);
+    for (size_t i = 0; i + 1 < pts.size(); i++) {
+        double a = pts[i], b = pts[i + 1], fa = horner(c, deg, a), fb = horner(c, deg, b);
+        if (fa == 0.0) { if (out.empty() || out.back() != a) out.push_back(a); continue; }
+        if (fb == 0.0) { out.push_back(b); continue; }
+        if ((fa < 0.0) == (fb < 0.0)) continue;
+        for (int it = 0; it < 200 && b - a > 0.0; it++) {            // monotone on (a, b): plain bisection down to adjacent doubles
+            const double m = 0.5 * (a + b);
+            if (m <= a || m >= b) break;
+            const double fm = horner(c, deg, m);
+            if (fm == 0.0) { a = b = m; break; }
+            if ((fm < 0.0) == (fa < 0.0)) { a = m; fa = fm; } else { b = m; }
+        }
+        out.push_back(0.5 * (a + b));
+    }
+}
+// max over tau in [0,1] of | sum_k w[k][.] tau^k |^2 for a vector polynomial of degree `deg` (w[k][d], lowest power first)
+double max_sq_norm(const double (*w)[3], int deg) {
+    double sq[16] = {0};                                             // |w|^2, lowest power first, degree 2 deg
+    for (int i = 0; i <= deg; i++) for (int j = 0; j <= deg; j++) sq[i + j] += w[i][0] * w[j][0] + w[i][1] * w[j][1] + w[i][2] * w[j][2];
+    const int d2 = 2 * deg;
+    double der[16];                                                  // derivative, highest power first
+    for (int k = d2; k >= 1; k--) der[d2 - k] = k * sq[k];
+    double dn = 0.0;
+    for (int i = 0; i < d2; i++) dn += der[i] * der[i];
+    if (dn < 2.220446049250313e-16) return 0.0;                      // the reference reports 0 for a (numerically) constant magnitude,
+    std::vector<double> cand;                                        // zero or not (trajectory.hpp:192-195, 240-243): kept
+    roots_unit(der, d2 - 1, cand);
+    cand.push_back(0.0); cand.push_back(1.0);
+    double best = 0.0;
+    for (double t : cand) {
+        double v[3] = {0, 0, 0}, tn = 1.0;
+        for (int k = 0; k <= deg; k++) { v[0] += w[k][0] * tn; v[1] += w[k][1] * tn; v[2] += w[k][2] * tn; tn *= t; }
+        best = std::max(best, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    }
+    return best;
+}
+
+} // namespace
+
+extern "C" {
+
+int frx_traj_max_rates(int n_pieces, const double *T, const double *C, double *max_vel, double *max_acc) {
+    if (n_pieces <= 0 || !T || !C || (!max_vel && !max_acc)) return FRX_ERR_INVALID_ARG;
+    for (int i = 0; i < n_pieces; i++) {
+        const double *c = C + 18 * (size_t)i, h = T[i];
+        // derivatives with respect to normalised time tau = t / h, lowest power first, scaled as normalizeVelCoeffMat /
+        // normalizeAccCoeffMat scale them (trajectory.hpp:147-175): dp/dtau = h v, d2p/dtau2 = h^2 a
+        double wv[5][3], wa[4][3], hp = h;
+        for (int k = 0; k <= 4; k++) { for (int d = 0; d < 3; d++) wv[k][d] = (k + 1) * c[3 * (k + 1) + d] * hp; hp *= h; }
+        hp = h * h;
+        for (int k = 0; k <= 3; k++) { for (int d = 0; d < 3; d++) wa[k][d] = (k + 2) * (k + 1) * c[3 * (k + 2) + d] * hp; hp *= h; }
+        if (max_vel) max_vel[i] = std::sqrt(max_sq_norm(wv, 4)) / h;
+        if (max_acc) max_acc[i] = std::sqrt(max_sq_norm(wa, 3)) / (h * h);
+    }
+    return FRX_OK;
+}
+
+} // extern "C"
+
 extern "C" {
 
 int frx_enumerate_vertices(int K, const double *h_rec, double *v_out, int cap, int *nv) {

@@ -159,6 +159,11 @@ int frx_msg_sample(int n_segment, const double *coef_x, const double *coef_y, co
 int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err,
                     double *avg_us);
 
+/* Post-checks of a result (MinCoPlan_CPU.cpp:131-132): the largest speed and the largest acceleration magnitude of every piece,
+ * Piece::getMaxVelRate / getMaxAccRate (trajectory.hpp:177-273; Trajectory::getMaxVelRate/getMaxAccRate = the max over pieces).
+ * T[n_pieces], C[n_pieces][6][3] as frx_optimize returns them; either output may be NULL. */
+int frx_traj_max_rates(int n_pieces, const double *T, const double *C, double *max_vel, double *max_acc);
+
 /* Replaces ~cuda_computer / kill_kernel (cc.cu:44-49, 566-579; GPU.hpp:907-909). */
 void frx_problem_destroy(frx_problem *p);
 

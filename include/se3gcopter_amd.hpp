@@ -8,6 +8,7 @@
 // shows the two-line Eigen adapters a maintainer adds on the reference side).  A batch of B candidates is the native
 // unit; B = 1 reproduces the reference's single-trajectory call.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -38,12 +39,20 @@ public:
     void getVel(double t, double *out) const { eval(t, 1, out); }      // :87-99
     void getAcc(double t, double *out) const { eval(t, 2, out); }      // :101-115
     void getJer(double t, double *out) const { eval(t, 3, out); }      // :117-129
+    // getMaxVelRate / getMaxAccRate (:177-273) through the library's post-check (frx_traj_max_rates)
+    double getMaxVelRate() const { double v = 0.0; rates(&v, nullptr); return v; }
+    double getMaxAccRate() const { double a = 0.0; rates(nullptr, &a); return a; }
     // normalizePosCoeffMat (:131-141): column j scaled by duration^(5-j)
     void normalizePosCoeffMat(double (&out)[3][6]) const {
         double t = 1.0;
         for (int j = 5; j >= 0; j--) { for (int d = 0; d < 3; d++) out[d][j] = po_.coeff[d][j] * t; t *= po_.duration; }
     }
 private:
+    void rates(double *v, double *a) const {
+        double c[18];                                                  // frx layout: row = power, column = axis
+        for (int k = 0; k < 6; k++) for (int d = 0; d < 3; d++) c[3 * k + d] = po_.coeff[d][5 - k];
+        if (frx_traj_max_rates(1, &po_.duration, c, v, a) != FRX_OK) throw std::runtime_error(frx_last_error());
+    }
     void eval(double t, int der, double *out) const {                  // lowest power first, as the reference accumulates
         static const double fac[4][6] = {{1, 1, 1, 1, 1, 1}, {0, 1, 2, 3, 4, 5}, {0, 0, 2, 6, 12, 20}, {0, 0, 0, 6, 24, 60}};
         out[0] = out[1] = out[2] = 0.0;
@@ -79,6 +88,8 @@ public:
     void getJer(double t, double *out) const { const int i = locatePieceIdx(t); pieces_[i].getJer(t, out); }   // :471-475
     // junction position between pieces i-1 and i, i = 0..N (getJuncPos, :477-491)
     void getJuncPos(int i, double *out) const { if (i != getPieceNum()) pieces_[i].getPos(0.0, out); else pieces_[i - 1].getPos(pieces_[i - 1].getDuration(), out); }
+    double getMaxVelRate() const { double m = 0.0; for (const Piece &p : pieces_) m = std::max(m, p.getMaxVelRate()); return m; }   // :505-518
+    double getMaxAccRate() const { double m = 0.0; for (const Piece &p : pieces_) m = std::max(m, p.getMaxAccRate()); return m; }   // :520-533
     // MavGlobalPlanner::traj2msg (se3_planner.cpp:31-58): the array fields of quadrotor_msgs/PolynomialTrajectory
     struct Msg { std::vector<double> coef_x, coef_y, coef_z, time; std::vector<unsigned> order; unsigned num_order = 5, num_segment = 0; double mag_coeff = 1.0; };
     Msg toMsg() const {

@@ -368,3 +368,31 @@ def corridor_oracle(path, obs, bbox, map_height, max_seg=4.0, blocked=None, dila
         wp = (1 * i + 4 * j) // 5                                        # :81-82 (integer arithmetic)
         i = wp if wp > i else i + 1                                      # the reference does not advance when wp == i
     return polys
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# result type: the reference's Piece / Trajectory / RootFinder compiled as they are
+# ---------------------------------------------------------------------------------------------------------------------
+_ref_traj = None
+
+
+def ref_traj():
+    """oracle/_ref/libref_traj.so = trajectory.hpp + root_finder.hpp of the reference against oracle/eigen_shim; None if absent."""
+    global _ref_traj
+    if _ref_traj is None:
+        path = os.path.join(HERE, "_ref", "libref_traj.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_piece_max_rates.argtypes = [C.c_double, _dp, _dp]
+        R.ref_traj_eval.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]
+        R.ref_traj_max_rates.argtypes = [C.c_int, _dp, _dp, _dp]
+        R.ref_piece_normalized.argtypes = [C.c_double, _dp, _dp]
+        _ref_traj = R
+    return _ref_traj
+
+
+def piece_layout(Cf):
+    """(6N x 3) coefficient rows (power k of piece i in row 6i+k) -> the reference Piece layout [piece][axis][column], column j = power 5-j."""
+    pc = np.asarray(Cf, dtype=np.float64).reshape(-1, 6, 3)
+    return np.ascontiguousarray(pc[:, ::-1, :].transpose(0, 2, 1))

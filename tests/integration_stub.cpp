@@ -38,7 +38,8 @@ int main() {
     double p0[3], pe[3], ve[3];
     traj.getPos(0.0, p0); traj.getPos(traj.getTotalDuration(), pe); traj.getVel(traj.getTotalDuration(), ve);
     const frx_amd::Trajectory::Msg msg = traj.toMsg();
-    std::printf("H-only setup: jerk cost %.6f, %d pieces, total %.4f s, end (%.6f %.6f %.6f), msg %u segments\n", jc2, traj.getPieceNum(), traj.getTotalDuration(), pe[0], pe[1], pe[2], msg.num_segment);
+    std::printf("H-only setup: jerk cost %.6f, %d pieces, total %.4f s, end (%.6f %.6f %.6f), msg %u segments, max vel %.3f acc %.3f\n", jc2, traj.getPieceNum(),
+                traj.getTotalDuration(), pe[0], pe[1], pe[2], msg.num_segment, traj.getMaxVelRate(), traj.getMaxAccRate());   // MinCoPlan_CPU.cpp:131-132
     const bool ends = std::fabs(p0[1]) < 1e-9 && std::fabs(pe[1] - 10.0) < 1e-9 && std::fabs(pe[2] - 1.0) < 1e-9 && std::fabs(ve[1]) < 1e-9;
     return (traj.getPieceNum() == 2 && ends && msg.coef_x.size() == 12 && std::isfinite(jc2)) ? 0 : 1;
 }

@@ -187,3 +187,73 @@ def test_path_to_plan_through_the_library(frx, sc):
         p, _, _, _ = frx.msg_sample(msg, float(t))
         assert any(np.all(np.einsum("dk,dk->k", H[:3], p[:, None] - H[3:]) <= 0.3) for H in polys)
     prob.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f3 against the reference's own Piece / Trajectory / RootFinder
+# ---------------------------------------------------------------------------------------------------------------------
+def _optimised(sc, ob, sid=2, N=10, gates=2):
+    cand = sc.make_candidate(sid, N, gates)
+    r = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=8).optimize(1e-6, max_iterations=80)
+    return r["T"], r["C"]
+
+
+def test_max_rates_match_reference_root_finder(frx, sc, ob):
+    """frx_traj_max_rates vs Piece::getMaxVelRate / getMaxAccRate of the reference (Sturm-sequence root isolation)"""
+    if ob.ref_traj() is None:
+        pytest.skip("oracle/_ref/libref_traj.so not built (reference tree absent)")
+    rng = np.random.default_rng(3)
+    for sid in (2, 6):
+        T, Cf = _optimised(sc, ob, sid, 12, 3)
+        mv, ma = frx.traj_max_rates(T, Cf)
+        pl = ob.piece_layout(Cf)
+        for i in range(len(T)):
+            out = np.zeros(2)
+            ob.ref_traj().ref_piece_max_rates(float(T[i]), np.ascontiguousarray(pl[i].reshape(-1)), out)
+            assert abs(mv[i] - out[0]) <= 1e-9 * max(out[0], 1.0) and abs(ma[i] - out[1]) <= 1e-9 * max(out[1], 1.0), (i, mv[i], ma[i], out)
+        out3 = np.zeros(3)
+        ob.ref_traj().ref_traj_max_rates(len(T), np.ascontiguousarray(T), np.ascontiguousarray(pl.reshape(-1)), out3)
+        assert abs(mv.max() - out3[0]) <= 1e-9 * out3[0] and abs(ma.max() - out3[1]) <= 1e-9 * out3[1] and abs(T.sum() - out3[2]) < 1e-12
+    # random quintics, incl. constant-velocity and zero pieces
+    for trial in range(200):
+        c = rng.normal(0, 1, (6, 3)) * rng.choice([0.0, 1.0], (6, 1), p=[0.2, 0.8])
+        T1 = np.array([rng.uniform(0.05, 3.0)])
+        mv, ma = frx.traj_max_rates(T1, c)
+        out = np.zeros(2)
+        ob.ref_traj().ref_piece_max_rates(float(T1[0]), np.ascontiguousarray(ob.piece_layout(c)[0].reshape(-1)), out)
+        assert abs(mv[0] - out[0]) <= 1e-9 * max(out[0], 1.0) and abs(ma[0] - out[1]) <= 1e-9 * max(out[1], 1.0), (trial, mv, ma, out)
+
+
+def test_max_rates_bound_dense_sampling(frx, sc, ob):
+    """reference-free property: the reported maxima dominate a dense sampling and are attained to 1e-9"""
+    T, Cf = _optimised(sc, ob, 4, 8, 2)
+    mv, ma = frx.traj_max_rates(T, Cf)
+    pc = Cf.reshape(-1, 6, 3)
+    k = np.arange(6)
+    for i in range(len(T)):
+        t = np.linspace(0, T[i], 20001)[:, None]
+        v = ((k * t ** np.maximum(k - 1, 0)) @ pc[i]); a = ((k * (k - 1) * t ** np.maximum(k - 2, 0)) @ pc[i])
+        sv, sa = np.linalg.norm(v, axis=1).max(), np.linalg.norm(a, axis=1).max()
+        assert mv[i] >= sv - 1e-12 and mv[i] <= sv * (1 + 1e-6) + 1e-12
+        assert ma[i] >= sa - 1e-12 and ma[i] <= sa * (1 + 1e-6) + 1e-12
+
+
+def test_wire_format_and_sampling_match_reference_types(frx, sc, ob):
+    """frx_traj_to_msg vs Piece::normalizePosCoeffMat, frx_msg_sample vs Trajectory::getPos/getVel/getAcc/getJer of the reference"""
+    if ob.ref_traj() is None:
+        pytest.skip("oracle/_ref/libref_traj.so not built (reference tree absent)")
+    T, Cf = _optimised(sc, ob)
+    pl = ob.piece_layout(Cf)
+    cx, cy, cz, tm, od = msg = frx.traj_to_msg(T, Cf)
+    for i in range(len(T)):
+        out = np.zeros(18)
+        ob.ref_traj().ref_piece_normalized(float(T[i]), np.ascontiguousarray(pl[i].reshape(-1)), out)
+        got = np.stack([cx[6 * i:6 * i + 6], cy[6 * i:6 * i + 6], cz[6 * i:6 * i + 6]])
+        assert np.abs(got - out.reshape(3, 6)).max() <= 1e-13 * max(np.abs(out).max(), 1.0)
+    rng = np.random.default_rng(1)
+    for t in list(rng.uniform(0, T.sum(), 50)) + [0.0, float(T[0]), float(T.sum())]:
+        want = [np.zeros(3) for _ in range(4)]
+        ob.ref_traj().ref_traj_eval(len(T), np.ascontiguousarray(T), np.ascontiguousarray(pl.reshape(-1)), float(t), *want)
+        got = frx.msg_sample(msg, t)
+        for g, w, nm in zip(got, want, "pvaj"):
+            assert np.abs(g - w).max() <= 1e-9 * max(np.abs(w).max(), 1.0), (t, nm)
