@@ -207,6 +207,18 @@ def main():
                  "frac": big.algorithmic_bytes() / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_samples_per_s": big.samples() / (us * 1e-6)}
         big.close(); del Tb, Cb, ob_
 
+    # the HBM-bound kernel of the path: the L-BFGS two-loop recursion (k_lbfgs_pre) streams every candidate's (s, y) history twice
+    # per accepted step.  Driven alone by frx_dv_selftest (HIP events around each launch) at the headline vector length.
+    hbm_kernel = None
+    if rank == 0 and args.large_batch > 0:
+        n_x = int(np.max(np.diff(prob.x_off))); m_hist = 128; bl = 256
+        row = min(64 * w * e for e in (2, 4, 8) for w in range(1, 9) if 64 * w * e >= n_x)   # padded row, frx::dv_geometry (768 at n ~ 704)
+        err, us = frx.dv_selftest(n_x, B=bl, m=m_hist, iters=160)
+        byts = bl * m_hist * 2 * 2 * row * 8                               # S and Y rows, read once in each of the two loops
+        hbm_kernel = {"kernel": "frx::k_lbfgs_pre", "candidates": bl, "history_pairs": m_hist, "vector_length": n_x, "avg_kernel_us": us,
+                      "bytes_per_launch": byts, "achieved": byts / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                      "check_rel_err_vs_host_recursion": err}
+
     plan = {}
     if not args.no_plan:
         if dist: dist.barrier()
@@ -254,7 +266,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "frx::k_penalty", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_kernel_us": pen_us, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
-                         "traffic_source": traffic_src, "large_batch": large, "valu": valu,
+                         "traffic_source": traffic_src, "large_batch": large, "valu": valu, "hbm_bound_kernel": hbm_kernel,
                          "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)},
             "cpu_baseline": cpu,
         }
