@@ -177,7 +177,7 @@ struct frx_problem {
     // line-search tap of k_backward_knot (set only while optimize_device_vectors runs)
     const double *tap_d = nullptr; const int *tap_flags = nullptr; void *tap_res = nullptr;
     unsigned *tap_arrive = nullptr; volatile unsigned *tap_flag = nullptr; unsigned tap_round = 0;
-    DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags;
+    DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags, d_pflags;
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -512,7 +512,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p; d.piece_iv = p->d_piece_iv.p;
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
     d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
-    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.stamps = nullptr;
+    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.stamps = nullptr; d.cand_active = nullptr; d.piece_active = nullptr;
     *out = p;
     return FRX_OK;
 }
@@ -819,13 +819,20 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     // with the knot/PCR kernels the reductions the line search needs ride on k_backward_knot (LineSearchTap); the banded-LU
     // kernels keep the separate k_lbfgs_post
     const bool fused_post = p->geo.solver == frx::SOLVER_KNOT_PCR;
-    struct TapGuard { frx_problem *q; ~TapGuard() { q->tap_d = nullptr; q->tap_flags = nullptr; q->tap_res = nullptr; q->tap_arrive = nullptr; q->tap_flag = nullptr; } } tap_guard{p};
+    struct TapGuard { frx_problem *q; ~TapGuard() { q->tap_d = nullptr; q->tap_flags = nullptr; q->tap_res = nullptr; q->dp.cand_active = nullptr; q->dp.piece_active = nullptr; q->tap_arrive = nullptr; q->tap_flag = nullptr; } } tap_guard{p};
     const char *mb_env = std::getenv("FRX_MAILBOX");
     const bool mailbox = fused_post && !(mb_env && mb_env[0] == '0');
     if (fused_post) {
         if (!p->d_flags.p && (e = p->d_flags.alloc(B)) != hipSuccess) return fail(FRX_ERR_ALLOC, hipGetErrorString(e));
         dv.dflags = p->d_flags.p;
         p->tap_d = p->d_dir.p; p->tap_flags = p->d_flags.p; p->tap_res = p->h_res.p;
+        // large batches: the objective kernels skip candidates that are not being evaluated this round (finished ones above all)
+        const char *sk = std::getenv("FRX_SKIP_INACTIVE");
+        if (sk ? sk[0] != '0' : B > 64) {
+            if (!p->d_pflags.p && (e = p->d_pflags.alloc(p->P)) != hipSuccess) return fail(FRX_ERR_ALLOC, hipGetErrorString(e));
+            dv.pflags = p->d_pflags.p; dv.poff = p->d_poff.p;
+            p->dp.cand_active = p->d_flags.p; p->dp.piece_active = p->d_pflags.p;
+        }
     }
     if (mailbox) {
         if (!p->d_arrive.p && ((e = p->d_arrive.alloc(1)) != hipSuccess || (e = p->h_flag.alloc(1)) != hipSuccess)) return fail(FRX_ERR_ALLOC, hipGetErrorString(e));

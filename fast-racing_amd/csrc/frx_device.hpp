@@ -28,6 +28,10 @@ struct DevProblem {
     const int *wp_vbeg, *wp_nv, *wp_xbeg;     // first vertex record, vertex count, absolute index of its xi segment in x
     const double *hblk;                       // [P][Kmax+1][4]: {origin xyz, K}, then K x (unit normal, n.(p_k - origin) - margin), zero padded
     const double *vrec;                       // waypoint vertices [..][3] in [v0, v_r - v0] form, waypoint order
+    // optional (null): command flags of this round per candidate / per fine piece, left by k_lbfgs_pre; candidates without
+    // DV_EVAL (finished, or restoring) are skipped by the objective kernels - the tail of a large batch runs at the cost of the
+    // candidates still active
+    const int *cand_active, *piece_active;
     long long *stamps;                        // optional (null): s_memtime stamps of candidate 0's phases, [2][16] (frx_profile_phases)
 };
 
@@ -57,7 +61,7 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;
 struct DvLaunch {
-    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; int *dflags = nullptr; size_t ld; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
+    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; int *dflags = nullptr, *pflags = nullptr; const int *poff = nullptr; size_t ld; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
 };
 // E doubles per thread x W waves: the smallest padded row 64*W*E that holds n; among equal rows the one with FEWER waves
 // (every wave runs the whole serial chain of the recursion; measured 76 vs 87 us per advance for 3x4 vs 6x2 at n = 704).

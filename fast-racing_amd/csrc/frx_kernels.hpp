@@ -210,6 +210,8 @@ __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *
     double *tS = cS + ppw * 18;
     double *hS = tS + ppw;
     double *red = hS + (size_t)ppw * hstride;
+    const int pl = lane / lpp, jl = lane - pl * lpp;
+    const int pfl = (dp.piece_active && pl < npieces) ? dp.piece_active[gp0 + pl] : DV_EVAL;   // issued with the sweeps below
 
     {
         const double *csrc = C + (size_t)gp0 * 18, *hsrc = dp.hblk + (size_t)gp0 * hstride;
@@ -221,8 +223,7 @@ __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *
     }
     __syncthreads();
 
-    const int pl = lane / lpp, jl = lane - pl * lpp;
-    const bool active = pl < npieces;
+    const bool active = pl < npieces && (pfl & DV_EVAL);
     double *mine = red + lane * 21;
     if (active) {
         const double *c = cS + pl * 18;
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
                                int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
+    if (dp.cand_active && !(dp.cand_active[b] & DV_EVAL)) return;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
@@ -687,6 +689,10 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
                                 LineSearchTap tap) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
+    if (dp.cand_active && !(dp.cand_active[b] & DV_EVAL)) {           // skipped candidate: only the arrival count
+        if (k == 0 && tap.arrive && atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
+        return;
+    }
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];

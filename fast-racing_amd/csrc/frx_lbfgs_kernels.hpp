@@ -36,6 +36,8 @@ struct DvBuffers {
                               // thread can issue unconditional 16-byte loads (thread t owns elements 2*(t + TPB*q) + {0,1})
     double *ys;               // [B][m]   y.s per slot
     int *dflags;              // [B] device copy of this round's command flags (for k_backward_knot's LineSearchTap)
+    int *pflags;              // [P] the same per fine piece (for k_penalty), or null
+    const int *poff;          // [B+1] fine-piece offsets (with pflags)
     double *gt;               // [B][m][4] cross products s_j . y_{j+d}, d = 1..3 (entry 3 unused), see k_lbfgs_pre
     int m, B;
 };
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvComm
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const DvCommand c = cmd[b];
     if (t == 0 && bf.dflags) bf.dflags[b] = c.flags;
+    if (bf.pflags) { const int q0 = bf.poff[b], q1 = bf.poff[b + 1]; for (int q = q0 + t; q < q1; q += TPB) bf.pflags[q] = c.flags; }
     if (!(c.flags & (DV_INIT | DV_ADVANCE | DV_TRIAL | DV_RESTORE))) return;
     const int base = bf.xoff[b], n = bf.xoff[b + 1] - base;
     double *x = bf.x + base, *g = bf.g + base, *xp = bf.xp + base, *gp = bf.gp + base, *d = bf.d + base;
