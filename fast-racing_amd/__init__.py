@@ -242,7 +242,10 @@ class Problem:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: module globals may already be gone
+            pass
 
     def set_solver(self, name: str):
         """'knot_pcr' (default) or 'banded_lu' (reference elimination order, cross-check)."""
