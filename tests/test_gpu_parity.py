@@ -129,7 +129,7 @@ def test_optimize_short_run_tracks_oracle(frx, sc, ob):
     prob.close()
 
 
-@pytest.mark.parametrize("N,gates,kappa,obst", [(32, 8, 8, False), (24, 6, 16, True)])
+@pytest.mark.parametrize("N,gates,kappa,obst", [(32, 8, 8, False), (24, 6, 16, True), (64, 16, 16, False)])   # last: one headline candidate
 def test_lockstep_parity_along_the_whole_optimisation(frx, sc, ob, N, gates, kappa, obst):
     """End-to-end contract (north_star: optimised MINCO coefficients within 1e-6 relative of the CPU path on
     identical inputs), in its well-posed form.
