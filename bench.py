@@ -212,7 +212,7 @@ def main():
     hbm_kernel = None
     if rank == 0 and args.large_batch > 0:
         n_x = int(np.max(np.diff(prob.x_off))); m_hist = 128; bl = 256
-        row = min(64 * w * e for e in (2, 4, 8) for w in range(1, 9) if 64 * w * e >= n_x)   # padded row, frx::dv_geometry (768 at n ~ 704)
+        row = min(64 * w * e for e in (2, 4, 6, 8) for w in range(1, 9) if 64 * w * e >= n_x)   # padded row, frx::dv_geometry (768 at n ~ 704)
         err, us = frx.dv_selftest(n_x, B=bl, m=m_hist, iters=160)
         byts = bl * m_hist * 2 * 2 * row * 8                               # S and Y rows, read once in each of the two loops
         hbm_kernel = {"kernel": "frx::k_lbfgs_pre", "candidates": bl, "history_pairs": m_hist, "vector_length": n_x, "avg_kernel_us": us,

@@ -54,6 +54,7 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
     switch (((dv.E * 16 + dv.W) * 64 + dv.PF) * 8 + dv.BLK) {
     FRX_PRE(2, 1, 16, 4) FRX_PRE(2, 2, 16, 4) FRX_PRE(2, 3, 16, 4) FRX_PRE(2, 4, 16, 4) FRX_PRE(2, 5, 16, 4) FRX_PRE(2, 6, 16, 4) FRX_PRE(2, 7, 16, 4) FRX_PRE(2, 8, 16, 4)
     FRX_PRE(4, 1, 8, 4) FRX_PRE(4, 2, 8, 4) FRX_PRE(4, 3, 8, 4) FRX_PRE(4, 4, 8, 4) FRX_PRE(4, 5, 8, 4) FRX_PRE(4, 6, 8, 4) FRX_PRE(4, 7, 8, 4) FRX_PRE(4, 8, 8, 4)
+    FRX_PRE(6, 1, 8, 4) FRX_PRE(6, 2, 8, 4) FRX_PRE(6, 3, 8, 4) FRX_PRE(6, 4, 8, 4) FRX_PRE(6, 5, 8, 4) FRX_PRE(6, 6, 8, 4) FRX_PRE(6, 7, 8, 4) FRX_PRE(6, 8, 8, 4)
     FRX_PRE(8, 1, 4, 4) FRX_PRE(8, 2, 4, 4) FRX_PRE(8, 3, 4, 4) FRX_PRE(8, 4, 4, 4) FRX_PRE(8, 5, 4, 4) FRX_PRE(8, 6, 4, 4) FRX_PRE(8, 7, 4, 4) FRX_PRE(8, 8, 4, 4)
     FRX_PRE(4, 3, 8, 1) FRX_PRE(4, 3, 8, 2) FRX_PRE(2, 6, 16, 1)     // experiments (FRX_DV_GEOM)
     default: return (int)hipErrorInvalidValue;

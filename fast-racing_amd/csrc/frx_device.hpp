@@ -64,14 +64,15 @@ struct DvLaunch {
     const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; int *dflags = nullptr, *pflags = nullptr; const int *poff = nullptr; size_t ld; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
 };
 // E doubles per thread x W waves: the smallest padded row 64*W*E that holds n; among equal rows the one with FEWER waves
-// (every wave runs the whole serial chain of the recursion; measured 76 vs 87 us per advance for 3x4 vs 6x2 at n = 704).
+// (every wave runs the whole serial chain of the recursion and the cross-wave part of a reduction grows with the wave count;
+// measured per advance at n = 641: 2 waves x 6 doubles 59.6, 3 x 4 61.6, 6 x 2 65.7 us).
 inline void dv_geometry(int n, int *E, int *W, int *PF) {
     size_t best = ~(size_t)0;
     *E = *W = *PF = 0;
-    for (int e : {8, 4, 2})
+    for (int e : {8, 6, 4, 2})
         for (int w = 1; w <= 8; w++) {
             const size_t hs = (size_t)64 * w * e;
-            if ((size_t)n <= hs && hs < best) { best = hs; *E = e; *W = w; *PF = 32 / e; }
+            if ((size_t)n <= hs && hs < best) { best = hs; *E = e; *W = w; *PF = e == 2 ? 16 : e == 8 ? 4 : 8; }
         }
 }
 int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream);

@@ -42,7 +42,8 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void wave_sum4_packed(double (&v)[4]) {
+// `spread` = false leaves total k in lane k (k < 4) only - enough when the totals go to LDS anyway.
+template <bool spread> __device__ __forceinline__ double wave_sum4_packed(double (&v)[4]) {
     const int lane = threadIdx.x & 63;
     const bool odd = lane & 1, up = lane & 2;
     const double x = odd ? v[1] : v[0], px = odd ? v[0] : v[1];
@@ -62,7 +63,8 @@ __device__ __forceinline__ void wave_sum4_packed(double (&v)[4]) {
         const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(q)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(q));      // lane ^ 32
         q += __hiloint2double(hi, lo);
     }
-    v[0] = dpp_mov<0x00>(q); v[1] = dpp_mov<0x55>(q); v[2] = dpp_mov<0xAA>(q); v[3] = dpp_mov<0xFF>(q);
+    if (spread) { v[0] = dpp_mov<0x00>(q); v[1] = dpp_mov<0x55>(q); v[2] = dpp_mov<0xAA>(q); v[3] = dpp_mov<0xFF>(q); }
+    return q;
 }
 
 struct DvBuffers {
@@ -125,8 +127,8 @@ __global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvComm
     auto block_sum_n = [&](double *v, int nv) {                         // nv <= 5 sums at the price of one barrier, in place
         if (nv == 4) {
             double w4[4] = {v[0], v[1], v[2], v[3]};
-            wave_sum4_packed(w4);
-            if (lane == 0) { part[parity][wave][0] = w4[0]; part[parity][wave][1] = w4[1]; part[parity][wave][2] = w4[2]; part[parity][wave][3] = w4[3]; }
+            const double q = wave_sum4_packed<false>(w4);
+            if (lane < 4) part[parity][wave][lane] = q;             // lane k holds total k
         } else {
 #pragma unroll
             for (int k = 0; k < 5; k++) if (k < nv) { const double w = wave_sum_dpp(v[k]); if (lane == 0) part[parity][wave][k] = w; }
