@@ -451,7 +451,8 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     const size_t lds_cap = 160 * 1024;
     if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
         delete p;
-        return fail(FRX_ERR_CAPACITY, "more than 256 pieces in one candidate: not supported (the reference caps at 100, cuda_computer.cuh:24)");
+        return fail(FRX_ERR_CAPACITY, "a candidate's knot system does not fit one workgroup: " + std::to_string(ge.lds_kbwd / 1024) + " KB of LDS needed, 160 KB available (" +
+                                          std::to_string(ge.knot_threads) + " knot threads, limit 256; about 128 pieces per candidate fit; the reference caps at 100, cuda_computer.cuh:24)");
     }
     // the banded-LU cross-check kernels need the whole band in LDS; fall back to "unavailable" instead of failing create
     p->banded_ok = !(ge.lds_bwd > lds_cap || ge.lds_fwd > lds_cap);
