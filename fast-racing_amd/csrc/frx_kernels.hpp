@@ -433,19 +433,26 @@ __global__ __launch_bounds__(64) void k_backward(DevProblem dp, const double *__
 // LDS (doubles): rows[2][18][nrow] (SoA, conflict-free) | KP,KV,KA [3][nrow+1] x 3 arrays | Tf[nrow] | Tc[maxCN] | red | xs | vs
 // =============================================================================================
 #define FRX_STAMP(slot) do { if (dp.stamps && b == 0 && k == 0) dp.stamps[slot] = (long long)__builtin_readcyclecounter(); } while (0)
-#define ROWF(buf, f, t) rowbuf[((buf) * 18 + (f)) * nrow + (t)]
+// Row buffer: [2][9][nrow] double2 - a block row is 18 doubles = 9 pairs (Dinv: 0,1; L: 2,3; U: 4,5; r: 6,7,8), one 16-byte LDS access
+// per pair, consecutive lanes consecutive addresses.  The buffer holds D^-1, not D: a neighbour only ever needs the inverse of this
+// row's diagonal block (alpha = L D_lo^-1), so the owner inverts once instead of both neighbours inverting the same block.
+#define ROW2(buf, f, t) ((double2 *)rowbuf)[((buf) * 9 + (f)) * nrow + (t)]
 
-__device__ __forceinline__ void row_store(double *rowbuf, int nrow, int buf, int t, const KnotRow &R) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) { ROWF(buf, i, t) = R.D[i]; ROWF(buf, 4 + i, t) = R.L[i]; ROWF(buf, 8 + i, t) = R.U[i]; }
-#pragma unroll
-    for (int i = 0; i < 6; i++) ROWF(buf, 12 + i, t) = R.r[i];
+__device__ __forceinline__ void row_store(double *rowbuf, int nrow, int buf, int t, const KnotRow &R, const double *Dinv) {
+    ROW2(buf, 0, t) = make_double2(Dinv[0], Dinv[1]); ROW2(buf, 1, t) = make_double2(Dinv[2], Dinv[3]);
+    ROW2(buf, 2, t) = make_double2(R.L[0], R.L[1]); ROW2(buf, 3, t) = make_double2(R.L[2], R.L[3]);
+    ROW2(buf, 4, t) = make_double2(R.U[0], R.U[1]); ROW2(buf, 5, t) = make_double2(R.U[2], R.U[3]);
+    ROW2(buf, 6, t) = make_double2(R.r[0], R.r[1]); ROW2(buf, 7, t) = make_double2(R.r[2], R.r[3]); ROW2(buf, 8, t) = make_double2(R.r[4], R.r[5]);
 }
-__device__ __forceinline__ void row_load(const double *rowbuf, int nrow, int buf, int t, KnotRow &R) {
+// neighbour row (its D field is the INVERSE of its diagonal block); `in` false = beyond the ends: the identity row
+__device__ __forceinline__ void row_load(const double *rowbuf, int nrow, int buf, int t, bool in, KnotRow &R) {
+    double2 q[9];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { R.D[i] = ROWF(buf, i, t); R.L[i] = ROWF(buf, 4 + i, t); R.U[i] = ROWF(buf, 8 + i, t); }
-#pragma unroll
-    for (int i = 0; i < 6; i++) R.r[i] = ROWF(buf, 12 + i, t);
+    for (int f = 0; f < 9; f++) q[f] = ROW2(buf, f, t);
+    R.D[0] = in ? q[0].x : 1.0; R.D[1] = in ? q[0].y : 0.0; R.D[2] = in ? q[1].x : 0.0; R.D[3] = in ? q[1].y : 1.0;
+    R.L[0] = in ? q[2].x : 0.0; R.L[1] = in ? q[2].y : 0.0; R.L[2] = in ? q[3].x : 0.0; R.L[3] = in ? q[3].y : 0.0;
+    R.U[0] = in ? q[4].x : 0.0; R.U[1] = in ? q[4].y : 0.0; R.U[2] = in ? q[5].x : 0.0; R.U[3] = in ? q[5].y : 0.0;
+    R.r[0] = in ? q[6].x : 0.0; R.r[1] = in ? q[6].y : 0.0; R.r[2] = in ? q[7].x : 0.0; R.r[3] = in ? q[7].y : 0.0; R.r[4] = in ? q[8].x : 0.0; R.r[5] = in ? q[8].y : 0.0;
 }
 
 // Parallel cyclic reduction over knots 1..N-1 (thread k owns knot k); returns this knot's (v, a) solution.
@@ -455,7 +462,9 @@ __device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nrow, int k, in
                                              double *save, size_t sstride, size_t gk, int nsteps) {
     const bool act = k >= 1 && k <= N - 1;
     int buf = 0, step = 0;
-    if (act) row_store(rowbuf, nrow, 0, k, me);
+    double Dinv[4] = {1.0, 0.0, 0.0, 1.0};
+    double2 *sp = save ? (double2 *)(save + gk * sstride) : nullptr;         // sstride is even: 16-byte aligned
+    if (act) { m2_inv(me.D, Dinv); row_store(rowbuf, nrow, 0, k, me, Dinv); }
     __syncthreads();
     // Inside the loop the barrier only has to order LDS traffic.  __syncthreads() also waits for vmcnt(0), and on gfx9 the
     // multiplier stores below count in vmcnt: every step would wait for its stores to be acknowledged by L2.
@@ -463,27 +472,28 @@ __device__ __forceinline__ void pcr_solve_wg(double *rowbuf, int nrow, int k, in
         if (act) {
             KnotRow lo, hi, out;
             double al[4], be[4];
-            if (k - s >= 1) row_load(rowbuf, nrow, buf, k - s, lo); else knot_row_identity(lo);
-            if (k + s <= N - 1) row_load(rowbuf, nrow, buf, k + s, hi); else knot_row_identity(hi);
-            pcr_step(me, lo, hi, out, al, be);
+            const bool inlo = k - s >= 1, inhi = k + s <= N - 1;
+            row_load(rowbuf, nrow, buf, inlo ? k - s : k, inlo, lo);      // clamped address, select afterwards: no divergent paths
+            row_load(rowbuf, nrow, buf, inhi ? k + s : k, inhi, hi);
+            pcr_step_inv(me, lo, hi, out, al, be);
             me = out;
-            row_store(rowbuf, nrow, buf ^ 1, k, me);
-            if (save) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) { save[gk * sstride + step * 8 + i] = al[i]; save[gk * sstride + step * 8 + 4 + i] = be[i]; }
+            m2_inv(me.D, Dinv);
+            row_store(rowbuf, nrow, buf ^ 1, k, me, Dinv);
+            if (sp) {
+                sp[step * 4 + 0] = make_double2(al[0], al[1]); sp[step * 4 + 1] = make_double2(al[2], al[3]);
+                sp[step * 4 + 2] = make_double2(be[0], be[1]); sp[step * 4 + 3] = make_double2(be[2], be[3]);
             }
         }
         buf ^= 1;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (act) {
-        pcr_finish(me, v, a);
-        if (save) {
-            double I[4];
-            m2_inv(me.D, I);
 #pragma unroll
-            for (int i = 0; i < 4; i++) save[gk * sstride + nsteps * 8 + i] = I[i];
+        for (int x3 = 0; x3 < 3; x3++) {                            // decoupled row: w = D^-1 r (pcr_finish)
+            v[x3] = Dinv[0] * me.r[x3] + Dinv[1] * me.r[3 + x3];
+            a[x3] = Dinv[2] * me.r[x3] + Dinv[3] * me.r[3 + x3];
         }
+        if (sp) { sp[nsteps * 4] = make_double2(Dinv[0], Dinv[1]); sp[nsteps * 4 + 1] = make_double2(Dinv[2], Dinv[3]); }
     }
 }
 
@@ -954,7 +964,7 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     FRX_STAMP(24);
 #undef KN
 }
-#undef ROWF
+#undef ROW2
 
 #undef BAND
 } // namespace frx

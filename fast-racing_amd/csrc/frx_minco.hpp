@@ -86,6 +86,24 @@ FRX_HD void pcr_step(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, Kn
         out.r[3 + a] = me.r[3 + a] - (al[2] * lo.r[a] + al[3] * lo.r[3 + a]) - (be[2] * hi.r[a] + be[3] * hi.r[3 + a]);
     }
 }
+// The same with the neighbours' diagonal blocks already inverted (lo.D, hi.D hold D^-1): the device row buffer stores the inverse.
+FRX_HD void pcr_step_inv(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, KnotRow &out, double *al, double *be) {
+    double t[4];
+    m2_mul(me.L, lo.D, al);
+    m2_mul(me.U, hi.D, be);
+    m2_mul(al, lo.U, t);
+    for (int i = 0; i < 4; i++) out.D[i] = me.D[i] - t[i];
+    m2_mul(be, hi.L, t);
+    for (int i = 0; i < 4; i++) out.D[i] -= t[i];
+    m2_mul(al, lo.L, t);
+    for (int i = 0; i < 4; i++) out.L[i] = -t[i];
+    m2_mul(be, hi.U, t);
+    for (int i = 0; i < 4; i++) out.U[i] = -t[i];
+    for (int a = 0; a < 3; a++) {
+        out.r[a] = me.r[a] - (al[0] * lo.r[a] + al[1] * lo.r[3 + a]) - (be[0] * hi.r[a] + be[1] * hi.r[3 + a]);
+        out.r[3 + a] = me.r[3 + a] - (al[2] * lo.r[a] + al[3] * lo.r[3 + a]) - (be[2] * hi.r[a] + be[3] * hi.r[3 + a]);
+    }
+}
 FRX_HD void pcr_step(const KnotRow &me, const KnotRow &lo, const KnotRow &hi, KnotRow &out) {
     double al[4], be[4];
     pcr_step(me, lo, hi, out, al, be);
