@@ -443,7 +443,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         ge.maxXb = maxXb; ge.maxVb = maxVb;
         ge.pcr_steps = 0;
         for (int s = 1; s < p->maxN - 1; s <<= 1) ge.pcr_steps++;
-        ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN + maxXb + maxVb);
+        ge.lds_kfwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + nt + p->maxCN + maxXb + maxVb + (size_t)(ge.pcr_steps * 8 + 5) * nt);
         ge.pcr_steps = 0;
         for (int s = 1; s < p->maxN - 1; s <<= 1) ge.pcr_steps++;
         ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * 4 + 2 + 2 * maxXb + maxVb + (size_t)(ge.pcr_steps * 8 + 5) * nt);

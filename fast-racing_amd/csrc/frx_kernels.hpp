@@ -545,6 +545,155 @@ __device__ __forceinline__ void pcr_apply_wg(double *rbuf, int nrow, int k, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised reduction for N - 1 <= 63 knots and 4 waves.  A PCR step of pcr_solve_wg is ~180 dependent FP64 instructions
+// issued by ONE wave while the other three wait at the barrier (measured ~1800 cycles per step: latency of dependent FP64
+// operations with nothing else to issue on that SIMD).  Here wave 0 reduces the MATRIX only (lane = knot) and publishes the step's
+// multipliers in LDS; waves 1-3 each carry ONE AXIS of the right-hand side (lane = knot) and apply step s while wave 0 already
+// works on step s+1.  The adjoint solve of k_backward_knot is the right-hand-side half alone.  Entry by entry the arithmetic is
+// that of pcr_step_inv / pcr_rhs_step.
+//   matrix rows : MR2(buf, f, k), f < 6  = (Dinv, L, U) as double2 pairs, [2][6][nrow] double2 at rowbuf
+//   rhs         : RS(buf, f, k),  f < 6  = first / second equation x axis, [2][6][nrow] doubles behind them
+//   multipliers : pw[k * pws + step * 8 + i] (alpha 0-3, beta 4-7), final D^-1 at pw[k * pws + nsteps * 8 + i]
+// ---------------------------------------------------------------------------------------------
+#define MR2(buf, f, t) ((double2 *)rowbuf)[((buf) * 6 + (f)) * nrow + (t)]
+#define RS(buf, f, t) rsb[((buf) * 6 + (f)) * nrow + (t)]
+__device__ __forceinline__ void pcr_axis_step(double *rsb, int nrow, int kk, int ax, int N, int s, int st, const double *pw, int pws, double &r0,
+                                              double &r1) {
+    const bool act = kk >= 1 && kk <= N - 1;
+    const int buf = st & 1;
+    const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+    const int kc = act ? kk : 1, klo = inlo ? kk - s : kc, khi = inhi ? kk + s : kc;
+    double ab[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
+    const double l0r = RS(buf, ax, klo), l1r = RS(buf, 3 + ax, klo), h0r = RS(buf, ax, khi), h1r = RS(buf, 3 + ax, khi);
+    const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+    const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);                // pcr_rhs_step
+    const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+    r0 = n0; r1 = n1;
+    if (act) { RS(buf ^ 1, ax, kk) = r0; RS(buf ^ 1, 3 + ax, kk) = r1; }
+}
+// all 256 threads; `with_matrix`: wave 0 reduces the matrix rows found in MR2(0, ..) (and saves the multipliers to `save`), otherwise
+// pw already holds them.  RS(0, ..) holds the right-hand side.  Solution to KV / KA.
+__device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, int N, bool with_matrix, double *pw, int pws, double *save, size_t sstride,
+                                             size_t gk0, int nsteps, double *KV, double *KA) {
+    double *rsb = rowbuf + (size_t)24 * nrow;
+    const int wave = t >> 6, kk = t & 63, ax = wave - 1;
+    const bool act = kk >= 1 && kk <= N - 1;
+    const int kc = act ? kk : 1;
+    int nst = 0;
+    for (int s = 1; s < N - 1; s <<= 1) nst++;
+    double D[4], L[4], U[4], r0 = 0.0, r1 = 0.0;
+    if (wave == 0 && with_matrix) {                                 // own row: D itself stays in registers, the buffer carries its inverse
+        const double2 l0 = MR2(0, 2, kc), l1 = MR2(0, 3, kc), u0 = MR2(0, 4, kc), u1 = MR2(0, 5, kc), d0 = MR2(0, 0, kc), d1 = MR2(0, 1, kc);
+        L[0] = l0.x; L[1] = l0.y; L[2] = l1.x; L[3] = l1.y; U[0] = u0.x; U[1] = u0.y; U[2] = u1.x; U[3] = u1.y;
+        D[0] = d0.x; D[1] = d0.y; D[2] = d1.x; D[3] = d1.y;       // the builder stored D here; replaced by its inverse below
+        double I[4];
+        m2_inv(D, I);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (act) { MR2(0, 0, kk) = make_double2(I[0], I[1]); MR2(0, 1, kk) = make_double2(I[2], I[3]); }
+    } else if (wave >= 1) {
+        r0 = RS(0, ax, kc); r1 = RS(0, 3 + ax, kc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!with_matrix) {
+        // right-hand sides alone (adjoint solve): lane = knot, so the neighbours k -+ s are lane shifts; the exchange goes through the
+        // LDS crossbar (ds_bpermute, no memory, no barrier) and the three axis waves run their six steps without meeting anyone
+        if (wave >= 1) {
+            for (int st = 0; st < nst; st++) {
+                const int s = 1 << st;
+                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                double ab[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
+                const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+                const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+                const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);    // pcr_rhs_step
+                const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+                r0 = n0; r1 = n1;
+            }
+            if (act) {
+                const double *Di = pw + kk * pws + nsteps * 8;
+                KV[ax * (nrow + 1) + kk] = Di[0] * r0 + Di[1] * r1;
+                KA[ax * (nrow + 1) + kk] = Di[2] * r0 + Di[3] * r1;
+            }
+        }
+        return;
+    }
+    const int first_rhs = 1;                                        // the right-hand side lags one step behind the matrix
+    for (int it = 0; it < nst + first_rhs; it++) {
+        if (wave == 0) {
+            if (with_matrix && it < nst) {
+                const int s = 1 << it, buf = it & 1;
+                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                const int klo = inlo ? kk - s : kc, khi = inhi ? kk + s : kc;
+                double2 q[12];
+#pragma unroll
+                for (int f = 0; f < 6; f++) { q[f] = MR2(buf, f, klo); q[6 + f] = MR2(buf, f, khi); }
+                double iLo[4], lL[4], lU[4], iHi[4], hL[4], hU[4], al[4], be[4], tt[4];
+                iLo[0] = inlo ? q[0].x : 1.0; iLo[1] = inlo ? q[0].y : 0.0; iLo[2] = inlo ? q[1].x : 0.0; iLo[3] = inlo ? q[1].y : 1.0;
+                lL[0] = inlo ? q[2].x : 0.0; lL[1] = inlo ? q[2].y : 0.0; lL[2] = inlo ? q[3].x : 0.0; lL[3] = inlo ? q[3].y : 0.0;
+                lU[0] = inlo ? q[4].x : 0.0; lU[1] = inlo ? q[4].y : 0.0; lU[2] = inlo ? q[5].x : 0.0; lU[3] = inlo ? q[5].y : 0.0;
+                iHi[0] = inhi ? q[6].x : 1.0; iHi[1] = inhi ? q[6].y : 0.0; iHi[2] = inhi ? q[7].x : 0.0; iHi[3] = inhi ? q[7].y : 1.0;
+                hL[0] = inhi ? q[8].x : 0.0; hL[1] = inhi ? q[8].y : 0.0; hL[2] = inhi ? q[9].x : 0.0; hL[3] = inhi ? q[9].y : 0.0;
+                hU[0] = inhi ? q[10].x : 0.0; hU[1] = inhi ? q[10].y : 0.0; hU[2] = inhi ? q[11].x : 0.0; hU[3] = inhi ? q[11].y : 0.0;
+                m2_mul(L, iLo, al);                                 // pcr_step_inv, matrix part
+                m2_mul(U, iHi, be);
+                m2_mul(al, lU, tt);
+#pragma unroll
+                for (int i = 0; i < 4; i++) D[i] = D[i] - tt[i];
+                m2_mul(be, hL, tt);
+#pragma unroll
+                for (int i = 0; i < 4; i++) D[i] -= tt[i];
+                m2_mul(al, lL, tt);
+#pragma unroll
+                for (int i = 0; i < 4; i++) L[i] = -tt[i];
+                m2_mul(be, hU, tt);
+#pragma unroll
+                for (int i = 0; i < 4; i++) U[i] = -tt[i];
+                double I[4];
+                m2_inv(D, I);
+                if (act) {
+                    MR2(buf ^ 1, 0, kk) = make_double2(I[0], I[1]); MR2(buf ^ 1, 1, kk) = make_double2(I[2], I[3]);
+                    MR2(buf ^ 1, 2, kk) = make_double2(L[0], L[1]); MR2(buf ^ 1, 3, kk) = make_double2(L[2], L[3]);
+                    MR2(buf ^ 1, 4, kk) = make_double2(U[0], U[1]); MR2(buf ^ 1, 5, kk) = make_double2(U[2], U[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { pw[kk * pws + it * 8 + i] = al[i]; pw[kk * pws + it * 8 + 4 + i] = be[i]; }
+                    double2 *sp = (double2 *)(save + (gk0 + kk) * sstride);
+                    sp[it * 4 + 0] = make_double2(al[0], al[1]); sp[it * 4 + 1] = make_double2(al[2], al[3]);
+                    sp[it * 4 + 2] = make_double2(be[0], be[1]); sp[it * 4 + 3] = make_double2(be[2], be[3]);
+                    if (it == nst - 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
+                        sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]);
+                    }
+                }
+            }
+        } else {
+            const int st = it - first_rhs;
+            if (st >= 0 && st < nst) pcr_axis_step(rsb, nrow, kk, ax, N, 1 << st, st, pw, pws, r0, r1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (wave == 0 && with_matrix && nst == 0 && act) {              // a single interior knot: no step, D^-1 straight away
+        double I[4];
+        m2_inv(D, I);
+        double2 *sp = (double2 *)(save + (gk0 + kk) * sstride);
+#pragma unroll
+        for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
+        sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]);
+    }
+    if (with_matrix && nst == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave >= 1 && act) {
+        const double *Di = pw + kk * pws + nsteps * 8;
+        KV[ax * (nrow + 1) + kk] = Di[0] * r0 + Di[1] * r1;
+        KA[ax * (nrow + 1) + kk] = Di[2] * r0 + Di[3] * r1;
+    }
+}
+#undef MR2
+#undef RS
+
 __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
@@ -561,6 +710,7 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
     double *Tc = Tf + nrow;
     double *xs = Tc + maxCN;                          // this candidate's variables (tau, xi), staged once
     double *vs = xs + maxXb;                          // this candidate's waypoint polytopes [v0, edges], waypoint order
+    double *pwf = vs + maxVb;                          // [nrow][nsteps*8+5] reduction multipliers (wave-specialised path)
 #define KN(arr, axis, idx) arr[(axis) * (nrow + 1) + (idx)]
     FRX_STAMP(0);
     // Every global read of the kernel is issued here, before the first barrier, so the whole kernel pays ONE memory
@@ -672,12 +822,25 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
         }
     }
     FRX_STAMP(4);
-    pcr_solve_wg(rowbuf, nrow, k, N, me, vk, ak, pcrw, (size_t)(nsteps * 8 + 4), (size_t)(p0 + k), nsteps);
-    FRX_STAMP(5);
-    if (k >= 1 && k <= N - 1) {
+    if (nrow == 64 && nthr == 256) {                               // wave-specialised reduction (pcr_waves_wg)
+        if (k >= 1 && k <= N - 1) {
+            double2 *mr = (double2 *)rowbuf;
+            mr[(0 * 6 + 0) * nrow + k] = make_double2(me.D[0], me.D[1]); mr[(0 * 6 + 1) * nrow + k] = make_double2(me.D[2], me.D[3]);
+            mr[(0 * 6 + 2) * nrow + k] = make_double2(me.L[0], me.L[1]); mr[(0 * 6 + 3) * nrow + k] = make_double2(me.L[2], me.L[3]);
+            mr[(0 * 6 + 4) * nrow + k] = make_double2(me.U[0], me.U[1]); mr[(0 * 6 + 5) * nrow + k] = make_double2(me.U[2], me.U[3]);
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) { KN(KV, ax, k) = vk[ax]; KN(KA, ax, k) = ak[ax]; }
+            for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = me.r[i];
+        }
+        __syncthreads();
+        pcr_waves_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
+    } else {
+        pcr_solve_wg(rowbuf, nrow, k, N, me, vk, ak, pcrw, (size_t)(nsteps * 8 + 4), (size_t)(p0 + k), nsteps);
+        if (k >= 1 && k <= N - 1) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) { KN(KV, ax, k) = vk[ax]; KN(KA, ax, k) = ak[ax]; }
+        }
     }
+    FRX_STAMP(5);
     __syncthreads();
     // piece coefficients (quintic Hermite), 18 contiguous doubles per piece
     if (k < N) {
@@ -820,15 +983,26 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
             }
         }
     FRX_STAMP(20);
-        pcr_apply_wg(rowbuf, nrow, k, N, rr, pw, nsteps);
+        const bool wsp = nrow == 64 && nthr == 256;                 // one wave per axis (pcr_waves_wg) writes mu to KV / KA itself
+        if (wsp) {
+            if (k >= 1 && k <= N - 1) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = rr[i];
+            }
+            __syncthreads();
+            pcr_waves_wg(rowbuf, nrow, k, N, false, pw, nsteps * 8 + 5, nullptr, 0, 0, nsteps, KV, KA);
+        } else {
+            pcr_apply_wg(rowbuf, nrow, k, N, rr, pw, nsteps);
+        }
     FRX_STAMP(21);
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) { muv[ax] = rr[ax]; mua[ax] = rr[3 + ax]; }
-    }
-    // publish mu (zero at the fixed end knots) — reuse KV/KA
+        // publish mu (zero at the fixed end knots) — reuse KV/KA
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
-        if (k <= N) { KN(KV, ax, k) = (k >= 1 && k <= N - 1) ? muv[ax] : 0.0; KN(KA, ax, k) = (k >= 1 && k <= N - 1) ? mua[ax] : 0.0; }
+        for (int ax = 0; ax < 3; ax++) {
+            if (wsp) { if (k == 0 || k == N) { KN(KV, ax, k) = 0.0; KN(KA, ax, k) = 0.0; } }
+            else if (k <= N) { KN(KV, ax, k) = (k >= 1 && k <= N - 1) ? muv[ax] : 0.0; KN(KA, ax, k) = (k >= 1 && k <= N - 1) ? mua[ax] : 0.0; }
+        }
     }
     if (k == 0 && N == nrow) {
 #pragma unroll
