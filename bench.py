@@ -218,6 +218,9 @@ def main():
         hbm_kernel = {"kernel": "frx::k_lbfgs_pre", "candidates": bl, "history_pairs": m_hist, "vector_length": n_x, "avg_kernel_us": us,
                       "bytes_per_launch": byts, "achieved": byts / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                       "check_rel_err_vs_host_recursion": err}
+        lp = os.path.join(ROOT, "profiles", "r01_pmc_lbfgs_pre.json")     # committed counter pass of the same call (scripts/gpu_pmc_lbfgs.sh)
+        if os.path.exists(lp):
+            hbm_kernel["traffic"] = json.load(open(lp))["traffic_bytes_per_launch"]; hbm_kernel["traffic_source"] = "profiles/r01_pmc_lbfgs_pre.json"
 
     plan = {}
     if not args.no_plan:
