@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
-    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates",
+    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
 ]
 
 _lib = None
@@ -92,6 +92,8 @@ def lib():
         L.frx_corridor_generate.argtypes = [C.c_int, _dp, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, BLOCKED_FN, C.c_void_p, C.c_int, C.c_int,
                                             C.POINTER(C.c_int), _ip, _dp]
         L.frx_traj_max_rates.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+        L.frx_objective_eval_async.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.frx_wait.argtypes = [C.c_void_p]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]

@@ -174,6 +174,7 @@ struct frx_problem {
     PinBuf<frx::DvCommand> h_cmd;
     PinBuf<frx::DvResult> h_res;
     int dv_mem = 0; size_t dv_hs = 0;
+    double *pending_f = nullptr, *pending_g = nullptr;      // outputs of an frx_objective_eval_async awaiting frx_wait
     // line-search tap of k_backward_knot (set only while optimize_device_vectors runs)
     const double *tap_d = nullptr; const int *tap_flags = nullptr; void *tap_res = nullptr;
     unsigned *tap_arrive = nullptr; volatile unsigned *tap_flag = nullptr; unsigned tap_round = 0;
@@ -684,6 +685,32 @@ int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     std::memcpy(f, p->h_f.p, sizeof(double) * p->B);
     std::memcpy(g, p->h_g.p, sizeof(double) * p->NX);
+    return FRX_OK;
+}
+
+// Asynchronous form of frx_objective_eval for host buffers: returns once the copies and kernels are enqueued on the handle's
+// stream; frx_wait() completes it and fills f, g (which must stay valid until then).  One evaluation in flight per handle.
+int frx_objective_eval_async(frx_problem *p, const double *x, double *f, double *g) {
+    if (!p || !x || !f || !g) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->pending_f) return fail(FRX_ERR_INVALID_ARG, "an asynchronous evaluation is already in flight on this handle (call frx_wait)");
+    HIP_TRY(hipSetDevice(p->device));
+    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+    HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
+    HIP_TRY(hipMemcpyAsync(p->h_f.p, p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_g.p, p->d_g.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream));
+    p->pending_f = f; p->pending_g = g;
+    return FRX_OK;
+}
+int frx_wait(frx_problem *p) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->pending_f) {
+        std::memcpy(p->pending_f, p->h_f.p, sizeof(double) * p->B);
+        std::memcpy(p->pending_g, p->h_g.p, sizeof(double) * p->NX);
+        p->pending_f = nullptr; p->pending_g = nullptr;
+    }
     return FRX_OK;
 }
 

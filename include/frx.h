@@ -159,6 +159,12 @@ int frx_msg_sample(int n_segment, const double *coef_x, const double *coef_y, co
 int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err,
                     double *avg_us);
 
+/* Asynchronous evaluation on host buffers (blocking and asynchronous variants): frx_objective_eval_async returns once
+ * the work is enqueued on the handle's stream, frx_wait completes it and fills f and g (valid until then; one evaluation in flight per
+ * handle).  The *_device entry points are asynchronous on the caller's stream by construction. */
+int frx_objective_eval_async(frx_problem *p, const double *x, double *f, double *g);
+int frx_wait(frx_problem *p);
+
 /* Post-checks of a result (MinCoPlan_CPU.cpp:131-132): the largest speed and the largest acceleration magnitude of every piece,
  * Piece::getMaxVelRate / getMaxAccRate (trajectory.hpp:177-273; Trajectory::getMaxVelRate/getMaxAccRate = the max over pieces).
  * T[n_pieces], C[n_pieces][6][3] as frx_optimize returns them; either output may be NULL. */

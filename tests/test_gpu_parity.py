@@ -363,3 +363,18 @@ def test_device_vector_plan_is_reproducible_and_reentrant(frx, sc):
     assert np.array_equal(rb["x"], rn["x"]) and np.array_equal(rb["evals"], rn["evals"])      # skipping changes cost, not results
     assert np.ptp(rb["iters"]) > 0                                                       # candidates did finish at different rounds
     p.close()
+
+
+@pytest.mark.gpu
+def test_async_evaluation_equals_blocking(frx, sc):
+    cands = sc.make_batch(2, 4, 16, 4)
+    p = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    x = p.initial_guess()
+    f0, g0 = p.objective(x)
+    f = np.zeros(p.B); g = np.zeros(p.NX)
+    assert frx.lib().frx_objective_eval_async(p.h, x, f, g) == 0
+    assert frx.lib().frx_objective_eval_async(p.h, x, f, g) < 0            # one in flight per handle
+    assert frx.lib().frx_wait(p.h) == 0
+    assert np.array_equal(f, f0) and np.array_equal(g, g0)
+    assert frx.lib().frx_wait(p.h) == 0                                    # idempotent
+    p.close()
