@@ -257,3 +257,18 @@ def test_wire_format_and_sampling_match_reference_types(frx, sc, ob):
         got = frx.msg_sample(msg, t)
         for g, w, nm in zip(got, want, "pvaj"):
             assert np.abs(g - w).max() <= 1e-9 * max(np.abs(w).max(), 1.0), (t, nm)
+
+
+def test_corridor_edge_cases(frx):
+    """two-point path, empty cloud, blocked-everywhere callback (every segment degenerates to consecutive points), capacity error"""
+    bbox = np.array([4.0, 4.0, 2.5])
+    cells = frx.corridor_generate(np.array([[0.0, 0.0, 1.0], [0.0, 3.0, 1.0]]), np.zeros((0, 3)), bbox, 3.0)
+    assert len(cells) == 1 and cells[0].shape == (6, 8)                       # local box (6 planes) + floor + ceiling
+    V = frx.enumerate_vertices(cells[0])
+    assert V.shape[1] == 8 and V[2].min() == pytest.approx(0.0) and V[2].max() == pytest.approx(3.0)   # clipped to z in [0, 3]
+    path = np.array([[0.0, 0.5 * i, 1.0] for i in range(30)])
+    every = frx.corridor_generate(path, np.zeros((0, 3)), bbox, 3.0, blocked=lambda a, b: True)
+    free = frx.corridor_generate(path, np.zeros((0, 3)), bbox, 3.0)
+    assert len(every) > len(free) >= 2                                       # blocked sight lines shorten the segments
+    with pytest.raises(frx.FrxError):
+        frx.corridor_generate(path, np.zeros((0, 3)), bbox, 3.0, cap_polys=1)
