@@ -378,3 +378,18 @@ def test_async_evaluation_equals_blocking(frx, sc):
     assert np.array_equal(f, f0) and np.array_equal(g, g0)
     assert frx.lib().frx_wait(p.h) == 0                                    # idempotent
     p.close()
+
+
+@pytest.mark.gpu
+def test_infeasible_scenario_fails_the_same_way(frx, sc, ob):
+    """Monte-Carlo scenario 170 has no feasible trajectory at the stock limits: the reference's L-BFGS gives up with
+    LBFGSERR_MINIMUMSTEP (-1005) at an objective ~1e10; the device path reports the same status for it and is not disturbed
+    for its healthy batch neighbour."""
+    cands = [sc.make_candidate(170, 64, 16), sc.make_candidate(3, 64, 16)]
+    p = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+    r = p.optimize(sc.ZHANGJIAJIE["opt_rel_tol"])
+    o = ob.Oracle(cands[0], sc.ZHANGJIAJIE, qd_intervals=16).optimize(sc.ZHANGJIAJIE["opt_rel_tol"])
+    print("device", r["status"], r["objective"], "oracle", o["status"], o["objective"])
+    assert o["status"] == -1005 and r["status"][0] == -1005 and r["objective"][0] > 1e8
+    assert r["status"][1] >= 0 and r["objective"][1] < 1e6
+    p.close()
