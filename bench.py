@@ -248,7 +248,7 @@ def main():
         ids = np.arange(rank * B, rank * B + B)
         gid, obj, owner, wc, wT = select_winner(
             dist, torch.device("cuda", local_rank), r["objective"], ids,
-            lambda i: r["C"][6 * prob.piece_off[i]:6 * prob.piece_off[i + 1]], lambda i: r["T"][prob.piece_off[i]:prob.piece_off[i + 1]], N)
+            lambda i: r["C"][6 * prob.piece_off[i]:6 * prob.piece_off[i + 1]], lambda i: r["T"][prob.piece_off[i]:prob.piece_off[i + 1]], N, local_status=r["status"])
         plan["plans_per_s"] = world * B / (r["ms_total"] * 1e-3)           # whole-job candidate optimisations per second
         plan.update({"winner_id": gid, "winner_rank": owner, "winner_objective": obj, "winner_total_time_s": float(wT.sum())})
 

@@ -21,6 +21,7 @@
 
 #include "../../include/frx.h"
 #include "frx_device.hpp"
+#include "frx_internal.hpp"
 #include "frx_lbfgs.hpp"
 
 namespace {
@@ -51,15 +52,14 @@ public:
         if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
             for (int c = 0; c < CPU_SETSIZE; c++)
                 if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
-        have_main_mask_ = pthread_getaffinity_np(pthread_self(), sizeof(main_mask_), &main_mask_) == 0;
-        // FRX_PIN=0 disables pinning; FRX_PIN_OFFSET / FRX_PIN_STRIDE choose which allowed CPUs are used
+        // Workers are pinned only while this is the ONLY live pool of the process (several host threads driving separate handles
+        // would otherwise pin their pools onto the same cores and spin against each other), and the CALLER's thread is never
+        // pinned: its affinity is the caller's business.  FRX_PIN=0 disables pinning altogether; FRX_PIN_OFFSET / FRX_PIN_STRIDE
+        // choose which allowed CPUs the workers take.
         const char *pe = std::getenv("FRX_PIN"), *po = std::getenv("FRX_PIN_OFFSET"), *ps = std::getenv("FRX_PIN_STRIDE");
         const int off = po ? std::atoi(po) : 0, stride = std::max(1, ps ? std::atoi(ps) : 1);
-        const bool do_pin = !(pe && pe[0] == '0') && n_ > 1 && (int)cpus.size() >= off + (n_ - 1) * stride + 1;
-        if (do_pin) {
-            pin(pthread_self(), cpus[off]);
-            pinned_main_ = true;
-        }
+        const bool alone = live_pools().fetch_add(1, std::memory_order_acq_rel) == 0;
+        const bool do_pin = alone && !(pe && pe[0] == '0') && n_ > 1 && (int)cpus.size() >= off + (n_ - 1) * stride + 1;
         for (int t = 1; t < n_; t++) {
             workers_.emplace_back([this, t] { loop(t); });
             if (do_pin) pin(workers_.back().native_handle(), cpus[off + t * stride]);
@@ -68,7 +68,7 @@ public:
     ~SpinPool() {
         stop_.store(true, std::memory_order_release);
         for (auto &w : workers_) w.join();
-        if (pinned_main_ && have_main_mask_) pthread_setaffinity_np(pthread_self(), sizeof(main_mask_), &main_mask_);
+        live_pools().fetch_sub(1, std::memory_order_acq_rel);
     }
     int size() const { return n_; }
     // fn(i) for i in [0, count): worker t takes i = t, t + n, t + 2n, ...
@@ -100,7 +100,7 @@ private:
                 for (int i = t; i < count_; i += n_) fn_(i);
                 pending_.fetch_sub(1, std::memory_order_release);
                 idle = 0;
-            } else if (++idle > 200000) { std::this_thread::yield(); idle = 0; }
+            } else if (++idle > (live_pools().load(std::memory_order_relaxed) > 1 ? 2000 : 200000)) { std::this_thread::yield(); idle = 0; }
             else cpu_relax();
         }
     }
@@ -111,8 +111,7 @@ private:
     std::atomic<int> pending_{0};
     std::atomic<unsigned> epoch_{0};
     std::atomic<bool> stop_{false};
-    cpu_set_t main_mask_;
-    bool have_main_mask_ = false, pinned_main_ = false;
+    static std::atomic<int> &live_pools() { static std::atomic<int> n{0}; return n; }
 };
 
 // ---- per-candidate host description (what setup() keeps for the initial guess) ----
@@ -127,9 +126,12 @@ template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     hipError_t alloc(size_t count) {
-        n = count;
-        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        release();
+        const hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
     }
     hipError_t upload(const std::vector<T> &h) {
         hipError_t e = alloc(h.size());
@@ -141,15 +143,18 @@ template <class T> struct PinBuf {
     T *p = nullptr;
     size_t n = 0;
     ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
     hipError_t alloc(size_t count) {
-        n = count;
+        release();
         hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
-        if (e == hipSuccess) std::memset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) { n = count; std::memset(p, 0, std::max<size_t>(count, 1) * sizeof(T)); } else p = nullptr;
         return e;
     }
 };
 
 } // namespace
+
+namespace frx { int set_error(int code, const std::string &msg) { return fail(code, msg); } }
 
 struct frx_problem {
     frx_config cfg;
@@ -468,8 +473,9 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) {                                                                         \
             std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            if (p->stream) (void)hipStreamDestroy(p->stream);                                           \
             delete p;                                                                                   \
-            return fail(FRX_ERR_NO_DEVICE, m_);                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? FRX_ERR_ALLOC : FRX_ERR_HIP, m_);                   \
         }                                                                                               \
     } while (0)
     CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -818,12 +824,22 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     const size_t HS = (size_t)64 * W * E;
     hipError_t e;
     if (p->dv_mem != m || p->dv_hs != HS) {
-        if ((e = p->d_xp.alloc(p->NX)) != hipSuccess || (e = p->d_gp.alloc(p->NX)) != hipSuccess || (e = p->d_dir.alloc(p->NX)) != hipSuccess ||
-            (e = p->d_S.alloc((size_t)m * B * HS)) != hipSuccess || (e = p->d_Y.alloc((size_t)m * B * HS)) != hipSuccess ||
-            (e = p->d_ys.alloc((size_t)B * m)) != hipSuccess || (e = p->d_gt.alloc((size_t)B * m * 4)) != hipSuccess || (e = p->h_cmd.alloc(B)) != hipSuccess || (e = p->h_res.alloc(B)) != hipSuccess)
+        p->dv_mem = 0; p->dv_hs = 0;
+        const size_t hist = (size_t)m * B * HS;
+        auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };   // keep what is large enough
+        if ((e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess ||
+            (e = need(p->d_S, hist)) != hipSuccess || (e = need(p->d_Y, hist)) != hipSuccess ||
+            (e = need(p->d_ys, (size_t)B * m)) != hipSuccess || (e = need(p->d_gt, (size_t)B * m * 4)) != hipSuccess || (e = need(p->h_cmd, B)) != hipSuccess || (e = need(p->h_res, B)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (e == hipErrorOutOfMemory) {                                       // the history does not fit: the host-vector solver needs no device history
+                p->d_S.release(); p->d_Y.release();
+                return 1;
+            }
             return fail(FRX_ERR_ALLOC, std::string("device-vector L-BFGS buffers: ") + hipGetErrorString(e));
-        // zero padding of the history slices is relied upon by the unconditional 16-byte loads of k_lbfgs_pre
-        if ((e = hipMemset(p->d_S.p, 0, sizeof(double) * (size_t)m * B * HS)) != hipSuccess || (e = hipMemset(p->d_Y.p, 0, sizeof(double) * (size_t)m * B * HS)) != hipSuccess)
+        }
+        // zero padding of the history slices is relied upon by the unconditional 16-byte loads of k_lbfgs_pre; on the handle's
+        // stream, like every consumer (the stream is non-blocking: the null stream would not order against it)
+        if ((e = hipMemsetAsync(p->d_S.p, 0, sizeof(double) * hist, p->stream)) != hipSuccess || (e = hipMemsetAsync(p->d_Y.p, 0, sizeof(double) * hist, p->stream)) != hipSuccess)
             return fail(FRX_ERR_HIP, hipGetErrorString(e));
         p->dv_mem = m; p->dv_hs = HS;
     }
@@ -836,11 +852,15 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     HIP_TRY(hipMemsetAsync(p->d_gt.p, 0, sizeof(double) * (size_t)B * m * 4, p->stream));
     std::vector<frx::SolverDV> sv(B);
     for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, p->h_cmd.p + b);
-    auto wait_stream = [&]() -> hipError_t {
-        for (;;) {
+    // every wait is bounded ("status codes, bounded waits"): FRX_ROUND_TIMEOUT_MS, default 5 s per round
+    const double round_timeout_ms = [] { const char *e = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 5000.0; }();
+    auto wait_stream = [&]() -> int {
+        const auto tw = clk::now();
+        for (unsigned spins = 1;; spins++) {
             hipError_t q = hipStreamQuery(p->stream);
-            if (q == hipSuccess) return hipSuccess;
-            if (q != hipErrorNotReady) return q;
+            if (q == hipSuccess) return FRX_OK;
+            if (q != hipErrorNotReady) return fail(FRX_ERR_HIP, std::string("device round failed: ") + hipGetErrorString(q));
+            if ((spins & 0x3FF) == 0 && ms_since(tw) > round_timeout_ms) return fail(FRX_ERR_TIMEOUT, "device round did not complete within FRX_ROUND_TIMEOUT_MS");
             __builtin_ia32_pause();
         }
     };
@@ -868,15 +888,28 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         p->h_flag.p[0] = 0;
         p->tap_arrive = p->d_arrive.p; p->tap_flag = p->h_flag.p; p->tap_round = 0;
     }
-    // completion of a round: the last workgroup of k_backward_knot posts the round number in mapped memory (LineSearchTap)
-    auto wait_round = [&](bool evaluated) -> hipError_t {
+    // completion of a round: the last workgroup of k_backward_knot posts the round number in mapped memory (LineSearchTap).
+    // The spin is bounded: a stream that drains without the post (arrival counter out of step, e.g. a launch that never
+    // happened) is reported at once, anything else after the deadline; the counters are re-initialised by the next call.
+    auto wait_round = [&](bool evaluated) -> int {
         if (!mailbox || !evaluated) return wait_stream();
+        const auto tw = clk::now();
         for (unsigned spins = 1;; spins++) {
-            if (*(volatile unsigned *)p->h_flag.p == p->tap_round) return hipSuccess;
-            if ((spins & 0xFFFF) == 0) { const hipError_t q = hipStreamQuery(p->stream); if (q != hipSuccess && q != hipErrorNotReady) return q; }
+            if (*(volatile unsigned *)p->h_flag.p == p->tap_round) return FRX_OK;
+            if ((spins & 0x3FFF) == 0) {
+                const hipError_t q = hipStreamQuery(p->stream);
+                if (q == hipSuccess) {
+                    if (*(volatile unsigned *)p->h_flag.p == p->tap_round) return FRX_OK;
+                    return fail(FRX_ERR_TIMEOUT, "round " + std::to_string(p->tap_round) + ": the stream drained but completion was never posted (arrival counter out of step)");
+                }
+                if (q != hipErrorNotReady) return fail(FRX_ERR_HIP, std::string("device round failed: ") + hipGetErrorString(q));
+                if (ms_since(tw) > round_timeout_ms) return fail(FRX_ERR_TIMEOUT, "round " + std::to_string(p->tap_round) + " did not complete within FRX_ROUND_TIMEOUT_MS");
+            }
             __builtin_ia32_pause();
         }
     };
+    // fault injection (tests): FRX_DEBUG_DROP_ROUND=k leaves k_backward_knot out of round k, so that round's completion is never posted
+    const long drop_round = [] { const char *e = std::getenv("FRX_DEBUG_DROP_ROUND"); return e ? std::atol(e) : -1L; }();
     double t_dev = 0.0, t_host = 0.0;
     long rounds = 0;
     const auto t0 = clk::now();
@@ -888,10 +921,11 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         HIP_TRY((hipError_t)frx::launch_lbfgs_pre(dv, p->h_cmd.p, p->h_res.p, p->stream));
         if (any_eval) {
             if (mailbox) p->tap_round++;
-            HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
+            if (rounds == drop_round) HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, false));
+            else HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
             if (!fused_post) HIP_TRY((hipError_t)frx::launch_lbfgs_post(dv, p->d_f.p, p->h_cmd.p, p->h_res.p, p->stream));
         }
-        HIP_TRY(wait_round(any_eval));
+        { const int wrc = wait_round(any_eval); if (wrc != FRX_OK) { const std::string keep = g_err; (void)wait_stream(); g_err = keep; return wrc; } }   // bounded drain, first error kept
         t_dev += ms_since(td);
         auto th = clk::now();
         for (int b = 0; b < B; b++) {

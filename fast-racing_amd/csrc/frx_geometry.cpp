@@ -18,14 +18,23 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <string>
 #include <vector>
 
 #include "../../include/frx.h"
+#include "frx_internal.hpp"
 
 namespace {
 
+enum { POLY_OK = 0, POLY_UNBOUNDED = 1, POLY_FLAT = 2 };
+
 // all vertices of { x : n_k . (x - p_k) <= 0 } by intersecting every triple of planes; K <= a few dozen
-int enumerate(int K, const double *h, std::vector<std::array<double, 3>> &out, double tol = 1e-9, double quant = 1e-7) {
+// `verdict` (optional): what geoutils::findInterior decides before the reference enumerates anything (geoutils.hpp:43-77: the
+// Chebyshev-centre LP must be bounded with a strictly positive radius, else enumerateVs and with it SE3GCOPTER::setup return
+// false, se3gcopter_cpu.hpp:1118-1121).  Here: POLY_UNBOUNDED when the recession cone {u : n_k . u <= 0} is not {0} (normals
+// of rank < 3, or an extreme ray n_a x n_b of the cone survives every plane), POLY_FLAT when the vertex centroid - strictly
+// interior for a full-dimensional polytope - has no positive slack on some plane (zero volume: e.g. two cells sharing a face).
+int enumerate(int K, const double *h, std::vector<std::array<double, 3>> &out, int *verdict = nullptr, double tol = 1e-9, double quant = 1e-7) {
     std::vector<std::array<double, 4>> pl(K);                 // unit normal, offset d: n.x <= d
     for (int k = 0; k < K; k++) {
         const double *r = h + 6 * k;
@@ -62,7 +71,43 @@ int enumerate(int K, const double *h, std::vector<std::array<double, 3>> &out, d
     std::sort(uniq.begin(), uniq.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     out.clear();
     for (const auto &u : uniq) out.push_back(u.second);
+    if (verdict) {
+        *verdict = POLY_OK;
+        // boundedness: every extreme ray of a pointed recession cone lies along n_a x n_b for some pair of planes; a cone with a
+        // lineality space means the normals do not span R^3, in which case no plane triple had a non-zero determinant above
+        bool spans = false, ray = false;
+        for (int a = 0; a < K && !ray; a++)
+            for (int b = a + 1; b < K && !ray; b++) {
+                const double *A = pl[a].data(), *B = pl[b].data();
+                double u[3] = {A[1] * B[2] - A[2] * B[1], A[2] * B[0] - A[0] * B[2], A[0] * B[1] - A[1] * B[0]};
+                const double un = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+                if (un <= 1e-10) continue;
+                for (double &c : u) c /= un;
+                for (int k = 0; k < K && !spans; k++) spans = std::fabs(pl[k][0] * u[0] + pl[k][1] * u[1] + pl[k][2] * u[2]) > 1e-10;
+                for (int sgn = -1; sgn <= 1 && !ray; sgn += 2) {
+                    bool free_dir = true;
+                    for (int k = 0; k < K && free_dir; k++) free_dir = sgn * (pl[k][0] * u[0] + pl[k][1] * u[1] + pl[k][2] * u[2]) <= 1e-12;
+                    ray = free_dir;
+                }
+            }
+        if (!spans || ray) *verdict = POLY_UNBOUNDED;
+        else if (out.size() < 4) *verdict = POLY_FLAT;
+        else {
+            double c[3] = {0.0, 0.0, 0.0};
+            for (const auto &v : out) { c[0] += v[0]; c[1] += v[1]; c[2] += v[2]; }
+            for (double &q : c) q /= (double)out.size();
+            double slack = std::numeric_limits<double>::max();
+            for (int k = 0; k < K; k++) slack = std::min(slack, pl[k][3] - (pl[k][0] * c[0] + pl[k][1] * c[1] + pl[k][2] * c[2]));
+            if (!(slack > tol)) *verdict = POLY_FLAT;
+        }
+    }
     return (int)out.size();
+}
+
+int polytope_error(int verdict, const char *what, int index) {
+    return frx::set_error(FRX_ERR_EMPTY_POLYTOPE, std::string(what) + " " + std::to_string(index) +
+                          (verdict == POLY_UNBOUNDED ? " is unbounded" : " has no interior (zero volume)") +
+                          ": SE3GCOPTER::setup returns false here (geoutils::findInterior, geoutils.hpp:43-77)");
 }
 
 } // namespace
@@ -199,14 +244,14 @@ extern "C" {
 
 int frx_line_segment_dilate(const double *p1, const double *p2, const double *bbox, int n_obs, const double *obs, double offset, int cap,
                             int *n_planes, double *h_rec, double *ell_C, double *ell_d) {
-    if (!p1 || !p2 || !bbox || n_obs < 0 || (n_obs && !obs) || !n_planes) return FRX_ERR_INVALID_ARG;
+    if (!p1 || !p2 || !bbox || n_obs < 0 || (n_obs && !obs) || !n_planes) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_line_segment_dilate: null or out-of-range argument");
     std::vector<V3> cloud(n_obs);
     for (int i = 0; i < n_obs; i++) cloud[i] = V3{obs[3 * i], obs[3 * i + 1], obs[3 * i + 2]};
     std::vector<Plane> pl; Ellipsoid3 E;
     dilate_segment(V3{p1[0], p1[1], p1[2]}, V3{p2[0], p2[1], p2[2]}, bbox, cloud, offset, pl, E);
     *n_planes = (int)pl.size();
     if (h_rec) {
-        if (cap < (int)pl.size()) return FRX_ERR_CAPACITY;
+        if (cap < (int)pl.size()) return frx::set_error(FRX_ERR_CAPACITY, "frx_line_segment_dilate: output capacity too small");
         for (size_t k = 0; k < pl.size(); k++) { double *r = h_rec + 6 * k; r[0] = pl[k].n.x; r[1] = pl[k].n.y; r[2] = pl[k].n.z; r[3] = pl[k].p.x; r[4] = pl[k].p.y; r[5] = pl[k].p.z; }
     }
     if (ell_C) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ell_C[3 * i + j] = E.C.m[i][j];
@@ -216,7 +261,7 @@ int frx_line_segment_dilate(const double *p1, const double *p2, const double *bb
 
 int frx_corridor_generate(int n_path, const double *path, int n_obs, const double *obs, const double *bbox, double map_height, double max_seg,
                           frx_blocked_fn blocked, void *user, int cap_polys, int cap_planes, int *n_polys, int *h_off, double *h_rec) {
-    if (n_path < 2 || !path || !bbox || n_obs < 0 || (n_obs && !obs) || !n_polys || !h_off || !h_rec || cap_polys < 1) return FRX_ERR_INVALID_ARG;
+    if (n_path < 2 || !path || !bbox || n_obs < 0 || (n_obs && !obs) || !n_polys || !h_off || !h_rec || cap_polys < 1) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_corridor_generate: null or out-of-range argument");
     std::vector<V3> cloud(n_obs);
     for (int i = 0; i < n_obs; i++) cloud[i] = V3{obs[3 * i], obs[3 * i + 1], obs[3 * i + 2]};
     auto P = [&](int i) { return V3{path[3 * i], path[3 * i + 1], path[3 * i + 2]}; };
@@ -237,7 +282,7 @@ int frx_corridor_generate(int n_path, const double *path, int n_obs, const doubl
         j--;                                                                 // the floor / ceiling planes are added, as in the reference)
         pl.push_back({V3{0.0, 0.0, 1.0}, V3{0.0, 0.0, map_height}});         // MinCoPlan_CPU.cpp:85-91
         pl.push_back({V3{0.0, 0.0, -1.0}, V3{0.0, 0.0, 0.0}});
-        if (np >= cap_polys || used + (int)pl.size() > cap_planes) return FRX_ERR_CAPACITY;
+        if (np >= cap_polys || used + (int)pl.size() > cap_planes) return frx::set_error(FRX_ERR_CAPACITY, "frx_corridor_generate: output capacity too small");
         for (const Plane &h : pl) { double *r = h_rec + 6 * (size_t)used++; r[0] = h.n.x; r[1] = h.n.y; r[2] = h.n.z; r[3] = h.p.x; r[4] = h.p.y; r[5] = h.p.z; }
         h_off[++np] = used;
         if (j >= n_path - 1) break;
@@ -319,7 +364,7 @@ double max_sq_norm(const double (*w)[3], int deg) {
 extern "C" {
 
 int frx_traj_max_rates(int n_pieces, const double *T, const double *C, double *max_vel, double *max_acc) {
-    if (n_pieces <= 0 || !T || !C || (!max_vel && !max_acc)) return FRX_ERR_INVALID_ARG;
+    if (n_pieces <= 0 || !T || !C || (!max_vel && !max_acc)) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_traj_max_rates: null or out-of-range argument");
     for (int i = 0; i < n_pieces; i++) {
         const double *c = C + 18 * (size_t)i, h = T[i];
         // derivatives with respect to normalised time tau = t / h, lowest power first, scaled as normalizeVelCoeffMat /
@@ -339,12 +384,13 @@ int frx_traj_max_rates(int n_pieces, const double *T, const double *C, double *m
 extern "C" {
 
 int frx_enumerate_vertices(int K, const double *h_rec, double *v_out, int cap, int *nv) {
-    if (K < 4 || !h_rec || !nv) return FRX_ERR_INVALID_ARG;
+    if (K < 4 || !h_rec || !nv) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_enumerate_vertices: K < 4 or null argument");
     std::vector<std::array<double, 3>> vs;
-    *nv = enumerate(K, h_rec, vs);
-    if (*nv < 4) return FRX_ERR_EMPTY_POLYTOPE;                 // no interior (setup() returns false, se3gcopter_cpu.hpp:1118-1121)
+    int verdict = POLY_OK;
+    *nv = enumerate(K, h_rec, vs, &verdict);
+    if (verdict != POLY_OK) return polytope_error(verdict, "polytope", 0);   // setup() returns false, se3gcopter_cpu.hpp:1118-1121
     if (v_out) {
-        if (cap < *nv) return FRX_ERR_CAPACITY;
+        if (cap < *nv) return frx::set_error(FRX_ERR_CAPACITY, "frx_enumerate_vertices: output capacity too small");
         for (int i = 0; i < *nv; i++) std::memcpy(v_out + 3 * i, vs[i].data(), sizeof(double) * 3);
     }
     return FRX_OK;
@@ -352,8 +398,9 @@ int frx_enumerate_vertices(int K, const double *h_rec, double *v_out, int cap, i
 
 int frx_problem_create_from_h(const frx_config *cfg, int device, int B, const int *coarse_n, const double *ini_state,
                               const double *fin_state, const int *h_off, const double *h_rec, frx_problem **out) {
-    if (!cfg || !coarse_n || !h_off || !h_rec || !out || B <= 0) return FRX_ERR_INVALID_ARG;
+    if (!cfg || !coarse_n || !h_off || !h_rec || !out || B <= 0) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_problem_create_from_h: null argument or B <= 0");
     std::vector<int> v_off{0};
+    int verdict = POLY_OK;
     std::vector<double> v_rec;
     std::vector<std::array<double, 3>> vs;
     std::vector<double> both;
@@ -361,13 +408,15 @@ int frx_problem_create_from_h(const frx_config *cfg, int device, int B, const in
     for (int b = 0; b < B; b++) {
         for (int i = 0; i < coarse_n[b]; i++) {
             const int hb = h_off[poly + i], K = h_off[poly + i + 1] - hb;
-            if (enumerate(K, h_rec + 6 * (size_t)hb, vs) < 4) return FRX_ERR_EMPTY_POLYTOPE;
+            enumerate(K, h_rec + 6 * (size_t)hb, vs, &verdict);
+            if (verdict != POLY_OK) return polytope_error(verdict, "corridor cell", poly + i);
             v_off.push_back(v_off.back() + (int)vs.size());
             for (const auto &v : vs) v_rec.insert(v_rec.end(), v.begin(), v.end());
             if (i + 1 < coarse_n[b]) {                               // overlap of consecutive cells (se3gcopter_cpu.hpp:1052-1054)
                 const int K2 = h_off[poly + i + 2] - h_off[poly + i + 1];
                 both.assign(h_rec + 6 * (size_t)hb, h_rec + 6 * (size_t)(hb + K + K2));
-                if (enumerate(K + K2, both.data(), vs) < 4) return FRX_ERR_EMPTY_POLYTOPE;
+                enumerate(K + K2, both.data(), vs, &verdict);
+                if (verdict != POLY_OK) return polytope_error(verdict, "overlap of corridor cells", poly + i);
                 v_off.push_back(v_off.back() + (int)vs.size());
                 for (const auto &v : vs) v_rec.insert(v_rec.end(), v.begin(), v.end());
             }
@@ -379,7 +428,7 @@ int frx_problem_create_from_h(const frx_config *cfg, int device, int B, const in
 
 int frx_traj_to_msg(int n_pieces, const double *T, const double *C, double *coef_x, double *coef_y, double *coef_z, double *time,
                     unsigned *order) {
-    if (n_pieces <= 0 || !T || !C || !coef_x || !coef_y || !coef_z || !time || !order) return FRX_ERR_INVALID_ARG;
+    if (n_pieces <= 0 || !T || !C || !coef_x || !coef_y || !coef_z || !time || !order) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_traj_to_msg: null or out-of-range argument");
     for (int i = 0; i < n_pieces; i++) {
         // Piece holds the 3x6 matrix highest power first (getTraj, se3gcopter_cpu.hpp:561); normalizePosCoeffMat scales column j
         // (power 5-j) by duration^(5-j) (trajectory.hpp:131-141); traj2msg pushes the columns in that order (se3_planner.cpp:44-51)
@@ -399,7 +448,7 @@ int frx_traj_to_msg(int n_pieces, const double *T, const double *C, double *coef
 
 int frx_msg_sample(int n_segment, const double *coef_x, const double *coef_y, const double *coef_z, const double *time,
                    const unsigned *order, double t, double *pos, double *vel, double *acc, double *jerk) {
-    if (n_segment <= 0 || !coef_x || !coef_y || !coef_z || !time || !order || !pos || !vel || !acc || !jerk) return FRX_ERR_INVALID_ARG;
+    if (n_segment <= 0 || !coef_x || !coef_y || !coef_z || !time || !order || !pos || !vel || !acc || !jerk) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_msg_sample: null or out-of-range argument");
     // traj_server.cpp:406-456
     t = std::max(0.0, t);
     int seg = 0, shift = 0;

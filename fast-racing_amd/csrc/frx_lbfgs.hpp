@@ -364,6 +364,9 @@ private:
         if (lsr < 0) {
             std::memcpy(x, xp.data(), sizeof(double) * n);
             std::memcpy(g, gp.data(), sizeof(double) * n);
+            // value() must belong to the point that is returned: the reference leaves fx of the last REJECTED trial in *ptr_fx
+            // (lbfgs.hpp:1287-1291, 1429) and its only caller discards it (CPU.hpp:1249); here the value ranks candidates
+            fx = fp;
             finish(lsr);
             return;
         }
@@ -531,6 +534,7 @@ private:
             return;
         }
         if (lsr < 0) {                                                 // revert to the previous point; no further evaluation
+            fx = fp;                                                   // the objective AT the restored point (see Solver)
             ret = lsr; phase = DONE;
             cmd->flags = DV_RESTORE; cmd->step = 0.0;
             return;

@@ -15,13 +15,20 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def select_winner(dist, device, local_objective: np.ndarray, local_ids: np.ndarray, local_coeffs, local_T, n_pieces_max: int):
+def select_winner(dist, device, local_objective: np.ndarray, local_ids: np.ndarray, local_coeffs, local_T, n_pieces_max: int,
+                  local_status=None):
     """All ranks learn the best candidate of the whole job.
 
     local_coeffs(i) / local_T(i) return the coefficient block (6N x 3) / durations (N) of local
     candidate i.  Returns (global_id, objective, owner_rank, coeffs, T).  Ties go to the lowest
-    global id so every rank takes the same decision."""
+    global id so every rank takes the same decision.  Candidates whose optimiser failed (`local_status` < 0: the line search
+    gave up and the point was reverted) or whose objective is not finite never win: their objective counts as +inf."""
     import torch
+    local_objective = np.array(local_objective, dtype=np.float64, copy=True)
+    bad = ~np.isfinite(local_objective)
+    if local_status is not None:
+        bad |= np.asarray(local_status) < 0
+    local_objective[bad] = np.inf
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     if len(local_objective):

@@ -36,11 +36,12 @@ extern "C" {
 typedef enum frx_status {
     FRX_OK = 0,
     FRX_ERR_INVALID_ARG = -1,
-    FRX_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime error at create */
+    FRX_ERR_NO_DEVICE = -2,        /* no usable HIP device (there is no CPU fallback) */
     FRX_ERR_HIP = -3,              /* HIP runtime error later on */
     FRX_ERR_EMPTY_POLYTOPE = -4,   /* a corridor cell or overlap has no vertices: SE3GCOPTER::setup returns false (CPU.hpp:1118-1121) */
     FRX_ERR_CAPACITY = -5,         /* piece count too large for the LDS-resident band (reference silently caps N <= 100, cc.cuh:24) */
-    FRX_ERR_ALLOC = -6
+    FRX_ERR_ALLOC = -6,            /* host or device allocation failed (at create or later) */
+    FRX_ERR_TIMEOUT = -7           /* a bounded wait on the device expired (FRX_ROUND_TIMEOUT_MS, default 5000); the handle stays usable */
 } frx_status;
 
 /* Scalar arguments of SE3GCOPTER::setup (CPU.hpp:1076-1092), named after the ROS parameters

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "frx.h"
@@ -109,7 +110,13 @@ private:
 
 class SE3GCOPTER {
 public:
+    SE3GCOPTER() = default;
     ~SE3GCOPTER() { kill_kernel(); }
+    // owns the device handle: movable, not copyable (a copy would destroy the same handle twice)
+    SE3GCOPTER(const SE3GCOPTER &) = delete;
+    SE3GCOPTER &operator=(const SE3GCOPTER &) = delete;
+    SE3GCOPTER(SE3GCOPTER &&o) noexcept { *this = std::move(o); }
+    SE3GCOPTER &operator=(SE3GCOPTER &&o) noexcept;
 
     // One candidate = (iniState 3x3 col-major, finState, cells[coarseN], overlaps[coarseN-1]).
     struct Candidate {
@@ -245,5 +252,16 @@ private:
     std::vector<double> jerk_;
     std::string err_;
 };
+
+inline SE3GCOPTER &SE3GCOPTER::operator=(SE3GCOPTER &&o) noexcept {
+    if (this != &o) {
+        kill_kernel();
+        p_ = o.p_; o.p_ = nullptr;
+        B_ = o.B_; P_ = o.P_; NX_ = o.NX_;
+        poff_ = std::move(o.poff_); status_ = std::move(o.status_); iters_ = std::move(o.iters_); evals_ = std::move(o.evals_);
+        jerk_ = std::move(o.jerk_); err_ = std::move(o.err_);
+    }
+    return *this;
+}
 
 } // namespace frx_amd

@@ -139,3 +139,29 @@ def test_device_vector_protocol_is_bit_identical_on_host_emulation(problems, ob)
             x = x0.copy(); fx = C.c_double(); it = C.c_int(); ev = C.c_int()
             rc = H.hostcheck_lbfgs_dv(o.n, x, C.byref(fx), ob.lib().orc_objective_fnptr(), o.h, pm, C.byref(it), C.byref(ev))
             assert rc == ret and fx.value == fr and np.array_equal(x, xr)
+
+
+def test_value_after_a_failed_line_search_belongs_to_the_restored_point(frx):
+    """When the line search gives up for good, x and g are reverted to the previous point (lbfgs.hpp:1287-1288); the objective
+    that is reported with them must be the one AT that point (it ranks candidates), not the last rejected trial's."""
+    ps = frx.LbfgsParams()
+    frx.lib().frx_lbfgs_default_params(C.byref(ps))
+    w = np.array([1.0, 10.0, 100.0])
+    calls = {"n": 0}
+
+    def cb(inst, n_active, ids, xp, fp, gp):
+        # a smooth bowl until the first step has been accepted, then a cliff (+1e30, finite): Armijo can never hold again, the
+        # search shrinks to min_step and gives up; the last rejected trial's value is the cliff
+        calls["n"] += 1
+        xa = np.ctypeslib.as_array(xp, shape=(3,)); ga = np.ctypeslib.as_array(gp, shape=(3,))
+        if calls["n"] <= 2:
+            fp[0] = float(np.sum(w * (xa - 1.0) ** 2)); ga[:] = 2.0 * w * (xa - 1.0)
+        else:
+            fp[0] = 1e30; ga[:] = 2.0 * w * (xa - 1.0)
+
+    x_off = np.array([0, 3], np.int32); x = np.zeros(3); f = np.zeros(1)
+    st = np.zeros(1, np.int32); it = np.zeros(1, np.int32); ev = np.zeros(1, np.int32)
+    assert frx.lib().frx_lbfgs_minimize_batch(1, x_off, x, f, st, it, ev, C.byref(ps), frx.BATCH_EVAL_FN(cb), None, 1) == 0
+    assert st[0] < 0 and calls["n"] > 2                                      # the search failed for good
+    f_at_x = float(np.sum(w * (x - 1.0) ** 2))
+    assert abs(f[0] - f_at_x) <= 1e-12 * max(f_at_x, 1.0), (f[0], f_at_x, x)

@@ -272,3 +272,49 @@ def test_corridor_edge_cases(frx):
     assert len(every) > len(free) >= 2                                       # blocked sight lines shorten the segments
     with pytest.raises(frx.FrxError):
         frx.corridor_generate(path, np.zeros((0, 3)), bbox, 3.0, cap_polys=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f1, degenerate inputs: zero-volume and unbounded polytopes (geoutils::findInterior -> SE3GCOPTER::setup == false)
+# ---------------------------------------------------------------------------------------------------------------------
+def _box(lo, hi):
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    cols = []
+    for a in range(3):
+        n = np.zeros(3); n[a] = 1.0
+        cols.append(np.concatenate([n, hi])); cols.append(np.concatenate([-n, lo]))
+    return np.array(cols).T                                                # 6 x 6: column = (outer normal; point)
+
+
+def _enumerate_rc(frx, H):
+    import ctypes as C
+    nv = C.c_int()
+    rc = frx.lib().frx_enumerate_vertices(H.shape[1], np.ascontiguousarray(H.T.reshape(-1)), None, 0, C.byref(nv))
+    return rc, nv.value, frx.lib().frx_last_error().decode()
+
+
+def test_zero_volume_and_unbounded_polytopes_are_rejected_like_the_reference(frx, sc, ob):
+    a, b = _box([0, 0, 0], [4, 4, 2]), _box([4, 0, 0], [8, 4, 2])          # two cells that only share the face x = 4
+    touching = np.concatenate([a, b], axis=1)
+    open_box = a[:, [0, 1, 2, 3, 4, 4]]                                    # the floor plane replaced by a second ceiling: unbounded downwards
+    rc, nv, msg = _enumerate_rc(frx, a)
+    assert rc == 0 and nv == 8
+    rc, nv, msg = _enumerate_rc(frx, touching)
+    assert rc == -4 and "no interior" in msg, (rc, nv, msg)                # 4 coplanar vertices used to pass the `< 4` test
+    rc, nv, msg = _enumerate_rc(frx, open_box)
+    assert rc == -4 and "unbounded" in msg, (rc, nv, msg)
+    octant = np.concatenate([a[:, [1, 3, 5]], a[:, [1, 3, 5]]], axis=1)    # x, y, z >= 0 (each plane twice): inscribed radius unbounded
+    rc, nv, msg = _enumerate_rc(frx, octant)
+    assert rc == -4 and "unbounded" in msg, (rc, nv, msg)
+    if ob.ref_gcopter() is None:
+        return
+    # the reference itself: a single-cell problem sets up for the box and refuses the two degenerate cells
+    st = np.zeros((3, 3)); st[:, 0] = (1.0, 1.0, 1.0)
+    fin = np.zeros((3, 3)); fin[:, 0] = (3.0, 3.0, 1.0)
+    box_v = frx.enumerate_vertices(a)
+    ob.Reference(sc.Candidate(st, fin, [a], [box_v]), sc.ZHANGJIAJIE, override_vs=False, qd_intervals=8)
+    # (the open box is NOT given to the reference: its Chebyshev LP is bounded there - radius 2 - so findInterior accepts it and
+    # enumerateVs then runs quickhull on the polar dual of an unbounded set, which has no defined result)
+    for bad in (touching, octant):
+        with pytest.raises(RuntimeError):
+            ob.Reference(sc.Candidate(st, fin, [bad], [box_v]), sc.ZHANGJIAJIE, override_vs=False, qd_intervals=8)
