@@ -120,12 +120,15 @@ def lib():
 
 
 class FrxError(RuntimeError):
-    pass
+    """A non-zero frx_status; `.code` is the status (include/frx.h), the text is frx_last_error()."""
+    code = 0
 
 
 def _check(rc: int):
     if rc != 0:
-        raise FrxError(f"frx error {rc}: {lib().frx_last_error().decode()}")
+        e = FrxError(f"frx error {rc}: {lib().frx_last_error().decode()}")
+        e.code = rc
+        raise e
 
 
 def gcopter_lbfgs_params(rel_cost_tol: float, max_iterations: int = 0) -> LbfgsParams:

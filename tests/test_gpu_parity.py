@@ -393,3 +393,24 @@ def test_infeasible_scenario_fails_the_same_way(frx, sc, ob):
     assert o["status"] == -1005 and r["status"][0] == -1005 and r["objective"][0] > 1e8
     assert r["status"][1] >= 0 and r["objective"][1] < 1e6
     p.close()
+
+
+@pytest.mark.gpu
+def test_lost_round_is_reported_and_the_handle_stays_usable(frx, sc):
+    """Fault injection (FRX_DEBUG_DROP_ROUND): the completion of one round is never posted.  The bounded wait returns
+    FRX_ERR_TIMEOUT with a message instead of spinning, and the next plan on the same handle is bit-identical to a fresh one."""
+    import os
+    cands = sc.make_batch(9, 3, 16, 4)
+    p = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    os.environ["FRX_DEBUG_DROP_ROUND"] = "7"
+    try:
+        with pytest.raises(frx.FrxError) as ei:
+            p.optimize(1e-5)
+    finally:
+        del os.environ["FRX_DEBUG_DROP_ROUND"]
+    assert ei.value.code == -7 and "never posted" in str(ei.value), str(ei.value)
+    r1 = p.optimize(1e-5)
+    q = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    r2 = q.optimize(1e-5)
+    assert np.array_equal(r1["x"], r2["x"]) and np.array_equal(r1["evals"], r2["evals"]) and np.all(r1["status"] >= 0)
+    p.close(); q.close()
