@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
+    "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace",
 ]
 
 _lib = None
@@ -94,6 +95,9 @@ def lib():
         L.frx_traj_max_rates.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.frx_objective_eval_async.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.frx_wait.argtypes = [C.c_void_p]
+        L.frx_problem_set_resident.argtypes = [C.c_void_p, C.c_int]
+        L.frx_optimize_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
+        L.frx_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -260,6 +264,24 @@ class Problem:
         """'device' (default: vectors on the GPU, decisions on the host) or 'host' (reference-exact host vectors)."""
         _check(lib().frx_problem_set_lbfgs_mode(self.h, {"device": 0, "host": 1}[name]))
 
+    def set_resident(self, enable: bool):
+        """Resident round kernel (default, when the batch fits the chip) or one launch per stage and round."""
+        _check(lib().frx_problem_set_resident(self.h, 1 if enable else 0))
+
+    def optimize_path(self):
+        """(resident_used, device_status) of the last optimize()."""
+        u = C.c_int(); st = C.c_uint()
+        _check(lib().frx_optimize_path(self.h, C.byref(u), C.byref(st)))
+        return int(u.value), int(st.value)
+
+    def trace(self):
+        """Rows {flags, step, f, g.d, gp.d_new, x.x, g.g} of candidate 0's evaluated commands (needs FRX_TRACE in the environment)."""
+        n = lib().frx_debug_trace(self.h, None, 0)
+        out = np.zeros((max(n, 0), 7))
+        if n > 0:
+            lib().frx_debug_trace(self.h, out.ctypes.data, n)
+        return out
+
     def initial_guess(self):
         x = np.zeros(self.NX)
         _check(lib().frx_initial_guess(self.h, x))
@@ -296,8 +318,9 @@ class Problem:
         _check(lib().frx_optimize(self.h, C.byref(pm), x, Cf, T, jc, obj, st, it, ev))
         stats = np.zeros(4)
         _check(lib().frx_optimize_stats(self.h, stats))
+        resident, dev_status = self.optimize_path()
         return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
-                    ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]))
+                    ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status)
 
     def algorithmic_bytes(self) -> int:
         """Penalty-kernel bytes per evaluation, SURVEY.md §8d: sum over pieces of 312 + 48 K_i."""

@@ -184,6 +184,15 @@ struct frx_problem {
     const double *tap_d = nullptr; const int *tap_flags = nullptr; void *tap_res = nullptr;
     unsigned *tap_arrive = nullptr; volatile unsigned *tap_flag = nullptr; unsigned tap_round = 0;
     DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags, d_pflags;
+    // resident round kernel (frx_round_kernel.hpp): cluster exchange buffers and mapped mailboxes, allocated on first use
+    DevBuf<double> d_pubsyg, d_part, d_upub, d_dpub, d_rdbg;
+    DevBuf<unsigned> d_rwords;
+    PinBuf<unsigned long long> h_rcmd, h_rres;              // [B] x 2 words, [B] x 8 words
+    int rk_B = 0, rk_G = 0, rk_NXP = 0;
+    int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident)
+    int resident_used = 0;                                  // diagnostics: 1 = the last frx_optimize ran on the resident kernel
+    unsigned resident_status = 0;                           // device-side error code of the last resident launch (RK_ERR_*)
+    std::vector<double> trace;                              // FRX_TRACE: per command of candidate 0 {flags, step, f, dg, dginit, xx, gg}
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -912,6 +921,8 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     const long drop_round = [] { const char *e = std::getenv("FRX_DEBUG_DROP_ROUND"); return e ? std::atol(e) : -1L; }();
     double t_dev = 0.0, t_host = 0.0;
     long rounds = 0;
+    const bool tracing = std::getenv("FRX_TRACE") != nullptr;
+    p->trace.clear();
     const auto t0 = clk::now();
     for (;;) {
         bool any_eval = false, any_cmd = false;
@@ -932,6 +943,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
             frx::DvCommand &c = p->h_cmd.p[b];
             const bool evaluated = (c.flags & frx::DV_EVAL) != 0;
             if (!evaluated) { c.flags = 0; continue; }                         // a RESTORE has been executed
+            if (tracing && b == 0) { const frx::DvResult &r = p->h_res.p[b]; const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
             sv[b].feed(p->h_res.p[b]);
         }
         t_host += ms_since(th);
@@ -947,6 +959,139 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         if (evals) evals[b] = sv[b].evaluations();
         if (objective) objective[b] = sv[b].value();
     }
+    return FRX_OK;
+}
+
+
+// Resident optimisation (frx_round_kernel.hpp): ONE launch per plan.  The host runs the same SolverDV state machines as
+// optimize_device_vectors, but talks to each candidate's cluster through its own mailbox and never waits for the batch: a candidate's
+// next command is posted the moment its result arrives.  Returns FRX_OK, a negative frx_status, or 1 = not applicable / the device
+// gave up (resident_status says why): the caller then runs the one-launch-per-stage path from the untouched x.
+static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals, double *objective) {
+    const int B = p->B, m = pm.mem_size, E = frx::ROUND_E;
+    p->resident_used = 0; p->resident_status = 0;
+    if (p->geo.solver != frx::SOLVER_KNOT_PCR || m < 1 || m > 128) return 1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return 1;
+    const int cus = prop.multiProcessorCount;
+    int G = std::max(2, (p->geo.maxXb + 2 * E - 1) / (2 * E));                       // history: 2 E elements of every pair per workgroup
+    {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them
+        const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
+        const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(B, 1)});
+        G = std::max(G, want);
+    }
+    if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
+    if ((long)B * G > cus) return 1;                                                  // every workgroup must be resident at once (one per CU)
+    const size_t lds = frx::round_lds_bytes(p->geo, m, E);
+    if (lds == 0 || lds > 160 * 1024) return 1;
+    const int NXP = G * 2 * E;
+    hipError_t e = hipSuccess;
+    if (p->rk_B != B || p->rk_G != G || p->rk_NXP != NXP) {
+        p->rk_B = 0;
+        auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
+        if ((e = p->d_pubsyg.alloc((size_t)B * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)B * G * 512)) != hipSuccess ||
+            (e = p->d_upub.alloc((size_t)B * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)B * NXP)) != hipSuccess ||
+            (e = p->d_rwords.alloc((size_t)4 * B + 2)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)2 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
+            (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        p->rk_B = B; p->rk_G = G; p->rk_NXP = NXP;
+    }
+    const bool want_dbg = std::getenv("FRX_RESIDENT_DBG") != nullptr;
+    if (want_dbg && (!p->d_rdbg.p || p->d_rdbg.n < (size_t)B * NXP) && p->d_rdbg.alloc((size_t)B * NXP) != hipSuccess) return 1;
+    const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
+    // state of this launch: all polled words zero, mailboxes empty
+    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)4 * B + 2), p->stream));
+    std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 2 * B);
+    std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
+    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+    HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    frx::RoundLaunch rl;
+    rl.x = p->d_x.p; rl.g = p->d_g.p; rl.xp = p->d_xp.p; rl.gp = p->d_gp.p; rl.d = p->d_dir.p; rl.f = p->d_f.p; rl.T = p->d_T.p; rl.C = p->d_C.p; rl.out20 = p->d_out20.p;
+    rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr;
+    rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
+    rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
+    rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
+
+    std::vector<frx::SolverDV> sv(B);
+    std::vector<frx::DvCommand> cmd(B);
+    std::vector<unsigned long long> seq(B, 0);
+    std::vector<char> waiting(B, 0), quit_sent(B, 0);
+    std::vector<long> ncmd(B, 0);
+    volatile unsigned long long *hc = p->h_rcmd.p, *hr = p->h_rres.p;
+    auto post = [&](int b, int flags, int slot, int bound, double step) {
+        std::memcpy((void *)(hc + 2 * b + 1), &step, sizeof(double));
+        std::atomic_thread_fence(std::memory_order_release);
+        ++seq[b];
+        hc[2 * b] = (seq[b] << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
+        ncmd[b]++;
+    };
+    const bool tracing = std::getenv("FRX_TRACE") != nullptr;
+    p->trace.clear();
+    for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, &cmd[b]);
+    const auto t0 = clk::now();
+    HIP_TRY((hipError_t)frx::launch_round(p->dp, p->geo, rl, p->stream));
+    int live = 0;
+    for (int b = 0; b < B; b++) {
+        if (cmd[b].flags != 0) { post(b, cmd[b].flags, cmd[b].slot, cmd[b].bound, cmd[b].step); waiting[b] = 1; live++; }
+        else { post(b, 128, 0, 0, 0.0); quit_sent[b] = 1; }                            // invalid parameters: nothing to run (DV_QUIT)
+    }
+    int rc = FRX_OK;
+    double t_host = 0.0;
+    auto t_last = clk::now();
+    while (live > 0) {
+        bool progress = false;
+        for (int b = 0; b < B; b++) {
+            if (!waiting[b]) continue;
+            const unsigned long long rs = hr[8 * b + 7];
+            if (rs == ~0ull) { rc = 1; live = 0; break; }                               // the device gave up on this candidate
+            if (rs != seq[b]) continue;
+            std::atomic_thread_fence(std::memory_order_acquire);
+            progress = true;
+            const auto th = clk::now();
+            frx::DvCommand &c = cmd[b];
+            if (c.flags & frx::DV_EVAL) {
+                frx::DvResult r;
+                std::memcpy(&r, (const void *)(hr + 8 * b), 5 * sizeof(double));
+                if (tracing && b == 0) { const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
+                sv[b].feed(r);
+            } else c.flags = 0;                                                         // a RESTORE has been executed
+            if (c.flags != 0) post(b, c.flags, c.slot, c.bound, c.step);
+            else { post(b, 128, 0, 0, 0.0); quit_sent[b] = 1; waiting[b] = 0; live--; }   // this candidate's cluster leaves the chip
+            t_host += ms_since(th);
+        }
+        if (progress) t_last = clk::now();
+        else if (ms_since(t_last) > timeout_ms) { rc = fail(FRX_ERR_TIMEOUT, "resident round kernel: no result within FRX_ROUND_TIMEOUT_MS"); break; }
+        else __builtin_ia32_pause();
+    }
+    for (int b = 0; b < B; b++) if (!quit_sent[b]) post(b, 128, 0, 0, 0.0);
+    {   // bounded drain: the kernel's own spins expire after the same timeout
+        const auto tw = clk::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(p->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail(FRX_ERR_HIP, std::string("resident round kernel failed: ") + hipGetErrorString(q));
+            if (ms_since(tw) > 3.0 * timeout_ms + 1000.0) return fail(FRX_ERR_TIMEOUT, "resident round kernel did not exit");
+            __builtin_ia32_pause();
+        }
+    }
+    unsigned st[2] = {0, 0};
+    HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)4 * B, sizeof(st), hipMemcpyDeviceToHost));
+    p->resident_status = st[1];
+    if (rc < 0) return rc;
+    if (rc != FRX_OK || st[1] != 0) return 1;
+    long rounds = 0;
+    for (int b = 0; b < B; b++) rounds = std::max(rounds, ncmd[b]);
+    p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
+    HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++) {
+        status[b] = sv[b].status();
+        if (iters) iters[b] = sv[b].iterations();
+        if (evals) evals[b] = sv[b].evaluations();
+        if (objective) objective[b] = sv[b].value();
+    }
+    p->resident_used = 1;
     return FRX_OK;
 }
 
@@ -986,8 +1131,18 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
     const bool want_device_vectors = !(lb_env && lb_env[0] == 'h') && p->lbfgs_mode != 1;
     int rc_dv = 1;
     if (want_device_vectors) {
-        rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective);
-        if (rc_dv < 0) return rc_dv;
+        // FRX_RESIDENT=0 keeps the one-launch-per-stage rounds; the default is the resident round kernel whenever the batch fits the
+        // chip (one workgroup per CU, B x G of them), with the per-stage path as fallback when it does not or when the device gives up
+        const char *rs_env = std::getenv("FRX_RESIDENT");
+        p->resident_used = 0;
+        if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0) {
+            rc_dv = optimize_resident(p, *params, x, status, iters, evals, objective);
+            if (rc_dv < 0) return rc_dv;
+        }
+        if (rc_dv != 0) {
+            rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective);
+            if (rc_dv < 0) return rc_dv;
+        }
     }
     if (rc_dv == 0) return finish_optimize(p, x, C, T, jerk_cost);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
@@ -1029,6 +1184,24 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
     if (rc != FRX_OK) return rc;
     std::memcpy(x, p->h_x.p, sizeof(double) * p->NX);
     return finish_optimize(p, x, C, T, jerk_cost);
+}
+
+int frx_problem_set_resident(frx_problem *p, int enable) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    p->resident_mode = enable ? 1 : 0;
+    return FRX_OK;
+}
+int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device_status) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (resident_used) *resident_used = p->resident_used;
+    if (device_status) *device_status = p->resident_status;
+    return FRX_OK;
+}
+int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    const int rows = (int)(p->trace.size() / 7);
+    if (out) std::memcpy(out, p->trace.data(), sizeof(double) * 7 * (size_t)std::min(rows, std::max(cap_rows, 0)));
+    return rows;
 }
 
 int frx_optimize_stats(const frx_problem *p, double *out4) {

@@ -1,8 +1,11 @@
 // hipcc translation unit: the gfx950 kernels and their launchers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
+#include "frx_round_kernel.hpp"
 
 namespace frx {
 
@@ -64,6 +67,35 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 }
 int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream) {
     hipLaunchKernelGGL(k_lbfgs_post, dim3(dv.B), dim3(64), 0, (hipStream_t)stream, to_buffers(dv), f, (const DvCommand *)cmd, (DvResult *)res);
+    return (int)hipGetLastError();
+}
+
+static int round_eval_doubles(const LaunchGeom &g) {
+    const size_t pen = (size_t)g.ppw * 19 + (size_t)g.ppw * (g.Kmax + 1) * 4 + 64 * 21;              // doubles per wave (LaunchGeom::lds_pen)
+    size_t e = std::max(g.lds_kfwd, g.lds_kbwd) / sizeof(double) + 2;
+    e = std::max(e, 4 * pen + 8);
+    return (int)((e + 1) & ~(size_t)1);
+}
+size_t round_lds_bytes(const LaunchGeom &g, int m, int E) {
+    if (E != ROUND_E || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
+    return sizeof(double) * (size_t)round_lds(m, 2 * E, round_eval_doubles(g)).total;
+}
+int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream) {
+    if (r.E != ROUND_E) return (int)hipErrorInvalidValue;
+    RoundArgs a;
+    a.dp = dp;
+    a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nrow = g.knot_threads; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax;
+    a.pen_lds = g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21;
+    a.x = r.x; a.g = r.g; a.xp = r.xp; a.gp = r.gp; a.d = r.d; a.f = r.f; a.T = r.T; a.C = r.C; a.out20 = r.out20; a.pcrw = g.pcrw;
+    a.pubsyg = r.pubsyg; a.part = r.part; a.upub = r.upub; a.dpub = r.dpub; a.dbg = r.dbg;
+    a.phase = r.words; a.cntA = r.words + r.B; a.uflag = r.words + 2 * r.B; a.cntL = r.words + 3 * r.B; a.census = r.words + 4 * r.B; a.status = r.words + 4 * r.B + 1;
+    a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
+    a.timeout_ticks = r.timeout_ticks;
+    a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g);
+    const size_t lds = round_lds_bytes(g, r.m, r.E);
+    hipError_t e = hipFuncSetAttribute((const void *)k_round<ROUND_E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_round<ROUND_E>), dim3(r.B * r.G), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

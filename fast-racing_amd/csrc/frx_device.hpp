@@ -76,6 +76,20 @@ inline void dv_geometry(int n, int *E, int *W, int *PF) {
         }
 }
 int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream);
+
+// ---- resident round kernel (frx_round_kernel.hpp): one launch per plan ----
+struct RoundLaunch {
+    double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20;              // leader vectors and stage buffers (the handle's own)
+    double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([B][3 NXP + 2], [B][G][512], [B][258], [B][NXP])
+    unsigned *words;                                               // [4 B + 2]: phase, cntA, uflag, cntL per candidate, then census, status
+    void *h_cmd, *h_res;                                           // mapped host mailboxes, [B] x 16 B and [B] x 64 B
+    unsigned long long timeout_ticks;
+    int B, G, m, E, NXP;
+};
+enum { ROUND_E = 48 };                                             // history doubles per thread and array of the instantiated kernel
+// LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)
+size_t round_lds_bytes(const LaunchGeom &g, int m, int E);
+int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream);
 int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream);
 
 } // namespace frx

@@ -32,9 +32,24 @@ namespace frx {
 // `arrive`/`flag`/`round`: completion mailbox.  Every workgroup bumps the device counter after its result is visible system-wide;
 // the one that brings it to B * round writes `round` into a word of mapped host memory, on which the host spins instead of
 // polling the stream through the driver (the reference's cuda_computer signals completion the same way, cc.cu:384-405, 537-547).
-struct LineSearchTap { const double *d; const int *flags; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; };
+// `lds_out` (persistent round kernel): the four values go to this LDS array {f, g.d, x.x, g.g} instead of `res`, whatever the flags.
+struct LineSearchTap { const double *d; const int *flags; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; double *lds_out = nullptr; };
 
 
+
+// Inter-workgroup data inside ONE launch (the persistent round kernel, frx_round_kernel.hpp): a CU's L1 is never refreshed by
+// another CU's stores and the per-XCD L2s are not coherent with each other (MI355X guide, "inter-workgroup visibility").  Payload
+// that crosses workgroups is therefore written with write-through (sc1) stores and read with L1-bypassing (sc1) loads - relaxed
+// agent-scope atomics lower to exactly these - and ordered by a drained flag / counter (Guideline 16, form R1).  SH = false: the
+// plain accesses of the one-launch-per-stage kernels (a kernel boundary orders everything).
+template <bool SH> __device__ __forceinline__ double ldg(const double *p) {
+    if (SH) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+template <bool SH> __device__ __forceinline__ void stg(double *p, double v) {
+    if (SH) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
     // butterfly: every lane ends with the same, order-fixed sum of the 64 lane values
@@ -199,12 +214,11 @@ __global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__r
 // cycles parked on s_waitcnt/s_barrier behind three dependent load rounds).
 // Dynamic LDS (doubles): cS[ppw*18] | tS[ppw] | hS[ppw*(Kmax+1)*4] | red[64*21]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
-                                                   double *__restrict__ out20, int lpp, int ppw, int Kmax) {
-    extern __shared__ double sm[];
-    const int lane = threadIdx.x;
-    const int gp0 = blockIdx.x * ppw;
-    const int npieces = min(ppw, dp.P - gp0);
+// The body works on the pieces [gp0, gp0 + npieces) with one WAVE and `sm` = that wave's private LDS; every wave of the workgroup
+// has to call it (it contains workgroup barriers), idle ones with npieces = 0.
+template <bool SH>
+__device__ __forceinline__ void penalty_body(const DevProblem &dp, const double *__restrict__ T, const double *__restrict__ C,
+                                             double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane) {
     const int hstride = (Kmax + 1) * 4;
     double *cS = sm;
     double *tS = cS + ppw * 18;
@@ -218,8 +232,8 @@ __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *
         const int nc = npieces * 18, nh = npieces * hstride;
 #pragma unroll 4
         for (int i = lane; i < nh; i += 64) hS[i] = hsrc[i];
-        for (int i = lane; i < nc; i += 64) cS[i] = csrc[i];
-        if (lane < npieces) tS[lane] = T[gp0 + lane];
+        for (int i = lane; i < nc; i += 64) cS[i] = ldg<SH>(csrc + i);
+        if (lane < npieces) tS[lane] = ldg<SH>(T + gp0 + lane);
     }
     __syncthreads();
 
@@ -264,8 +278,14 @@ __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *
         const int p2 = idx / 20, v = idx - p2 * 20;
         double s = 0.0;
         for (int l = 0; l < lpp; l++) s += red[(p2 * lpp + l) * 21 + v];
-        out20[(size_t)gp0 * 20 + idx] = s;
+        stg<SH>(out20 + (size_t)gp0 * 20 + idx, s);
     }
+}
+__global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                   double *__restrict__ out20, int lpp, int ppw, int Kmax) {
+    extern __shared__ double sm[];
+    const int gp0 = blockIdx.x * ppw;
+    penalty_body<false>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -694,11 +714,11 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
 #undef MR2
 #undef RS
 
-__global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
-    extern __shared__ double sm[];
-    const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
-    if (dp.cand_active && !(dp.cand_active[b] & DV_EVAL)) return;
+// SH: T and C are consumed by OTHER workgroups of the same launch (see ldg / stg above).
+template <bool SH>
+__device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
+                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm) {
+    const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
@@ -758,7 +778,7 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
     if (k < N) {
         hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
-        Tout[p0 + k] = hMine;
+        stg<SH>(Tout + p0 + k, hMine);
     }
     FRX_STAMP(2);
     // forwardP (CPU.hpp:729-747): waypoint w (= knot w+1) is handled by a QUAD of lanes, each taking every 4th vertex;
@@ -850,22 +870,25 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
             double c[6];
             hermite_coeffs(hMine, KN(KP, ax, k), KN(KV, ax, k), KN(KA, ax, k), KN(KP, ax, k + 1), KN(KV, ax, k + 1), KN(KA, ax, k + 1), c);
 #pragma unroll
-            for (int q = 0; q < 6; q++) co[q * 3 + ax] = c[q];
+            for (int q = 0; q < 6; q++) stg<SH>(co + q * 3 + ax, c[q]);
         }
     }
     FRX_STAMP(6);
 }
+__global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
+                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
+    extern __shared__ double sm[];
+    if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) return;
+    forward_knot_body<false>(dp, x, Tout, Cout, maxCN, maxXb, maxVb, nrow, pcrw, nsteps, blockIdx.x, sm);
+}
 
-__global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+// SH: out20 (and T, C) were written by workgroups of the same launch.
+template <bool SH>
+__device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
-                                LineSearchTap tap) {
-    extern __shared__ double sm[];
-    const int b = blockIdx.x, k = threadIdx.x, nthr = blockDim.x;
-    if (dp.cand_active && !(dp.cand_active[b] & DV_EVAL)) {           // skipped candidate: only the arrival count
-        if (k == 0 && tap.arrive && atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
-        return;
-    }
+                                const LineSearchTap &tap, int b, double *sm) {
+    const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
@@ -882,19 +905,19 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by k_forward_knot
     double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
     const bool tapped = tap.d != nullptr;
-    const int tap_flags = tapped ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
+    const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
     double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
     FRX_STAMP(16);
     // all global reads up front (see k_forward_knot)
     double h = 1.0, c[18], cb[18], o0 = 0.0, o1 = 0.0, r_tl[3] = {0, 0, 0};
     int r_wnv = 1, r_wvb = 0, r_wxb = 0;
     if (k < N) {
-        h = Tin[p0 + k];
+        h = ldg<SH>(Tin + p0 + k);
         const double *ci = Cin + (size_t)(p0 + k) * 18;
         const double *o = out20 + (size_t)(p0 + k) * 20;
-        o0 = o[0]; o1 = o[1];
+        o0 = ldg<SH>(o); o1 = ldg<SH>(o + 1);
 #pragma unroll
-        for (int q = 0; q < 18; q++) { c[q] = ci[q]; cb[q] = o[2 + q]; }
+        for (int q = 0; q < 18; q++) { c[q] = ldg<SH>(ci + q); cb[q] = ldg<SH>(o + 2 + q); }
     }
     if ((k >> 2) < N - 1) { const int gw = p0 - b + (k >> 2); r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }   // quad k>>2 = waypoint
     if (k < 3) { r_tl[0] = dp.tailPVA[b * 9 + k]; r_tl[1] = dp.tailPVA[b * 9 + 3 + k]; r_tl[2] = dp.tailPVA[b * 9 + 6 + k]; }
@@ -1124,11 +1147,11 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         double *red3 = rowbuf;                                        // row buffer is dead by now
         if ((k & 63) == 0) { red3[w] = w0; red3[nw + w] = w1; red3[2 * nw + w] = w2; }
         __syncthreads();
-        if (k == 0 && (tap_flags & DV_EVAL)) {
+        if (k == 0 && ((tap_flags & DV_EVAL) || tap.lds_out)) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
-            DvResult *r = tap.res + b;
-            r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2;
+            if (tap.lds_out) { tap.lds_out[0] = fval; tap.lds_out[1] = a0; tap.lds_out[2] = a1; tap.lds_out[3] = a2; }
+            else { DvResult *r = tap.res + b; r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2; }
         }
         if (k == 0 && tap.arrive) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the result above is visible before the count moves
@@ -1137,6 +1160,17 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     }
     FRX_STAMP(24);
 #undef KN
+}
+__global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+                                const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
+                                LineSearchTap tap) {
+    extern __shared__ double sm[];
+    if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) {           // skipped candidate: only the arrival count
+        if (threadIdx.x == 0 && tap.arrive && atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
+        return;
+    }
+    backward_knot_body<false>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, nrow, pcrw, nsteps, tap, blockIdx.x, sm);
 }
 #undef ROW2
 

@@ -1,0 +1,434 @@
+// The resident round kernel: a whole optimisation of B candidates as ONE launch.
+//
+// What the reference does on its device (cuda_computer.cu:51-64, 384-405, 454-466, 535-548): the penalty kernel is launched once,
+// polls a flag in mapped host memory, evaluates, posts `done`, and the host spins on it; every other stage of a round runs on the
+// CPU.  Here every stage of a round runs on the device and the kernel stays resident for the whole plan: the host keeps the
+// line-search DECISIONS (frx_lbfgs.hpp, SolverDV) and talks to each candidate through a 16-byte command / 64-byte result mailbox
+// in mapped host memory; candidates advance independently of each other (no batch-wide round barrier).
+//
+// Geometry: a CLUSTER of G workgroups (256 threads, one per CU) per candidate, grid = B x G <= number of CUs.
+//   workgroup 0      LEADER: owns x, g, xp, gp, d (global memory, touched by this CU only), talks to the host, runs the MINCO
+//                    forward map and the adjoint (forward_knot_body / backward_knot_body of frx_kernels.hpp, unchanged arithmetic)
+//   workgroup G-1    DENSE: keeps the m x m factors of the compact L-BFGS representation resident in LDS
+//   workgroups 0..G-2 evaluate the penalty integrand of their share of the pieces (penalty_body)
+//   every workgroup  keeps 1/G of the candidate's (s, y) HISTORY RESIDENT IN REGISTERS: thread (slot j, half h) holds the elements
+//                    [h E, (h+1) E) of its workgroup's chunk of s_j and y_j - 2 E doubles; the whole 46 MB history of the headline
+//                    batch lives in the register files of the chip and is never re-read from HBM (k_lbfgs_pre streams it twice
+//                    per accepted step: 55 us of a 101 us round at the headline batch).
+//
+// Direction: with the history distributed by ELEMENTS, the two-loop recursion (2 m strictly sequential dot products of length n,
+// lbfgs.hpp:1381-1411) would need 2 m cross-CU reductions.  The same product  d = -H g  is evaluated in the compact form of
+// Byrd-Nocedal-Schnabel (1994, eq. 3.1-3.5 with H0 = gamma I, gamma = y.s / y.y of the newest pair as in lbfgs.hpp:1403):
+//       w = R^-1 (S^T g),   v = (D + gamma Y^T Y) w - gamma Y^T g,   u = R^-T v,        R_ij = s_i . y_j (i not newer than j)
+//       d = -gamma g - S u + gamma Y w
+// i.e. one pass over the history for 4 m dot products (S^T g, Y^T g and the new column S^T y_new, Y^T y_new of R and Y^T Y,
+// all from registers), two triangular solves + one mat-vec on the dense workgroup, one pass for the linear combination.
+// In exact arithmetic this IS the two-loop recursion; in FP64 the iterates agree to rounding (tests: plans and per-round traces against the one-launch-per-stage
+// path, whose direction kernel is checked against the host recursion).
+//
+// Cross-workgroup data uses write-through stores + L1-bypassing loads ordered by drained flags / counters (ldg / stg in
+// frx_kernels.hpp; MI355X guide, Guideline 16 form R1).  Every spin is bounded: a wait that expires records an error code in
+// `status`, which ends every workgroup of the launch, and the host driver falls back to the one-launch-per-stage path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "frx_kernels.hpp"
+#include "frx_lbfgs_kernels.hpp"
+
+namespace frx {
+
+typedef unsigned long long rk_u64;
+#define FRX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define FRX_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
+enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3 };
+enum { RK_OK = 0, RK_ERR_CENSUS = 1, RK_ERR_HOST = 2, RK_ERR_PHASE = 3, RK_ERR_ARRIVE = 4, RK_ERR_DENSE = 5, RK_ERR_UFLAG = 6, RK_ERR_HOST_ABORT = 7 };
+enum { DV_QUIT = 128 };                        // extra command flag of the resident kernel (frx_lbfgs.hpp: DV_* are < 32)
+
+// host -> device: word = seq << 32 | bound << 20 | slot << 8 | flags (written last); step first.  device -> host: seq written last.
+struct RoundCmd { rk_u64 word; double step; };
+struct RoundRes { double f, dg, xx, gg, dginit, pad[2]; rk_u64 seq; };
+static_assert(sizeof(RoundRes) == 64, "one result per cache line");
+
+// LDS layout (doubles), shared by the kernel and the host-side size computation
+struct RoundLds {
+    int ctl, sC, yC, gC, pair, cS, cY, role, total;      // offsets; role = eval scratch | dense state
+    int Rt, Yt, vinv, va, vb, vc, ve, vw, vv, mv;        // dense state (offsets from 0)
+};
+__host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) {
+    RoundLds L;
+    int o = 0;
+    L.ctl = o; o += 32;
+    L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT;
+    L.pair = o; o += 2 * 4 * 128;
+    L.cS = o; o += 128; L.cY = o; o += 128;
+    o = (o + 1) & ~1;
+    L.role = o;
+    const int tri = m * (m + 1) / 2;
+    int d = o;
+    L.Rt = d; d += tri; L.Yt = d; d += tri;
+    L.vinv = d; d += 128; L.va = d; d += 128; L.vb = d; d += 128; L.vc = d; d += 128; L.ve = d; d += 128; L.vw = d; d += 128; L.vv = d; d += 128;
+    L.mv = d; d += 256;
+    const int e = o + eval_doubles;
+    L.total = (d > e ? d : e) + 2;
+    return L;
+}
+
+struct RoundArgs {
+    DevProblem dp;
+    int maxCN, maxXb, maxVb, nrow, nsteps, lpp, ppw, Kmax, pen_lds;   // geometry of the evaluation bodies (LaunchGeom); pen_lds in doubles per wave
+    double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20, *pcrw;           // leader-private vectors + the evaluation's stage buffers
+    double *pubsyg;          // [B][3 NXP + 2] leader -> cluster: s, y, g of an accepted step, then (slot, pair count)
+    double *part;            // [B][G][4][128] cluster -> dense: partial dot products
+    double *upub;            // [B][258]      dense -> cluster: -u, gamma w, gamma
+    double *dpub;            // [B][NXP]      cluster -> leader: direction chunks
+    unsigned *phase, *cntA, *uflag, *cntL;   // [B] each (zeroed before every launch)
+    unsigned *census, *status;               // [1] each (zeroed before every launch)
+    RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
+    rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
+    int B, G, m, NXP, eval_doubles;
+    double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
+};
+
+// ---- bounded waits (ONE lane) ----
+__device__ __forceinline__ bool rk_expired(const RoundArgs &a, rk_u64 deadline) {
+    return __hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u || wall_clock64() > deadline;
+}
+__device__ __forceinline__ bool rk_wait_eq(const unsigned *w, unsigned want, const RoundArgs &a) {
+    const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+    for (unsigned spins = 0;; spins++) {
+        if (__hip_atomic_load(w, FRX_RLX_AGENT) == want) return true;
+        if ((spins & 31u) == 31u && rk_expired(a, dl)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void rk_fail(const RoundArgs &a, unsigned code) {
+    unsigned expect = 0u;
+    __hip_atomic_compare_exchange_strong(a.status, &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every storing wave drains its write-through stores, the workgroup meets, then ONE lane publishes (Guideline 16, R1)
+__device__ __forceinline__ void rk_drain_and_meet() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <int E>
+__global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int CHT = 2 * E;
+    const int c = blockIdx.x / a.G, wg = blockIdx.x - c * a.G, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool leader = wg == 0, dense = wg == a.G - 1;
+    const int m = a.m;
+    const RoundLds L = round_lds(m, CHT, a.eval_doubles);
+    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word, [3] spare
+    double *ctlD = sm + L.ctl + 8;                                        // [0..3] f, g.d, x.x, g.g; [4] dginit; [5] step
+    double *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *cSv = sm + L.cS, *cYv = sm + L.cY, *ev = sm + L.role;
+    const int slot = t & 127, half = t >> 7;
+    const int xbase = a.dp.xoff[c], n = a.dp.xoff[c + 1] - xbase;
+    double *x = a.x + xbase, *g = a.g + xbase, *xp = a.xp + xbase, *gp = a.gp + xbase, *dv = a.d + xbase;
+    double *pub = a.pubsyg + (size_t)c * (3 * a.NXP + 2), *part = a.part + (size_t)c * a.G * 512, *upub = a.upub + (size_t)c * 258, *dpub = a.dpub + (size_t)c * a.NXP;
+
+    // ---- census: every workgroup of the grid must be resident before anybody waits for anybody ----
+    if (t == 0) {
+        __hip_atomic_fetch_add(a.census, 1u, FRX_RLX_AGENT);
+        const bool ok = rk_wait_eq(a.census, gridDim.x, a);
+        if (!ok) rk_fail(a, RK_ERR_CENSUS);
+        ctlU[0] = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    if (ctlU[0] == 0u) return;
+    __syncthreads();
+
+    // history registers: (s_slot, y_slot) restricted to this thread's elements; dense-state bookkeeping
+    double Sreg[E], Yreg[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
+    if (dense) {
+        for (int i = t; i < 128; i += 256) sm[L.vinv + i] = 0.0;
+    }
+    unsigned pseq = 0, nphase = 0, nadv = 0;                              // phases published / completed, accepted steps so far
+    rk_u64 hseq = 0;                                                       // host commands consumed (leader)
+    int lstage = 0, flags = 0, jnew = 0, bound = 0;
+    double step = 0.0;
+    const int p0 = a.dp.poff[c], N = a.dp.poff[c + 1] - p0;
+
+    for (;;) {
+        int kind = 0;
+        // =====================================================================================================
+        // LEADER: next command / next stage of the current command; decides which phase (if any) the cluster runs
+        // =====================================================================================================
+        if (leader) {
+            if (lstage == 0) {
+                if (t == 0) {
+                    const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+                    rk_u64 w = 0;
+                    bool ok = true;
+                    for (unsigned spins = 0;; spins++) {
+                        w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
+                        if ((w >> 32) == hseq + 1) break;
+                        if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
+                    }
+                    if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
+                    ctlU[1] = (unsigned)w; ctlU[2] = (unsigned)(w >> 32);
+                    if (ok) ctlD[5] = __longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS));
+                }
+                __syncthreads();
+                const unsigned w = ctlU[1];
+                flags = (int)(w & 0xFFu); jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
+                step = ctlD[5];
+                hseq++;
+                __syncthreads();
+                if (flags & DV_QUIT) kind = PH_QUIT;
+                else if (flags & DV_RESTORE) {                              // lbfgs.hpp:1287-1288; no evaluation follows
+                    for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }
+                    rk_drain_and_meet();
+                    if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
+                    continue;
+                } else if (flags & DV_ADVANCE) {                            // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
+                    for (int i = t; i < a.NXP; i += 256) {
+                        double s = 0.0, y = 0.0, gv = 0.0;
+                        if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
+                        stg<true>(pub + i, s); stg<true>(pub + a.NXP + i, y); stg<true>(pub + 2 * a.NXP + i, gv);
+                    }
+                    if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew); stg<true>(pub + 3 * a.NXP + 1, (double)bound); }   // the step's slot and pair count ride along
+                    kind = PH_ADV; lstage = 1;
+                } else {
+                    if (flags & DV_INIT) {                                  // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
+                        for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
+                    }
+                    lstage = 1;
+                }
+            }
+            if (lstage == 1 && kind == 0) {
+                if (flags & DV_TRIAL) {                                     // x = xp + step * d (lbfgs.hpp:825-826)
+                    __syncthreads();
+                    for (int i = t; i < n; i += 256) x[i] = xp[i] + step * dv[i];
+                }
+                if (flags & DV_EVAL) {
+                    __syncthreads();                                        // (vmcnt(0) + barrier: x is complete and visible to this CU)
+                    forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev);
+                    kind = PH_CT; lstage = 2;
+                } else {
+                    rk_drain_and_meet();
+                    if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
+                    lstage = 0;
+                    continue;
+                }
+            }
+            rk_drain_and_meet();                                            // everything published so far has left this CU
+            pseq++;
+            if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+        } else {
+            if (t == 0) {
+                const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+                unsigned w = 0;
+                bool ok = true;
+                for (unsigned spins = 0;; spins++) {
+                    w = __hip_atomic_load(a.phase + c, FRX_RLX_AGENT);
+                    if ((w >> 4) == pseq + 1) break;
+                    if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
+                ctlU[0] = w & 15u;
+            }
+            __syncthreads();
+            kind = (int)ctlU[0];
+            pseq++;
+            __syncthreads();
+        }
+        if (kind == PH_QUIT) break;
+
+        // =====================================================================================================
+        // PHASE ADV (every workgroup): new pair into the history, 4 m dot products, dense solve, linear combination
+        // =====================================================================================================
+        if (kind == PH_ADV) {
+            nadv++;
+            // -- 1. this workgroup's chunk of s, y, g --
+            const int e0 = wg * CHT;
+            for (int i = t; i < CHT; i += 256) { sC[i] = ldg<true>(pub + e0 + i); yC[i] = ldg<true>(pub + a.NXP + e0 + i); gC[i] = ldg<true>(pub + 2 * a.NXP + e0 + i); }
+            if (!leader) {
+                if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 3 * a.NXP + 1); }
+            }
+            __syncthreads();
+            if (!leader) { jnew = (int)ctlU[1]; bound = (int)ctlU[2]; }
+            jnew = __builtin_amdgcn_readfirstlane(jnew); bound = __builtin_amdgcn_readfirstlane(bound);     // wave-uniform by construction
+            // -- 2. the new pair replaces slot jnew --
+            if (slot == jnew) {
+#pragma unroll
+                for (int e = 0; e < E; e++) { Sreg[e] = sC[half * E + e]; Yreg[e] = yC[half * E + e]; }
+            }
+            // -- 3. pass A: s_j.g, y_j.g, s_j.y_new, y_j.y_new over this thread's elements --
+            int age = jnew - slot; if (age < 0) age += m;
+            const bool valid = slot < m && age < bound;
+            {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                if (valid) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        const double gg = gC[half * E + e], yn = yC[half * E + e];
+                        acc[0] += Sreg[e] * gg; acc[1] += Yreg[e] * gg; acc[2] += Sreg[e] * yn; acc[3] += Yreg[e] * yn;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) pair[(half * 4 + q) * 128 + slot] = acc[q];
+            }
+            __syncthreads();
+            for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)wg * 512 + o, pair[o] + pair[512 + o]);
+            rk_drain_and_meet();
+            if (t == 0) __hip_atomic_fetch_add(a.cntA + c, 1u, FRX_RLX_AGENT);
+            // -- 4. dense workgroup: reduce the partials, update R and Y^T Y, solve --
+            if (dense) {
+                double *Rt = sm + L.Rt, *Yt = sm + L.Yt, *vinv = sm + L.vinv, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw,
+                       *vv = sm + L.vv, *mv = sm + L.mv;
+                if (t == 0) { const bool ok = rk_wait_eq(a.cntA + c, (unsigned)a.G * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+                __syncthreads();
+                for (int o = t; o < 512; o += 256) {
+                    double s = 0.0;
+                    for (int w2 = 0; w2 < a.G; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);      // fixed order: deterministic
+                    (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
+                }
+                __syncthreads();
+                auto tri = [&](int p, int q) { const int lo = p < q ? p : q, hi = p < q ? q : p; return ((lo * (2 * m - lo + 1)) >> 1) + (hi - lo); };
+                auto age_of = [&](int j) { int ag = jnew - j; return ag < 0 ? ag + m : ag; };
+                if (t < m && age_of(t) < bound) { Rt[tri(t, jnew)] = vc[t]; Yt[tri(t, jnew)] = ve[t]; }
+                if (t == 0) vinv[jnew] = 1.0 / vc[jnew];
+                if (t < 128) vw[t] = 0.0;
+                __syncthreads();
+                const double gamma = vc[jnew] / ve[jnew];                  // y.s / y.y of the newest pair (lbfgs.hpp:1403)
+                // w = R^-1 a: newest row first (R is upper triangular in old -> new order); ONE wave, lane l owns slots l and l + 64
+                if (wave == 0) {
+                    const int s0 = lane, s1 = lane + 64;
+                    const int a0 = age_of(s0), a1 = age_of(s1);
+                    const bool v0 = s0 < m && a0 < bound, v1 = s1 < m && a1 < bound;
+                    double r0 = v0 ? va[s0] : 0.0, r1 = v1 ? va[s1] : 0.0;
+                    for (int k = 0; k < bound; k++) {
+                        int sk = jnew - k; if (sk < 0) sk += m;
+                        const double e0r = (v0 && a0 > k) ? Rt[tri(s0, sk)] : 0.0, e1r = (v1 && a1 > k) ? Rt[tri(s1, sk)] : 0.0;
+                        const double own = (sk & 64) ? r1 : r0;
+                        const int olo = __builtin_amdgcn_readlane(__double2loint(own), sk & 63), ohi = __builtin_amdgcn_readlane(__double2hiint(own), sk & 63);
+                        const double wk = __hiloint2double(ohi, olo) * vinv[sk];
+                        r0 -= e0r * wk; r1 -= e1r * wk;
+                        if (lane == 0) vw[sk] = wk;
+                    }
+                }
+                __syncthreads();
+                // v = D w + gamma (Y^T Y) w - gamma b: thread (i, hj) sums the columns [64 hj, 64 hj + 64)
+                {
+                    const int i = t & 127, hj = t >> 7;
+                    double s = 0.0;
+                    if (i < m && age_of(i) < bound)
+                        for (int j = 64 * hj; j < 64 * hj + 64 && j < m; j++) s += Yt[tri(i, j)] * vw[j];       // vw = 0 on slots without a pair
+                    mv[hj * 128 + i] = s;
+                }
+                __syncthreads();
+                if (t < 128) vv[t] = (t < m && age_of(t) < bound) ? (vw[t] / vinv[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t]) : 0.0;
+                __syncthreads();
+                // u = R^-T v: oldest row first
+                if (wave == 0) {
+                    const int s0 = lane, s1 = lane + 64;
+                    const int a0 = age_of(s0), a1 = age_of(s1);
+                    const bool v0 = s0 < m && a0 < bound, v1 = s1 < m && a1 < bound;
+                    double r0 = v0 ? vv[s0] : 0.0, r1 = v1 ? vv[s1] : 0.0;
+                    for (int k = bound - 1; k >= 0; k--) {
+                        int sk = jnew - k; if (sk < 0) sk += m;
+                        const double e0r = (v0 && a0 < k) ? Rt[tri(sk, s0)] : 0.0, e1r = (v1 && a1 < k) ? Rt[tri(sk, s1)] : 0.0;
+                        const double own = (sk & 64) ? r1 : r0;
+                        const int olo = __builtin_amdgcn_readlane(__double2loint(own), sk & 63), ohi = __builtin_amdgcn_readlane(__double2hiint(own), sk & 63);
+                        const double uk = __hiloint2double(ohi, olo) * vinv[sk];
+                        r0 -= e0r * uk; r1 -= e1r * uk;
+                        if (lane == 0) va[sk] = uk;                          // va is free by now: u goes there
+                    }
+                }
+                __syncthreads();
+                if (t < 128) {
+                    const bool vl = t < m && age_of(t) < bound;
+                    stg<true>(upub + t, vl ? -va[t] : 0.0);
+                    stg<true>(upub + 128 + t, vl ? gamma * vw[t] : 0.0);
+                }
+                if (t == 128) stg<true>(upub + 256, gamma);
+                rk_drain_and_meet();
+                if (t == 0) __hip_atomic_store(a.uflag + c, nadv, FRX_RLX_AGENT);
+            }
+            // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
+            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + c, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
+            __syncthreads();
+            {
+                const double coefS = ldg<true>(upub + slot), coefY = ldg<true>(upub + 128 + slot);
+                if (t == 0) ctlD[6] = ldg<true>(upub + 256);
+                double *wsum = pair;                                       // [4 waves][E]
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    double v4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v4[k] = valid ? (coefS * Sreg[e4 + k] + coefY * Yreg[e4 + k]) : 0.0;
+                    const double q = wave_sum4_packed<false>(v4);          // lane k < 4 holds the sum of value k over the wave's 64 slots
+                    if (lane < 4) wsum[wave * E + e4 + lane] = q;
+                }
+                __syncthreads();
+                const double gamma = ctlD[6];
+                for (int i = t; i < CHT; i += 256) {
+                    const int hh = i / E, e = i - hh * E;
+                    const double di = (wsum[(2 * hh) * E + e] + wsum[(2 * hh + 1) * E + e]) - gamma * gC[i];
+                    stg<true>(dpub + wg * CHT + i, di);
+                }
+            }
+        }
+        // =====================================================================================================
+        // PHASE CT (workgroups 0..G-2): penalty integrand of this workgroup's share of the candidate's pieces
+        // =====================================================================================================
+        if (kind == PH_CT && !dense) {
+            const int npw = a.G - 1, ntasks = (N + a.ppw - 1) / a.ppw, per_pass = npw * 4;
+            for (int base = 0; base < ntasks; base += per_pass) {
+                const int task = base + wg * 4 + wave;
+                const int np = task < ntasks ? min(a.ppw, N - task * a.ppw) : 0;
+                penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, np, ev + (size_t)wave * a.pen_lds, lane);
+                __syncthreads();
+            }
+        }
+        // ---- every workgroup reports the end of its part of the phase to the leader ----
+        rk_drain_and_meet();
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
+        nphase++;
+        if (leader) {
+            if (t == 0) { const bool ok = rk_wait_eq(a.cntL + c, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
+            __syncthreads();
+            const bool ok = ctlU[0] != 0u;
+            __syncthreads();
+            if (!ok) {                                                      // tell the host and the cluster, then leave
+                pseq++;
+                if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
+                break;
+            }
+            if (kind == PH_ADV) {                                           // gather the direction; dginit = gp . d (lbfgs.hpp:756)
+                double acc = 0.0;
+                for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
+                const double ws = wave_sum_dpp(acc);
+                if (lane == 0) pair[wave] = ws;
+                __syncthreads();
+                if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]);
+                __syncthreads();
+            }
+            if (lstage == 2) {                                              // after the penalty phase: adjoint, gradient, line-search scalars
+                LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
+                backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev);
+                rk_drain_and_meet();
+                if (t == 0) {
+                    RoundRes *r = a.h_res + c;
+                    __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
+                    __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
+                    __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
+                    __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
+                    __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
+                }
+                lstage = 0;
+                __syncthreads();
+            }
+        }
+    }
+}
+
+} // namespace frx

@@ -253,6 +253,22 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
 int frx_optimize_stats(const frx_problem *p, double *out4);
 
 /*
+ * How frx_optimize runs a plan on the device.  The reference's device side is ONE kernel that stays resident and is driven through
+ * a mailbox in mapped host memory (cc.cu:51-64, 396-405, 454-466, 535-548); the default here has the same shape: the RESIDENT ROUND
+ * KERNEL (csrc/frx_round_kernel.hpp) - one launch per plan, a cluster of workgroups per candidate, history of the L-BFGS in
+ * registers, per-candidate command/result mailboxes - whenever the batch fits the chip (B x G workgroups <= CUs, mem_size <= 128).
+ * Larger batches, and any launch on which a device-side wait expires, run one launch per stage and round (k_lbfgs_pre ->
+ * k_forward_knot -> k_penalty -> k_backward_knot).  frx_problem_set_resident(p, 0) pins a handle to the per-stage rounds
+ * (environment: FRX_RESIDENT=0).  frx_optimize_path reports what the last plan used (1 = resident kernel) and the resident
+ * kernel's device-side status word (0 = clean; otherwise the code of the wait that expired).
+ */
+int frx_problem_set_resident(frx_problem *p, int enable);
+int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device_status);
+/* Diagnostic (tests): with FRX_TRACE set in the environment, frx_optimize records for candidate 0 one row per evaluated command
+ * {flags, step, f, g.d, gp.d_new, x.x, g.g}; returns the number of rows and copies up to cap_rows of them (7 doubles each). */
+int frx_debug_trace(const frx_problem *p, double *out, int cap_rows);
+
+/*
  * Host-side solver on its own (used by the CPU tests and by integrators that bring their own
  * objective): minimises `count` independent problems with the batched state machine.  `eval`
  * is called with the ids of the problems that need a value; x/g are the packed arrays

@@ -1,0 +1,94 @@
+"""The resident round kernel (csrc/frx_round_kernel.hpp: one launch per plan, compact-form L-BFGS direction from a register-resident
+history, per-candidate mailboxes) against the one-launch-per-stage rounds (whose direction kernel is pinned to the host two-loop
+recursion by frx_dv_selftest and whose evaluation kernels are pinned to the oracle).  Both run the SAME host state machines, so
+command by command the scalars that cross the mailbox must agree to rounding until the path sensitivity of the optimisation
+ takes over; complete plans must end with the same status and inside the CPU-vs-CPU' envelope."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plan(prob, tol, resident, trace=False, **kw):
+    prob.set_resident(resident)
+    if trace:
+        os.environ["FRX_TRACE"] = "1"
+    try:
+        r = prob.optimize(tol, **kw)
+    finally:
+        os.environ.pop("FRX_TRACE", None)
+    r["trace"] = prob.trace() if trace else None
+    return r
+
+
+@pytest.mark.parametrize("B,N,gates,kappa", [(3, 16, 4, 8), (1, 64, 16, 16), (2, 5, 1, 8)])
+def test_resident_rounds_equal_per_stage_rounds(frx, sc, B, N, gates, kappa):
+    cands = sc.make_batch(11, B, N, gates)
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x0 = prob.initial_guess()
+    a = _plan(prob, 1e-6, True, trace=True, x0=x0, max_iterations=40)
+    b = _plan(prob, 1e-6, False, trace=True, x0=x0, max_iterations=40)
+    assert a["resident"] == 1 and a["device_status"] == 0, (a["resident"], a["device_status"])
+    assert b["resident"] == 0
+    ta, tb = a["trace"], b["trace"]
+    rows = min(len(ta), len(tb), 30)
+    assert rows >= 10, (len(ta), len(tb))
+    worst = 0.0
+    for i in range(rows):
+        fa, fb = ta[i], tb[i]
+        assert int(fa[0]) == int(fb[0]), f"command {i}: flags {fa[0]} vs {fb[0]}"
+        scale_g = np.sqrt(max(fb[6], 1e-300))
+        errs = [abs(fa[1] - fb[1]) / max(abs(fb[1]), 1e-300), abs(fa[2] - fb[2]) / abs(fb[2]), abs(fa[5] - fb[5]) / max(fb[5], 1e-300), abs(fa[6] - fb[6]) / max(fb[6], 1e-300)]
+        if int(fb[0]) & 4:      # ADVANCE: the new direction's slope
+            errs.append(abs(fa[4] - fb[4]) / max(abs(fb[4]), 1e-300))
+        worst = max(worst, max(errs))
+        assert max(errs) < 1e-6, f"command {i} (flags {int(fb[0])}): step/f/xx/gg[/dginit] rel err {errs}\nresident {fa}\nper-stage {fb}"
+    print(f"B={B} N={N}: {rows} commands compared, worst relative difference {worst:.2e}; resident {a['ms_total']:.2f} ms vs per-stage {b['ms_total']:.2f} ms for {a['rounds']} rounds")
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-5 * np.abs(b["x"]).max()
+    prob.close()
+
+
+def test_resident_plans_end_like_per_stage_plans(frx, sc):
+    """Stock tolerance, headline geometry (8 candidates x 64 pieces x kappa 16): same L-BFGS verdicts, objectives within the path
+    sensitivity measured between two CPU runs (tests/test_gpu_configs.py), bit-reproducible from call to call."""
+    B, N, gates, kappa = 8, 64, 16, 16
+    cands = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    a = _plan(prob, tol, True)
+    a2 = _plan(prob, tol, True)
+    b = _plan(prob, tol, False)
+    assert a["resident"] == 1 and a["device_status"] == 0 and b["resident"] == 0
+    print(json.dumps({"resident_ms": a["ms_total"], "resident_rounds": a["rounds"], "per_stage_ms": b["ms_total"], "per_stage_rounds": b["rounds"],
+                      "us_per_round_resident": 1e3 * a["ms_total"] / a["rounds"], "us_per_round_per_stage": 1e3 * b["ms_total"] / b["rounds"]}))
+    assert np.array_equal(a["x"], a2["x"]) and np.array_equal(a["evals"], a2["evals"])        # deterministic: fixed-order reductions everywhere
+    assert np.array_equal(a["status"], b["status"]) and np.all(a["status"] >= 0)
+    rel = np.abs(a["objective"] - b["objective"]) / np.abs(b["objective"])
+    assert rel.max() < 5e-3, rel
+    prob.close()
+
+
+def test_batches_that_do_not_fit_the_chip_take_the_per_stage_path(frx, sc):
+    cands = [sc.make_candidate(7, 12, 3, perturb_id=i) for i in range(140)]       # 140 clusters x >= 2 workgroups > 256 CUs
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    r = prob.optimize(1e-5, max_iterations=30)
+    assert r["resident"] == 0 and np.all(np.isfinite(r["objective"]))
+    prob.close()
+
+
+def test_resident_kernel_handles_failing_and_finishing_candidates(frx, sc, ob):
+    """An infeasible scenario (reference verdict LBFGSERR_MINIMUMSTEP: restore + stop) next to healthy ones of different length:
+    clusters leave the chip one by one."""
+    cands = [sc.make_candidate(170, 64, 16), sc.make_candidate(3, 64, 16), sc.make_candidate(5, 64, 16)]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+    r = _plan(prob, sc.ZHANGJIAJIE["opt_rel_tol"], True)
+    assert r["resident"] == 1 and r["device_status"] == 0
+    assert r["status"][0] == -1005 and r["objective"][0] > 1e8 and np.all(r["status"][1:] >= 0)
+    # the reported objective belongs to the returned point
+    f, _ = prob.objective(r["x"])
+    assert abs(f[0] - r["objective"][0]) <= 1e-9 * abs(f[0])
+    prob.close()
