@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
-    "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace",
+    "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace", "frx_resident_profile",
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def lib():
         L.frx_problem_set_resident.argtypes = [C.c_void_p, C.c_int]
         L.frx_optimize_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
         L.frx_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.frx_resident_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -281,6 +282,15 @@ class Problem:
         if n > 0:
             lib().frx_debug_trace(self.h, out.ctypes.data, n)
         return out
+
+    def resident_profile(self):
+        """[B][G][16] microseconds per segment of the last resident plan (needs FRX_RESIDENT_PROF in the environment)."""
+        n = lib().frx_resident_profile(self.h, None, 0)
+        if n <= 0:
+            return None
+        out = np.zeros(n, dtype=np.uint64)
+        lib().frx_resident_profile(self.h, out.ctypes.data, n)
+        return out.reshape(self.B, -1, 16).astype(np.float64) / 100.0
 
     def initial_guess(self):
         x = np.zeros(self.NX)

@@ -186,6 +186,8 @@ struct frx_problem {
     DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags, d_pflags;
     // resident round kernel (frx_round_kernel.hpp): cluster exchange buffers and mapped mailboxes, allocated on first use
     DevBuf<double> d_pubsyg, d_part, d_upub, d_dpub, d_rdbg;
+    DevBuf<unsigned long long> d_rprof;                     // FRX_RESIDENT_PROF: [B][G][16] per-segment ticks of the last resident launch
+    std::vector<unsigned long long> rprof;
     DevBuf<unsigned> d_rwords;
     PinBuf<unsigned long long> h_rcmd, h_rres;              // [B] x 2 words, [B] x 8 words
     int rk_B = 0, rk_G = 0, rk_NXP = 0;
@@ -944,7 +946,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
             const bool evaluated = (c.flags & frx::DV_EVAL) != 0;
             if (!evaluated) { c.flags = 0; continue; }                         // a RESTORE has been executed
             if (tracing && b == 0) { const frx::DvResult &r = p->h_res.p[b]; const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
-            sv[b].feed(p->h_res.p[b]);
+            if (sv[b].saw_nonfinite(p->h_res.p[b].f)) sv[b].give_up(frx::LBERR_ROUNDING); else sv[b].feed(p->h_res.p[b]);
         }
         t_host += ms_since(th);
         rounds++;
@@ -1000,6 +1002,12 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     const bool want_dbg = std::getenv("FRX_RESIDENT_DBG") != nullptr;
     if (want_dbg && (!p->d_rdbg.p || p->d_rdbg.n < (size_t)B * NXP) && p->d_rdbg.alloc((size_t)B * NXP) != hipSuccess) return 1;
+    const bool want_prof = std::getenv("FRX_RESIDENT_PROF") != nullptr;
+    if (want_prof) {
+        if ((!p->d_rprof.p || p->d_rprof.n < (size_t)B * G * 16) && p->d_rprof.alloc((size_t)B * G * 16) != hipSuccess) return 1;
+        HIP_TRY(hipMemsetAsync(p->d_rprof.p, 0, sizeof(unsigned long long) * (size_t)B * G * 16, p->stream));
+    }
+    p->rprof.clear();
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
     HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)4 * B + 2), p->stream));
@@ -1013,6 +1021,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
+    rl.prof = want_prof ? p->d_rprof.p : nullptr;
 
     std::vector<frx::SolverDV> sv(B);
     std::vector<frx::DvCommand> cmd(B);
@@ -1055,7 +1064,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
                 frx::DvResult r;
                 std::memcpy(&r, (const void *)(hr + 8 * b), 5 * sizeof(double));
                 if (tracing && b == 0) { const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
-                sv[b].feed(r);
+                if (sv[b].saw_nonfinite(r.f)) sv[b].give_up(frx::LBERR_ROUNDING); else sv[b].feed(r);
             } else c.flags = 0;                                                         // a RESTORE has been executed
             if (c.flags != 0) post(b, c.flags, c.slot, c.bound, c.step);
             else { post(b, 128, 0, 0, 0.0); quit_sent[b] = 1; waiting[b] = 0; live--; }   // this candidate's cluster leaves the chip
@@ -1085,13 +1094,14 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     for (int b = 0; b < B; b++) rounds = std::max(rounds, ncmd[b]);
     p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
+    if (want_prof) { p->rprof.resize((size_t)B * G * 16); HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * p->rprof.size(), hipMemcpyDeviceToHost)); }
     for (int b = 0; b < B; b++) {
         status[b] = sv[b].status();
         if (iters) iters[b] = sv[b].iterations();
         if (evals) evals[b] = sv[b].evaluations();
         if (objective) objective[b] = sv[b].value();
     }
-    p->resident_used = 1;
+    p->resident_used = G;
     return FRX_OK;
 }
 
@@ -1196,6 +1206,12 @@ int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device
     if (resident_used) *resident_used = p->resident_used;
     if (device_status) *device_status = p->resident_status;
     return FRX_OK;
+}
+int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_words) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    const int n = (int)p->rprof.size();
+    if (out) std::memcpy(out, p->rprof.data(), sizeof(unsigned long long) * (size_t)std::min(n, std::max(cap_words, 0)));
+    return n;
 }
 int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");

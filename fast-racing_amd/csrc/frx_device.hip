@@ -93,9 +93,12 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.timeout_ticks = r.timeout_ticks;
     a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g);
     const size_t lds = round_lds_bytes(g, r.m, r.E);
-    hipError_t e = hipFuncSetAttribute((const void *)k_round<ROUND_E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    a.prof = (rk_u64 *)r.prof;
+    const void *fn = r.prof ? (const void *)k_round<ROUND_E, true> : (const void *)k_round<ROUND_E, false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_round<ROUND_E>), dim3(r.B * r.G), dim3(256), lds, (hipStream_t)stream, a);
+    if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(r.B * r.G), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(r.B * r.G), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

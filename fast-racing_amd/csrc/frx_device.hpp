@@ -84,6 +84,7 @@ struct RoundLaunch {
     unsigned *words;                                               // [4 B + 2]: phase, cntA, uflag, cntL per candidate, then census, status
     void *h_cmd, *h_res;                                           // mapped host mailboxes, [B] x 16 B and [B] x 64 B
     unsigned long long timeout_ticks;
+    unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
     int B, G, m, E, NXP;
 };
 enum { ROUND_E = 48 };                                             // history doubles per thread and array of the instantiated kernel

@@ -458,6 +458,11 @@ public:
     int iterations() const { return k; }
     int evaluations() const { return evals; }
     double value() const { return fx; }
+    // Driver-side guard: a NaN objective passes every comparison of the backtracking search as "accepted" (lbfgs.hpp:986-1010), so
+    // with max_iterations = 0 the reference would iterate on NaNs for ever; the drivers stop a candidate after 64 consecutive
+    // non-finite values with LBFGSERR_ROUNDING, keeping the last finite point's bookkeeping.
+    void give_up(int code) { ret = code; phase = DONE; cmd->flags = 0; cmd->step = 0.0; }
+    bool saw_nonfinite(double f) { nonfinite = (std::isnan(f) || std::isinf(f)) ? nonfinite + 1 : 0; return nonfinite >= 64; }
 
     void feed(const DvResult &r) {
         ++evals;
@@ -513,7 +518,7 @@ private:
     frx_lbfgs_params pm;
     DvCommand *cmd = nullptr;
     Phase phase = DONE;
-    int ret = 0, k = 0, end = 0, evals = 0;
+    int ret = 0, k = 0, end = 0, evals = 0, nonfinite = 0;
     double fx = 0, step = 0, stepp = 0, fp = 0, xx = 0, gg = 0, dginit_cur = 0;
     std::vector<double> pf;
     LineSearch ls;

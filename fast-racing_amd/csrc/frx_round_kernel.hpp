@@ -53,12 +53,12 @@ static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 // LDS layout (doubles), shared by the kernel and the host-side size computation
 struct RoundLds {
     int ctl, sC, yC, gC, pair, cS, cY, role, total;      // offsets; role = eval scratch | dense state
-    int Rt, Yt, vinv, va, vb, vc, ve, vw, vv, mv;        // dense state (offsets from 0)
+    int Rt, Yt, vinv, va, vb, vc, ve, vw, vv, mv;        // dense state (offsets from 0): Rt = packed R^-1, Yt = packed Y^T Y, vinv = diag(R)
 };
 __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) {
     RoundLds L;
     int o = 0;
-    L.ctl = o; o += 32;
+    L.ctl = o; o += 48;                                   // 16 unsigned | 8 doubles | 16 profile accumulators
     L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT;
     L.pair = o; o += 2 * 4 * 128;
     L.cS = o; o += 128; L.cY = o; o += 128;
@@ -88,7 +88,11 @@ struct RoundArgs {
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
     int B, G, m, NXP, eval_doubles;
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
+    rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
 };
+// profile segments (thread 0 of every workgroup accumulates the time since its previous checkpoint into one of these)
+enum { RK_P_WAIT_HOST = 0, RK_P_VECTORS = 1, RK_P_FORWARD = 2, RK_P_WAIT_PHASE = 3, RK_P_PASS_A = 4, RK_P_WAIT_PART = 5, RK_P_DENSE_IN = 6, RK_P_SOLVE = 7,
+       RK_P_WAIT_U = 8, RK_P_PASS_B = 9, RK_P_PENALTY = 10, RK_P_WAIT_ARRIVE = 11, RK_P_GATHER = 12, RK_P_BACKWARD = 13, RK_P_POST = 14, RK_P_PUBLISH = 15 };
 
 // ---- bounded waits (ONE lane) ----
 __device__ __forceinline__ bool rk_expired(const RoundArgs &a, rk_u64 deadline) {
@@ -112,10 +116,12 @@ __device__ __forceinline__ void rk_drain_and_meet() {
     __syncthreads();
 }
 
-template <int E>
+template <int E, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int CHT = 2 * E;
+    rk_u64 prof_last = 0;
+#define RK_PROF(seg) do { if (PROF && threadIdx.x == 0) { const rk_u64 now_ = wall_clock64(); ((rk_u64 *)(sm + L.ctl + 16))[seg] += now_ - prof_last; prof_last = now_; } } while (0)
     const int c = blockIdx.x / a.G, wg = blockIdx.x - c * a.G, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool leader = wg == 0, dense = wg == a.G - 1;
     const int m = a.m;
@@ -139,12 +145,14 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     if (ctlU[0] == 0u) return;
     __syncthreads();
 
+    if (PROF) { if (t < 16) ((rk_u64 *)(sm + L.ctl + 16))[t] = 0; __syncthreads(); prof_last = wall_clock64(); }
     // history registers: (s_slot, y_slot) restricted to this thread's elements; dense-state bookkeeping
     double Sreg[E], Yreg[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
-    if (dense) {
-        for (int i = t; i < 128; i += 256) sm[L.vinv + i] = 0.0;
+    if (dense) {                                                           // R^-1, Y^T Y, D start as zeros: no uninitialised word is ever multiplied
+        for (int i = L.Rt + t; i < L.va; i += 256) sm[i] = 0.0;
+        __syncthreads();
     }
     unsigned pseq = 0, nphase = 0, nadv = 0;                              // phases published / completed, accepted steps so far
     rk_u64 hseq = 0;                                                       // host commands consumed (leader)
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                     if (ok) ctlD[5] = __longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS));
                 }
                 __syncthreads();
+                RK_PROF(RK_P_WAIT_HOST);
                 const unsigned w = ctlU[1];
                 flags = (int)(w & 0xFFu); jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
                 step = ctlD[5];
@@ -206,8 +215,10 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 }
                 if (flags & DV_EVAL) {
                     __syncthreads();                                        // (vmcnt(0) + barrier: x is complete and visible to this CU)
+                    RK_PROF(RK_P_VECTORS);
                     forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev);
                     kind = PH_CT; lstage = 2;
+                    RK_PROF(RK_P_FORWARD);
                 } else {
                     rk_drain_and_meet();
                     if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             rk_drain_and_meet();                                            // everything published so far has left this CU
             pseq++;
             if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+            RK_PROF(RK_P_PUBLISH);
         } else {
             if (t == 0) {
                 const rk_u64 dl = wall_clock64() + a.timeout_ticks;
@@ -236,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             kind = (int)ctlU[0];
             pseq++;
             __syncthreads();
+            RK_PROF(RK_P_WAIT_PHASE);
         }
         if (kind == PH_QUIT) break;
 
@@ -277,82 +290,74 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)wg * 512 + o, pair[o] + pair[512 + o]);
             rk_drain_and_meet();
             if (t == 0) __hip_atomic_fetch_add(a.cntA + c, 1u, FRX_RLX_AGENT);
+            RK_PROF(RK_P_PASS_A);
             // -- 4. dense workgroup: reduce the partials, update R and Y^T Y, solve --
             if (dense) {
                 double *Rt = sm + L.Rt, *Yt = sm + L.Yt, *vinv = sm + L.vinv, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw,
                        *vv = sm + L.vv, *mv = sm + L.mv;
                 if (t == 0) { const bool ok = rk_wait_eq(a.cntA + c, (unsigned)a.G * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
                 __syncthreads();
+                RK_PROF(RK_P_WAIT_PART);
                 for (int o = t; o < 512; o += 256) {
                     double s = 0.0;
                     for (int w2 = 0; w2 < a.G; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);      // fixed order: deterministic
                     (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
                 }
                 __syncthreads();
-                auto tri = [&](int p, int q) { const int lo = p < q ? p : q, hi = p < q ? q : p; return ((lo * (2 * m - lo + 1)) >> 1) + (hi - lo); };
+                RK_PROF(RK_P_DENSE_IN);
+                // The dense step keeps R^-1 itself (packed by slot pair: entry (i, j), i not newer than j, at tri(i, j)), not R: when the
+                // oldest pair is dropped R^-1 loses its first row and column and nothing else changes; a new pair appends the column
+                // (-R22^-1 c / rho, 1 / rho) with c = S^T y_new, rho = s_new . y_new.  Every product is then a masked mat-vec over all
+                // 256 threads instead of a 128-step substitution issued by one wave (measured: 2 x 128 dependent steps = 20 of a round's
+                // 78 us).  Checked on a complete headline optimisation (3500 accepted steps, cond(R) up to 1e6): the direction stays
+                // within 3e-13 of the two-loop recursion, no drift (scripts/lbfgs_inverse_stability.py).
+                auto off_of = [&](int q) { return (q * (2 * m - q + 1)) >> 1; };
+                auto tri2 = [&](int sl, int offl, int sk, int offk) { return sl < sk ? offl + (sk - sl) : offk + (sl - sk); };
                 auto age_of = [&](int j) { int ag = jnew - j; return ag < 0 ? ag + m : ag; };
-                if (t < m && age_of(t) < bound) { Rt[tri(t, jnew)] = vc[t]; Yt[tri(t, jnew)] = ve[t]; }
-                if (t == 0) vinv[jnew] = 1.0 / vc[jnew];
-                if (t < 128) vw[t] = 0.0;
-                __syncthreads();
-                const double gamma = vc[jnew] / ve[jnew];                  // y.s / y.y of the newest pair (lbfgs.hpp:1403)
-                // w = R^-1 a: newest row first (R is upper triangular in old -> new order); ONE wave, lane l owns slots l and l + 64
-                if (wave == 0) {
-                    const int s0 = lane, s1 = lane + 64;
-                    const int a0 = age_of(s0), a1 = age_of(s1);
-                    const bool v0 = s0 < m && a0 < bound, v1 = s1 < m && a1 < bound;
-                    double r0 = v0 ? va[s0] : 0.0, r1 = v1 ? va[s1] : 0.0;
-                    for (int k = 0; k < bound; k++) {
-                        int sk = jnew - k; if (sk < 0) sk += m;
-                        const double e0r = (v0 && a0 > k) ? Rt[tri(s0, sk)] : 0.0, e1r = (v1 && a1 > k) ? Rt[tri(s1, sk)] : 0.0;
-                        const double own = (sk & 64) ? r1 : r0;
-                        const int olo = __builtin_amdgcn_readlane(__double2loint(own), sk & 63), ohi = __builtin_amdgcn_readlane(__double2hiint(own), sk & 63);
-                        const double wk = __hiloint2double(ohi, olo) * vinv[sk];
-                        r0 -= e0r * wk; r1 -= e1r * wk;
-                        if (lane == 0) vw[sk] = wk;
+                const int pp = t & 127, hq = t >> 7, opp = off_of(pp), app = age_of(pp);
+                const bool vpp = pp < m && app < bound;
+                // mode 0: all pairs; 1: q not older than p (row of R^-1); 2: q not newer than p (column of R^-1); 3: like 1 without slot jnew
+                auto matvec = [&](const double *M, const double *vec, int mode) {
+                    double sacc = 0.0;
+                    if (vpp) {
+                        const int q1 = min(64 * hq + 64, m);
+#pragma unroll 4
+                        for (int q = 64 * hq; q < q1; q++) {
+                            const int aq = age_of(q);
+                            const bool use = aq < bound && (mode == 0 || (mode == 2 ? aq >= app : aq <= app)) && (mode != 3 || (q != jnew && pp != jnew));
+                            const double e = M[tri2(pp, opp, q, off_of(q))];
+                            sacc += (use ? e : 0.0) * vec[q];
+                        }
                     }
-                }
+                    mv[hq * 128 + pp] = sacc;
+                    __syncthreads();
+                };
+                if (t < m && age_of(t) < bound) Yt[tri2(t, off_of(t), jnew, off_of(jnew))] = ve[t];
+                const double rho = vc[jnew], gamma = rho / ve[jnew];        // y.s, and y.s / y.y of the newest pair (lbfgs.hpp:1403)
+                if (t == 0) vinv[jnew] = rho;                               // diagonal of R (the array keeps D, despite its name)
+                matvec(Rt, vc, 3);                                          // z = R22^-1 c
+                if (t < 128 && vpp) Rt[tri2(pp, opp, jnew, off_of(jnew))] = pp == jnew ? 1.0 / rho : -(mv[pp] + mv[128 + pp]) / rho;
                 __syncthreads();
-                // v = D w + gamma (Y^T Y) w - gamma b: thread (i, hj) sums the columns [64 hj, 64 hj + 64)
-                {
-                    const int i = t & 127, hj = t >> 7;
-                    double s = 0.0;
-                    if (i < m && age_of(i) < bound)
-                        for (int j = 64 * hj; j < 64 * hj + 64 && j < m; j++) s += Yt[tri(i, j)] * vw[j];       // vw = 0 on slots without a pair
-                    mv[hj * 128 + i] = s;
-                }
+                matvec(Rt, va, 1);                                          // w = R^-1 (S^T g)
+                if (t < 128) vw[t] = vpp ? mv[t] + mv[128 + t] : 0.0;
                 __syncthreads();
-                if (t < 128) vv[t] = (t < m && age_of(t) < bound) ? (vw[t] / vinv[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t]) : 0.0;
+                matvec(Yt, vw, 0);                                          // (Y^T Y) w
+                if (t < 128) vv[t] = vpp ? (vinv[t] * vw[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t]) : 0.0;
                 __syncthreads();
-                // u = R^-T v: oldest row first
-                if (wave == 0) {
-                    const int s0 = lane, s1 = lane + 64;
-                    const int a0 = age_of(s0), a1 = age_of(s1);
-                    const bool v0 = s0 < m && a0 < bound, v1 = s1 < m && a1 < bound;
-                    double r0 = v0 ? vv[s0] : 0.0, r1 = v1 ? vv[s1] : 0.0;
-                    for (int k = bound - 1; k >= 0; k--) {
-                        int sk = jnew - k; if (sk < 0) sk += m;
-                        const double e0r = (v0 && a0 < k) ? Rt[tri(sk, s0)] : 0.0, e1r = (v1 && a1 < k) ? Rt[tri(sk, s1)] : 0.0;
-                        const double own = (sk & 64) ? r1 : r0;
-                        const int olo = __builtin_amdgcn_readlane(__double2loint(own), sk & 63), ohi = __builtin_amdgcn_readlane(__double2hiint(own), sk & 63);
-                        const double uk = __hiloint2double(ohi, olo) * vinv[sk];
-                        r0 -= e0r * uk; r1 -= e1r * uk;
-                        if (lane == 0) va[sk] = uk;                          // va is free by now: u goes there
-                    }
-                }
-                __syncthreads();
+                matvec(Rt, vv, 2);                                          // u = R^-T v
                 if (t < 128) {
-                    const bool vl = t < m && age_of(t) < bound;
-                    stg<true>(upub + t, vl ? -va[t] : 0.0);
-                    stg<true>(upub + 128 + t, vl ? gamma * vw[t] : 0.0);
+                    stg<true>(upub + t, vpp ? -(mv[t] + mv[128 + t]) : 0.0);
+                    stg<true>(upub + 128 + t, vpp ? gamma * vw[t] : 0.0);
                 }
                 if (t == 128) stg<true>(upub + 256, gamma);
                 rk_drain_and_meet();
                 if (t == 0) __hip_atomic_store(a.uflag + c, nadv, FRX_RLX_AGENT);
+                RK_PROF(RK_P_SOLVE);
             }
             // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
             if (t == 0) { const bool ok = rk_wait_eq(a.uflag + c, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
             __syncthreads();
+            RK_PROF(RK_P_WAIT_U);
             {
                 const double coefS = ldg<true>(upub + slot), coefY = ldg<true>(upub + 128 + slot);
                 if (t == 0) ctlD[6] = ldg<true>(upub + 256);
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                     stg<true>(dpub + wg * CHT + i, di);
                 }
             }
+            RK_PROF(RK_P_PASS_B);
         }
         // =====================================================================================================
         // PHASE CT (workgroups 0..G-2): penalty integrand of this workgroup's share of the candidate's pieces
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, np, ev + (size_t)wave * a.pen_lds, lane);
                 __syncthreads();
             }
+            RK_PROF(RK_P_PENALTY);
         }
         // ---- every workgroup reports the end of its part of the phase to the leader ----
         rk_drain_and_meet();
@@ -395,6 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             __syncthreads();
             const bool ok = ctlU[0] != 0u;
             __syncthreads();
+            RK_PROF(RK_P_WAIT_ARRIVE);
             if (!ok) {                                                      // tell the host and the cluster, then leave
                 pseq++;
                 if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
@@ -408,11 +416,13 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 __syncthreads();
                 if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]);
                 __syncthreads();
+                RK_PROF(RK_P_GATHER);
             }
             if (lstage == 2) {                                              // after the penalty phase: adjoint, gradient, line-search scalars
                 LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
                 backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev);
                 rk_drain_and_meet();
+                RK_PROF(RK_P_BACKWARD);
                 if (t == 0) {
                     RoundRes *r = a.h_res + c;
                     __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
@@ -426,9 +436,12 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 }
                 lstage = 0;
                 __syncthreads();
+                RK_PROF(RK_P_POST);
             }
         }
     }
+    if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+#undef RK_PROF
 }
 
 } // namespace frx

@@ -259,7 +259,7 @@ int frx_optimize_stats(const frx_problem *p, double *out4);
  * registers, per-candidate command/result mailboxes - whenever the batch fits the chip (B x G workgroups <= CUs, mem_size <= 128).
  * Larger batches, and any launch on which a device-side wait expires, run one launch per stage and round (k_lbfgs_pre ->
  * k_forward_knot -> k_penalty -> k_backward_knot).  frx_problem_set_resident(p, 0) pins a handle to the per-stage rounds
- * (environment: FRX_RESIDENT=0).  frx_optimize_path reports what the last plan used (1 = resident kernel) and the resident
+ * (environment: FRX_RESIDENT=0).  frx_optimize_path reports what the last plan used (0 = per-stage rounds, G > 0 = resident kernel with G workgroups per candidate) and the resident
  * kernel's device-side status word (0 = clean; otherwise the code of the wait that expired).
  */
 int frx_problem_set_resident(frx_problem *p, int enable);
@@ -267,6 +267,9 @@ int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device
 /* Diagnostic (tests): with FRX_TRACE set in the environment, frx_optimize records for candidate 0 one row per evaluated command
  * {flags, step, f, g.d, gp.d_new, x.x, g.g}; returns the number of rows and copies up to cap_rows of them (7 doubles each). */
 int frx_debug_trace(const frx_problem *p, double *out, int cap_rows);
+/* Diagnostic: with FRX_RESIDENT_PROF set, the resident kernel runs its instrumented instantiation and leaves 16 counters of 100 MHz
+ * ticks per workgroup ([B][G][16], segments RK_P_* of csrc/frx_round_kernel.hpp); returns the word count, copies up to cap_words. */
+int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_words);
 
 /*
  * Host-side solver on its own (used by the CPU tests and by integrators that bring their own

@@ -1,0 +1,30 @@
+"""Per-segment time of the resident round kernel (FRX_RESIDENT_PROF instantiation): leader, dense and one plain member workgroup of
+candidate 0, microseconds per round.  Usage: python scripts/resident_profile.py [B] [N] [kappa] [max_iterations]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from frx_import import frx
+from fast_racing_amd import scenario as sc
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+kappa = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 400
+SEG = ["wait_host", "vectors", "forward", "wait_phase", "pass_a", "wait_part", "dense_in", "solve", "wait_u", "pass_b", "penalty", "wait_arrive", "gather", "backward", "post", "publish"]
+cands = [sc.make_candidate(0, N, N // 4, perturb_id=b) for b in range(B)]
+prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+x0 = prob.initial_guess()
+prob.optimize(1e-6, x0=x0, max_iterations=20)                     # warm
+os.environ["FRX_RESIDENT_PROF"] = "1"
+r = prob.optimize(1e-6, x0=x0, max_iterations=iters)
+del os.environ["FRX_RESIDENT_PROF"]
+pr = prob.resident_profile()
+rounds = int(r["evals"][0])
+G = pr.shape[1]
+out = {"B": B, "N": N, "kappa": kappa, "G": G, "rounds_cand0": rounds, "iters_cand0": int(r["iters"][0]), "plan_ms": r["ms_total"], "us_per_round_wall": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
+for name, wg in (("leader", 0), ("member1", 1), ("dense", G - 1)):
+    out[name] = {SEG[i]: round(float(pr[0, wg, i]) / rounds, 2) for i in range(16) if pr[0, wg, i] > 0}
+    out[name]["total"] = round(float(pr[0, wg].sum()) / rounds, 2)
+print(json.dumps(out, indent=1))
+prob.set_resident(False)
+r2 = prob.optimize(1e-6, x0=x0, max_iterations=iters)
+print(json.dumps({"per_stage_ms": r2["ms_total"], "per_stage_us_per_round": 1e3 * r2["ms_total"] / r2["rounds"]}))

@@ -32,7 +32,7 @@ def test_resident_rounds_equal_per_stage_rounds(frx, sc, B, N, gates, kappa):
     x0 = prob.initial_guess()
     a = _plan(prob, 1e-6, True, trace=True, x0=x0, max_iterations=40)
     b = _plan(prob, 1e-6, False, trace=True, x0=x0, max_iterations=40)
-    assert a["resident"] == 1 and a["device_status"] == 0, (a["resident"], a["device_status"])
+    assert a["resident"] >= 2 and a["device_status"] == 0, (a["resident"], a["device_status"])
     assert b["resident"] == 0
     ta, tb = a["trace"], b["trace"]
     rows = min(len(ta), len(tb), 30)
@@ -62,7 +62,7 @@ def test_resident_plans_end_like_per_stage_plans(frx, sc):
     a = _plan(prob, tol, True)
     a2 = _plan(prob, tol, True)
     b = _plan(prob, tol, False)
-    assert a["resident"] == 1 and a["device_status"] == 0 and b["resident"] == 0
+    assert a["resident"] >= 2 and a["device_status"] == 0 and b["resident"] == 0
     print(json.dumps({"resident_ms": a["ms_total"], "resident_rounds": a["rounds"], "per_stage_ms": b["ms_total"], "per_stage_rounds": b["rounds"],
                       "us_per_round_resident": 1e3 * a["ms_total"] / a["rounds"], "us_per_round_per_stage": 1e3 * b["ms_total"] / b["rounds"]}))
     assert np.array_equal(a["x"], a2["x"]) and np.array_equal(a["evals"], a2["evals"])        # deterministic: fixed-order reductions everywhere
@@ -86,7 +86,7 @@ def test_resident_kernel_handles_failing_and_finishing_candidates(frx, sc, ob):
     cands = [sc.make_candidate(170, 64, 16), sc.make_candidate(3, 64, 16), sc.make_candidate(5, 64, 16)]
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
     r = _plan(prob, sc.ZHANGJIAJIE["opt_rel_tol"], True)
-    assert r["resident"] == 1 and r["device_status"] == 0
+    assert r["resident"] >= 2 and r["device_status"] == 0
     assert r["status"][0] == -1005 and r["objective"][0] > 1e8 and np.all(r["status"][1:] >= 0)
     # the reported objective belongs to the returned point
     f, _ = prob.objective(r["x"])
