@@ -70,11 +70,12 @@ int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void
     return (int)hipGetLastError();
 }
 
+static int round_ct_doubles(const LaunchGeom &g) { return (g.maxN * 19 + 1) & ~1; }
 static int round_eval_doubles(const LaunchGeom &g) {
     const size_t pen = (size_t)g.ppw * 19 + (size_t)g.ppw * (g.Kmax + 1) * 4 + 64 * 21;              // doubles per wave (LaunchGeom::lds_pen)
     size_t e = std::max(g.lds_kfwd, g.lds_kbwd) / sizeof(double) + 2;
     e = std::max(e, 4 * pen + 8);
-    return (int)((e + 1) & ~(size_t)1);
+    return (int)((e + 1) & ~(size_t)1) + round_ct_doubles(g);
 }
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E) {
     if (E != ROUND_E || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
@@ -91,7 +92,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.phase = r.words; a.cntA = r.words + r.B; a.uflag = r.words + 2 * r.B; a.cntL = r.words + 3 * r.B; a.census = r.words + 4 * r.B; a.status = r.words + 4 * r.B + 1;
     a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
     a.timeout_ticks = r.timeout_ticks;
-    a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g);
+    a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g);
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;
     const void *fn = r.prof ? (const void *)k_round<ROUND_E, true> : (const void *)k_round<ROUND_E, false>;

@@ -717,7 +717,8 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
 // SH: T and C are consumed by OTHER workgroups of the same launch (see ldg / stg above).
 template <bool SH>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm) {
+                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr) {
+    // ct_lds (optional, LDS, 19 doubles per piece: 18 coefficients + duration): a copy for the backward pass of the same workgroup
     const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
@@ -779,6 +780,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
         stg<SH>(Tout + p0 + k, hMine);
+        if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
     FRX_STAMP(2);
     // forwardP (CPU.hpp:729-747): waypoint w (= knot w+1) is handled by a QUAD of lanes, each taking every 4th vertex;
@@ -870,7 +872,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             double c[6];
             hermite_coeffs(hMine, KN(KP, ax, k), KN(KV, ax, k), KN(KA, ax, k), KN(KP, ax, k + 1), KN(KV, ax, k + 1), KN(KA, ax, k + 1), c);
 #pragma unroll
-            for (int q = 0; q < 6; q++) stg<SH>(co + q * 3 + ax, c[q]);
+            for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, c[q]); if (ct_lds) ct_lds[k * 19 + q * 3 + ax] = c[q]; }
         }
     }
     FRX_STAMP(6);
@@ -887,7 +889,7 @@ template <bool SH>
 __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
-                                const LineSearchTap &tap, int b, double *sm) {
+                                const LineSearchTap &tap, int b, double *sm, const double *ct_lds = nullptr) {
     const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
@@ -912,12 +914,20 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     double h = 1.0, c[18], cb[18], o0 = 0.0, o1 = 0.0, r_tl[3] = {0, 0, 0};
     int r_wnv = 1, r_wvb = 0, r_wxb = 0;
     if (k < N) {
-        h = ldg<SH>(Tin + p0 + k);
         const double *ci = Cin + (size_t)(p0 + k) * 18;
         const double *o = out20 + (size_t)(p0 + k) * 20;
         o0 = ldg<SH>(o); o1 = ldg<SH>(o + 1);
 #pragma unroll
-        for (int q = 0; q < 18; q++) { c[q] = ldg<SH>(ci + q); cb[q] = ldg<SH>(o + 2 + q); }
+        for (int q = 0; q < 18; q++) cb[q] = ldg<SH>(o + 2 + q);
+        if (ct_lds) {                                           // this workgroup's own forward pass left them in LDS
+            h = ct_lds[k * 19 + 18];
+#pragma unroll
+            for (int q = 0; q < 18; q++) c[q] = ct_lds[k * 19 + q];
+        } else {
+            h = ldg<SH>(Tin + p0 + k);
+#pragma unroll
+            for (int q = 0; q < 18; q++) c[q] = ldg<SH>(ci + q);
+        }
     }
     if ((k >> 2) < N - 1) { const int gw = p0 - b + (k >> 2); r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }   // quad k>>2 = waypoint
     if (k < 3) { r_tl[0] = dp.tailPVA[b * 9 + k]; r_tl[1] = dp.tailPVA[b * 9 + 3 + k]; r_tl[2] = dp.tailPVA[b * 9 + 6 + k]; }

@@ -68,7 +68,7 @@ __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) 
     int d = o;
     L.Rt = d; d += tri; L.Yt = d; d += tri;
     L.vinv = d; d += 128; L.va = d; d += 128; L.vb = d; d += 128; L.vc = d; d += 128; L.ve = d; d += 128; L.vw = d; d += 128; L.vv = d; d += 128;
-    L.mv = d; d += 256;
+    L.mv = d; d += 512;                                  // two [2][128] half-sum buffers
     const int e = o + eval_doubles;
     L.total = (d > e ? d : e) + 2;
     return L;
@@ -86,7 +86,7 @@ struct RoundArgs {
     unsigned *census, *status;               // [1] each (zeroed before every launch)
     RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
-    int B, G, m, NXP, eval_doubles;
+    int B, G, m, NXP, eval_doubles, ct_doubles;                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
 };
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     const RoundLds L = round_lds(m, CHT, a.eval_doubles);
     volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word, [3] spare
     double *ctlD = sm + L.ctl + 8;                                        // [0..3] f, g.d, x.x, g.g; [4] dginit; [5] step
-    double *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *cSv = sm + L.cS, *cYv = sm + L.cY, *ev = sm + L.role;
+    double *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
     const int slot = t & 127, half = t >> 7;
     const int xbase = a.dp.xoff[c], n = a.dp.xoff[c + 1] - xbase;
     double *x = a.x + xbase, *g = a.g + xbase, *xp = a.xp + xbase, *gp = a.gp + xbase, *dv = a.d + xbase;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 if (flags & DV_EVAL) {
                     __syncthreads();                                        // (vmcnt(0) + barrier: x is complete and visible to this CU)
                     RK_PROF(RK_P_VECTORS);
-                    forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev);
+                    forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl);
                     kind = PH_CT; lstage = 2;
                     RK_PROF(RK_P_FORWARD);
                 } else {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             // -- 4. dense workgroup: reduce the partials, update R and Y^T Y, solve --
             if (dense) {
                 double *Rt = sm + L.Rt, *Yt = sm + L.Yt, *vinv = sm + L.vinv, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw,
-                       *vv = sm + L.vv, *mv = sm + L.mv;
+                       *vv = sm + L.vv, *mv = sm + L.mv, *mz = sm + L.mv + 256;
                 if (t == 0) { const bool ok = rk_wait_eq(a.cntA + c, (unsigned)a.G * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
                 __syncthreads();
                 RK_PROF(RK_P_WAIT_PART);
@@ -316,37 +316,85 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 auto age_of = [&](int j) { int ag = jnew - j; return ag < 0 ? ag + m : ag; };
                 const int pp = t & 127, hq = t >> 7, opp = off_of(pp), app = age_of(pp);
                 const bool vpp = pp < m && app < bound;
-                // mode 0: all pairs; 1: q not older than p (row of R^-1); 2: q not newer than p (column of R^-1); 3: like 1 without slot jnew
-                auto matvec = [&](const double *M, const double *vec, int mode) {
-                    double sacc = 0.0;
+                // Three passes over the packed matrices, 16 columns per trip (all 32 LDS reads of a trip are issued before the first FMA
+                // needs one; a trip of 4 was latency-bound: ~4 us per pass, measured).  Thread (p, hq) sums the columns [64 hq, 64 hq + 64).
+                //   pass 1  rows of the OLD R^-1 without slot jnew, two right-hand sides at once: z = R22^-1 c and t = R22^-1 a
+                //           => new column (-z / rho, 1 / rho), and w = (t - z a_new / rho, a_new / rho)
+                //   pass 2  (Y^T Y) w        (no mask: entries without a pair are zero, and so is w there)
+                //   pass 3  columns of the new R^-1: u = R^-T v
+                const int q0 = 64 * hq;
+                if (t < m && age_of(t) < bound) Yt[tri2(t, off_of(t), jnew, off_of(jnew))] = ve[t];
+                const double rho = vc[jnew], gamma = rho / ve[jnew];        // y.s, and y.s / y.y of the newest pair (lbfgs.hpp:1403)
+                if (t == 0) vinv[jnew] = rho;                               // diagonal of R (the array keeps D, despite its name)
+                {
+                    double sz = 0.0, st = 0.0;
+                    if (vpp && pp != jnew) {
+#pragma unroll 1
+                        for (int qb = 0; qb < 64; qb += 16) {
+                            double e[16], cq[16], aqv[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                const int q = min(q0 + qb + u, m - 1);
+                                e[u] = Rt[tri2(pp, opp, q, off_of(q))]; cq[u] = vc[q]; aqv[u] = va[q];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                const int q = q0 + qb + u, aq = age_of(min(q, m - 1));
+                                const double em = (q < m && q != jnew && aq < bound && aq <= app) ? e[u] : 0.0;
+                                sz += em * cq[u]; st += em * aqv[u];
+                            }
+                        }
+                    }
+                    mv[hq * 128 + pp] = sz; mz[hq * 128 + pp] = st;
+                    __syncthreads();
+                }
+                if (t < 128) {
+                    const double wl = va[jnew] / rho;
+                    double wp = 0.0;
                     if (vpp) {
-                        const int q1 = min(64 * hq + 64, m);
-#pragma unroll 4
-                        for (int q = 64 * hq; q < q1; q++) {
-                            const int aq = age_of(q);
-                            const bool use = aq < bound && (mode == 0 || (mode == 2 ? aq >= app : aq <= app)) && (mode != 3 || (q != jnew && pp != jnew));
-                            const double e = M[tri2(pp, opp, q, off_of(q))];
-                            sacc += (use ? e : 0.0) * vec[q];
+                        if (pp == jnew) { Rt[tri2(pp, opp, jnew, off_of(jnew))] = 1.0 / rho; wp = wl; }
+                        else { const double z = mv[pp] + mv[128 + pp]; Rt[tri2(pp, opp, jnew, off_of(jnew))] = -z / rho; wp = (mz[pp] + mz[128 + pp]) - z * wl; }
+                    }
+                    vw[t] = wp;
+                }
+                __syncthreads();
+                {
+                    double sacc = 0.0;
+                    if (pp < m) {
+#pragma unroll 1
+                        for (int qb = 0; qb < 64; qb += 16) {
+                            double e[16], xq[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) { const int q = min(q0 + qb + u, m - 1); e[u] = Yt[tri2(pp, opp, q, off_of(q))]; xq[u] = (q0 + qb + u < m) ? vw[q] : 0.0; }
+#pragma unroll
+                            for (int u = 0; u < 16; u++) sacc += e[u] * xq[u];
                         }
                     }
                     mv[hq * 128 + pp] = sacc;
                     __syncthreads();
-                };
-                if (t < m && age_of(t) < bound) Yt[tri2(t, off_of(t), jnew, off_of(jnew))] = ve[t];
-                const double rho = vc[jnew], gamma = rho / ve[jnew];        // y.s, and y.s / y.y of the newest pair (lbfgs.hpp:1403)
-                if (t == 0) vinv[jnew] = rho;                               // diagonal of R (the array keeps D, despite its name)
-                matvec(Rt, vc, 3);                                          // z = R22^-1 c
-                if (t < 128 && vpp) Rt[tri2(pp, opp, jnew, off_of(jnew))] = pp == jnew ? 1.0 / rho : -(mv[pp] + mv[128 + pp]) / rho;
-                __syncthreads();
-                matvec(Rt, va, 1);                                          // w = R^-1 (S^T g)
-                if (t < 128) vw[t] = vpp ? mv[t] + mv[128 + t] : 0.0;
-                __syncthreads();
-                matvec(Yt, vw, 0);                                          // (Y^T Y) w
+                }
                 if (t < 128) vv[t] = vpp ? (vinv[t] * vw[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t]) : 0.0;
                 __syncthreads();
-                matvec(Rt, vv, 2);                                          // u = R^-T v
+                {
+                    double sacc = 0.0;
+                    if (vpp) {
+#pragma unroll 1
+                        for (int qb = 0; qb < 64; qb += 16) {
+                            double e[16], xq[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) { const int q = min(q0 + qb + u, m - 1); e[u] = Rt[tri2(pp, opp, q, off_of(q))]; xq[u] = vv[q]; }
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                const int q = q0 + qb + u, aq = age_of(min(q, m - 1));
+                                sacc += ((q < m && aq < bound && aq >= app) ? e[u] : 0.0) * xq[u];
+                            }
+                        }
+                    }
+                    mz[hq * 128 + pp] = sacc;
+                    __syncthreads();
+                }
                 if (t < 128) {
-                    stg<true>(upub + t, vpp ? -(mv[t] + mv[128 + t]) : 0.0);
+                    stg<true>(upub + t, vpp ? -(mz[t] + mz[128 + t]) : 0.0);
                     stg<true>(upub + 128 + t, vpp ? gamma * vw[t] : 0.0);
                 }
                 if (t == 128) stg<true>(upub + 256, gamma);
@@ -420,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             }
             if (lstage == 2) {                                              // after the penalty phase: adjoint, gradient, line-search scalars
                 LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
-                backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev);
+                backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl);
                 rk_drain_and_meet();
                 RK_PROF(RK_P_BACKWARD);
                 if (t == 0) {
