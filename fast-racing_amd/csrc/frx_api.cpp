@@ -983,7 +983,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         G = std::max(G, want);
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
-    if ((long)B * G > cus) return 1;                                                  // every workgroup must be resident at once (one per CU)
+    if ((long)8 * G * ((B + 7) / 8) > cus) return 1;                                  // every workgroup must be resident at once (one per CU; grid = 8 G ceil(B/8))
     const size_t lds = frx::round_lds_bytes(p->geo, m, E);
     if (lds == 0 || lds > 160 * 1024) return 1;
     const int NXP = G * 2 * E;
@@ -993,7 +993,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
         if ((e = p->d_pubsyg.alloc((size_t)B * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)B * G * 512)) != hipSuccess ||
             (e = p->d_upub.alloc((size_t)B * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)B * NXP)) != hipSuccess ||
-            (e = p->d_rwords.alloc((size_t)4 * B + 2)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)2 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
+            (e = p->d_rwords.alloc((size_t)4 * B + 2 + (size_t)B * G)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)2 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
@@ -1010,7 +1010,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     p->rprof.clear();
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
-    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)4 * B + 2), p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)4 * B + 2 + (size_t)B * G), p->stream));
     std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 2 * B);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);

@@ -89,7 +89,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.pen_lds = g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21;
     a.x = r.x; a.g = r.g; a.xp = r.xp; a.gp = r.gp; a.d = r.d; a.f = r.f; a.T = r.T; a.C = r.C; a.out20 = r.out20; a.pcrw = g.pcrw;
     a.pubsyg = r.pubsyg; a.part = r.part; a.upub = r.upub; a.dpub = r.dpub; a.dbg = r.dbg;
-    a.phase = r.words; a.cntA = r.words + r.B; a.uflag = r.words + 2 * r.B; a.cntL = r.words + 3 * r.B; a.census = r.words + 4 * r.B; a.status = r.words + 4 * r.B + 1;
+    a.phase = r.words; a.cntA = r.words + r.B; a.uflag = r.words + 2 * r.B; a.cntL = r.words + 3 * r.B; a.census = r.words + 4 * r.B; a.status = r.words + 4 * r.B + 1; a.xcc = r.words + 4 * r.B + 2;
     a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
     a.timeout_ticks = r.timeout_ticks;
     a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g);
@@ -98,8 +98,8 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     const void *fn = r.prof ? (const void *)k_round<ROUND_E, true> : (const void *)k_round<ROUND_E, false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(r.B * r.G), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(r.B * r.G), dim3(256), lds, (hipStream_t)stream, a);
+    if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(8 * r.G * ((r.B + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(8 * r.G * ((r.B + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

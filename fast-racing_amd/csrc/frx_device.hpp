@@ -81,7 +81,7 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 struct RoundLaunch {
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20;              // leader vectors and stage buffers (the handle's own)
     double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([B][3 NXP + 2], [B][G][512], [B][258], [B][NXP])
-    unsigned *words;                                               // [4 B + 2]: phase, cntA, uflag, cntL per candidate, then census, status
+    unsigned *words;                                               // [4 B + 2 + B G]: phase, cntA, uflag, cntL per candidate, then census, status, XCC ids
     void *h_cmd, *h_res;                                           // mapped host mailboxes, [B] x 16 B and [B] x 64 B
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)

@@ -46,8 +46,11 @@ template <bool SH> __device__ __forceinline__ double ldg(const double *p) {
     if (SH) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return *p;
 }
-template <bool SH> __device__ __forceinline__ void stg(double *p, double v) {
-    if (SH) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// `wt` (run-time, SH only): false when the launch has VERIFIED (XCC_ID census of the cluster, frx_round_kernel.hpp) that producer and
+// consumers sit on one XCD - then the shared L2 is the coherence point and a plain store (L1 is write-through) that the consumer reads
+// with an L1-bypassing load is enough; measured 30-40 % off every hand-off (profiles/r02_cluster_probe.txt).
+template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool wt = true) {
+    if (SH && wt) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
 
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__r
 // has to call it (it contains workgroup barriers), idle ones with npieces = 0.
 template <bool SH>
 __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double *__restrict__ T, const double *__restrict__ C,
-                                             double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane) {
+                                             double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, bool wt = true) {
     const int hstride = (Kmax + 1) * 4;
     double *cS = sm;
     double *tS = cS + ppw * 18;
@@ -278,7 +281,7 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
         const int p2 = idx / 20, v = idx - p2 * 20;
         double s = 0.0;
         for (int l = 0; l < lpp; l++) s += red[(p2 * lpp + l) * 21 + v];
-        stg<SH>(out20 + (size_t)gp0 * 20 + idx, s);
+        stg<SH>(out20 + (size_t)gp0 * 20 + idx, s, wt);
     }
 }
 __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
@@ -717,7 +720,7 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
 // SH: T and C are consumed by OTHER workgroups of the same launch (see ldg / stg above).
 template <bool SH>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr) {
+                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true) {
     // ct_lds (optional, LDS, 19 doubles per piece: 18 coefficients + duration): a copy for the backward pass of the same workgroup
     const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
@@ -779,7 +782,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     if (k < N) {
         hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
-        stg<SH>(Tout + p0 + k, hMine);
+        stg<SH>(Tout + p0 + k, hMine, wt);
         if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
     FRX_STAMP(2);
@@ -872,7 +875,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             double c[6];
             hermite_coeffs(hMine, KN(KP, ax, k), KN(KV, ax, k), KN(KA, ax, k), KN(KP, ax, k + 1), KN(KV, ax, k + 1), KN(KA, ax, k + 1), c);
 #pragma unroll
-            for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, c[q]); if (ct_lds) ct_lds[k * 19 + q * 3 + ax] = c[q]; }
+            for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, c[q], wt); if (ct_lds) ct_lds[k * 19 + q * 3 + ax] = c[q]; }
         }
     }
     FRX_STAMP(6);

@@ -84,6 +84,7 @@ struct RoundArgs {
     double *dpub;            // [B][NXP]      cluster -> leader: direction chunks
     unsigned *phase, *cntA, *uflag, *cntL;   // [B] each (zeroed before every launch)
     unsigned *census, *status;               // [1] each (zeroed before every launch)
+    unsigned *xcc;                           // [B][G] XCC id + 1 of every workgroup (zeroed before every launch)
     RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
     int B, G, m, NXP, eval_doubles, ct_doubles;                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
@@ -122,7 +123,14 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     constexpr int CHT = 2 * E;
     rk_u64 prof_last = 0;
 #define RK_PROF(seg) do { if (PROF && threadIdx.x == 0) { const rk_u64 now_ = wall_clock64(); ((rk_u64 *)(sm + L.ctl + 16))[seg] += now_ - prof_last; prof_last = now_; } } while (0)
-    const int c = blockIdx.x / a.G, wg = blockIdx.x - c * a.G, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // Workgroup -> (candidate, role).  Blocks b with equal b % 8 have been observed to share an XCD (MI355X guide; HIP promises
+    // nothing), so cluster c takes the blocks (c % 8) + 8 (wg + G (c / 8)): if the observation holds, a cluster's hand-offs stay
+    // inside one XCD's L2.  Nothing relies on it: every workgroup publishes its XCC_ID, and only a cluster that finds all of
+    // its members on one XCD switches its payload stores from write-through to plain (`wt` below).
+    const int lane8 = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int wg = rest % a.G, c = lane8 + 8 * (rest / a.G);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (c >= a.B) return;                                                 // grid is 8 G ceil(B / 8) blocks
     const bool leader = wg == 0, dense = wg == a.G - 1;
     const int m = a.m;
     const RoundLds L = round_lds(m, CHT, a.eval_doubles);
@@ -134,15 +142,24 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     double *x = a.x + xbase, *g = a.g + xbase, *xp = a.xp + xbase, *gp = a.gp + xbase, *dv = a.d + xbase;
     double *pub = a.pubsyg + (size_t)c * (3 * a.NXP + 2), *part = a.part + (size_t)c * a.G * 512, *upub = a.upub + (size_t)c * 258, *dpub = a.dpub + (size_t)c * a.NXP;
 
-    // ---- census: every workgroup of the grid must be resident before anybody waits for anybody ----
+    // ---- census: every workgroup of the launch must be resident before anybody waits for anybody ----
     if (t == 0) {
+        unsigned my_xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        my_xcc = (my_xcc & 15u) + 1u;
+        __hip_atomic_store(a.xcc + c * a.G + wg, my_xcc, FRX_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(a.census, 1u, FRX_RLX_AGENT);
-        const bool ok = rk_wait_eq(a.census, gridDim.x, a);
+        const bool ok = rk_wait_eq(a.census, (unsigned)(a.B * a.G), a);
         if (!ok) rk_fail(a, RK_ERR_CENSUS);
+        bool same = ok;
+        for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + c * a.G + k, FRX_RLX_AGENT) == my_xcc;
         ctlU[0] = ok ? 1u : 0u;
+        ctlU[3] = same ? 1u : 0u;
     }
     __syncthreads();
     if (ctlU[0] == 0u) return;
+    const bool wt = ctlU[3] == 0u;                                        // write-through payload stores unless the cluster shares an XCD
     __syncthreads();
 
     if (PROF) { if (t < 16) ((rk_u64 *)(sm + L.ctl + 16))[t] = 0; __syncthreads(); prof_last = wall_clock64(); }
@@ -197,9 +214,9 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                     for (int i = t; i < a.NXP; i += 256) {
                         double s = 0.0, y = 0.0, gv = 0.0;
                         if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
-                        stg<true>(pub + i, s); stg<true>(pub + a.NXP + i, y); stg<true>(pub + 2 * a.NXP + i, gv);
+                        stg<true>(pub + i, s, wt); stg<true>(pub + a.NXP + i, y, wt); stg<true>(pub + 2 * a.NXP + i, gv, wt);
                     }
-                    if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew); stg<true>(pub + 3 * a.NXP + 1, (double)bound); }   // the step's slot and pair count ride along
+                    if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
                     kind = PH_ADV; lstage = 1;
                 } else {
                     if (flags & DV_INIT) {                                  // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 if (flags & DV_EVAL) {
                     __syncthreads();                                        // (vmcnt(0) + barrier: x is complete and visible to this CU)
                     RK_PROF(RK_P_VECTORS);
-                    forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl);
+                    forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt);
                     kind = PH_CT; lstage = 2;
                     RK_PROF(RK_P_FORWARD);
                 } else {
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 for (int q = 0; q < 4; q++) pair[(half * 4 + q) * 128 + slot] = acc[q];
             }
             __syncthreads();
-            for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)wg * 512 + o, pair[o] + pair[512 + o]);
+            for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)wg * 512 + o, pair[o] + pair[512 + o], wt);
             rk_drain_and_meet();
             if (t == 0) __hip_atomic_fetch_add(a.cntA + c, 1u, FRX_RLX_AGENT);
             RK_PROF(RK_P_PASS_A);
@@ -394,10 +411,10 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                     __syncthreads();
                 }
                 if (t < 128) {
-                    stg<true>(upub + t, vpp ? -(mz[t] + mz[128 + t]) : 0.0);
-                    stg<true>(upub + 128 + t, vpp ? gamma * vw[t] : 0.0);
+                    stg<true>(upub + t, vpp ? -(mz[t] + mz[128 + t]) : 0.0, wt);
+                    stg<true>(upub + 128 + t, vpp ? gamma * vw[t] : 0.0, wt);
                 }
-                if (t == 128) stg<true>(upub + 256, gamma);
+                if (t == 128) stg<true>(upub + 256, gamma, wt);
                 rk_drain_and_meet();
                 if (t == 0) __hip_atomic_store(a.uflag + c, nadv, FRX_RLX_AGENT);
                 RK_PROF(RK_P_SOLVE);
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 for (int i = t; i < CHT; i += 256) {
                     const int hh = i / E, e = i - hh * E;
                     const double di = (wsum[(2 * hh) * E + e] + wsum[(2 * hh + 1) * E + e]) - gamma * gC[i];
-                    stg<true>(dpub + wg * CHT + i, di);
+                    stg<true>(dpub + wg * CHT + i, di, wt);
                 }
             }
             RK_PROF(RK_P_PASS_B);
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             for (int base = 0; base < ntasks; base += per_pass) {
                 const int task = base + wg * 4 + wave;
                 const int np = task < ntasks ? min(a.ppw, N - task * a.ppw) : 0;
-                penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, np, ev + (size_t)wave * a.pen_lds, lane);
+                penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, np, ev + (size_t)wave * a.pen_lds, lane, wt);
                 __syncthreads();
             }
             RK_PROF(RK_P_PENALTY);
