@@ -290,7 +290,8 @@ class Problem:
             return None
         out = np.zeros(n, dtype=np.uint64)
         lib().frx_resident_profile(self.h, out.ctypes.data, n)
-        return out.reshape(self.B, -1, 16).astype(np.float64) / 100.0
+        self.last_stamps = out[-32:].astype(np.int64)                  # shader-clock stamps of candidate 0's forward (0..6) / adjoint (16..24) bodies
+        return out[:-32].reshape(self.B, -1, 16).astype(np.float64) / 100.0
 
     def initial_guess(self):
         x = np.zeros(self.NX)

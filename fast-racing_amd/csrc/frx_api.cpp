@@ -192,6 +192,7 @@ struct frx_problem {
     PinBuf<unsigned long long> h_rcmd, h_rres;              // [B] x 2 words, [B] x 8 words
     int rk_B = 0, rk_G = 0, rk_NXP = 0;
     int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident)
+    int resident_retried = 0;                               // candidates of the last plan re-run on the per-stage rounds after an L-BFGS error
     int resident_used = 0;                                  // diagnostics: 1 = the last frx_optimize ran on the resident kernel
     unsigned resident_status = 0;                           // device-side error code of the last resident launch (RK_ERR_*)
     std::vector<double> trace;                              // FRX_TRACE: per command of candidate 0 {flags, step, f, dg, dginit, xx, gg}
@@ -821,8 +822,10 @@ static int finish_optimize(frx_problem *p, const double *x, double *C, double *T
 // vector.  A round = k_lbfgs_pre (history update + two-loop recursion for candidates that just accepted a step, then the
 // trial point) -> k_forward -> k_penalty -> k_backward -> k_lbfgs_post; 32 B of commands go down and 40 B of results
 // come back per candidate, through mapped host memory.
+// `only` (optional, [B]): candidates with only[b] == 0 take no part - their x, status, counters and objective are left untouched
+// (used to re-run, on this path, candidates that failed on the resident kernel).
 static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals,
-                                   double *objective) {
+                                   double *objective, const std::vector<char> *only = nullptr) {
     const int B = p->B, m = pm.mem_size;
     // k_lbfgs_pre geometry (frx::dv_geometry).  FRX_DV_GEOM=E,W,PF,BLK overrides (experiments).
     int E = 0, W = 0, PF = 0, BLK = 4;
@@ -862,7 +865,10 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     HIP_TRY(hipMemsetAsync(p->d_ys.p, 0, sizeof(double) * (size_t)B * m, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_gt.p, 0, sizeof(double) * (size_t)B * m * 4, p->stream));
     std::vector<frx::SolverDV> sv(B);
-    for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, p->h_cmd.p + b);
+    for (int b = 0; b < B; b++) {
+        sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, p->h_cmd.p + b);
+        if (only && !(*only)[b]) sv[b].give_up(0);                              // not part of this run
+    }
     // every wait is bounded ("status codes, bounded waits"): FRX_ROUND_TIMEOUT_MS, default 5 s per round
     const double round_timeout_ms = [] { const char *e = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 5000.0; }();
     auto wait_stream = [&]() -> int {
@@ -954,8 +960,9 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     p->stats[0] = ms_since(t0); p->stats[1] = t_dev; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpyAsync(p->h_x.p, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    std::memcpy(x, p->h_x.p, sizeof(double) * p->NX);
     for (int b = 0; b < B; b++) {
+        if (only && !(*only)[b]) continue;
+        std::memcpy(x + p->xoff[b], p->h_x.p + p->xoff[b], sizeof(double) * (p->xoff[b + 1] - p->xoff[b]));
         status[b] = sv[b].status();
         if (iters) iters[b] = sv[b].iterations();
         if (evals) evals[b] = sv[b].evaluations();
@@ -973,20 +980,26 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     const int B = p->B, m = pm.mem_size, E = frx::ROUND_E;
     p->resident_used = 0; p->resident_status = 0;
     if (p->geo.solver != frx::SOLVER_KNOT_PCR || m < 1 || m > 128) return 1;
+    // The compact representation inverts R = S^T Y (triangular part); with fewer variables than twice the history length the pairs
+    // become linearly dependent and R^-1 loses its digits (n = 1: entries grow like 2^k), where the two-loop recursion of
+    // k_lbfgs_pre stays stable.  Such problems (a few pieces) are latency-trivial anyway and take the per-stage rounds.
+    for (int b = 0; b < B; b++)
+        if (p->xoff[b + 1] - p->xoff[b] < 2 * m) return 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
-    int G = std::max(2, (p->geo.maxXb + 2 * E - 1) / (2 * E));                       // history: 2 E elements of every pair per workgroup
+    int G = 1 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each)
     {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them
         const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
         const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(B, 1)});
         G = std::max(G, want);
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
+    G = std::max(G, 2);
     if ((long)8 * G * ((B + 7) / 8) > cus) return 1;                                  // every workgroup must be resident at once (one per CU; grid = 8 G ceil(B/8))
     const size_t lds = frx::round_lds_bytes(p->geo, m, E);
     if (lds == 0 || lds > 160 * 1024) return 1;
-    const int NXP = G * 2 * E;
+    const int NXP = (G - 1) * 2 * E;
     hipError_t e = hipSuccess;
     if (p->rk_B != B || p->rk_G != G || p->rk_NXP != NXP) {
         p->rk_B = 0;
@@ -1022,6 +1035,12 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
+    struct StampGuard { frx_problem *q; ~StampGuard() { q->dp.stamps = nullptr; } } stamp_guard{p};
+    if (want_prof) {                                                                  // phase stamps of candidate 0's forward / adjoint bodies (last evaluation)
+        if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(32));
+        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, 32 * sizeof(long long), p->stream));
+        p->dp.stamps = p->d_stamps.p;
+    }
 
     std::vector<frx::SolverDV> sv(B);
     std::vector<frx::DvCommand> cmd(B);
@@ -1048,7 +1067,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     // Mailbox service: candidate b belongs to service thread b % nsrv (the caller is thread 0).  One thread keeps up with ~8 clusters
     // (a result every ~10 us); at the headline batch the device measured 8.6 us between posting a result and seeing the next command
     // with a single thread, 3.2 us when the thread serves one candidate.
-    int nsrv = B >= 16 ? std::min(4, B / 8) : 1;
+    int nsrv = B >= 32 ? 2 : 1;                                                       // (more threads measured no better: 1 / 4 / 8 / 32 threads -> 60.5 / 60.9 / 63.7 / 67.7 us per round)
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), B));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     std::vector<double> t_host_thr(nsrv, 0.0);
@@ -1113,7 +1132,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     for (int b = 0; b < B; b++) rounds = std::max(rounds, ncmd[b]);
     p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
-    if (want_prof) { p->rprof.resize((size_t)B * G * 16); HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * p->rprof.size(), hipMemcpyDeviceToHost)); }
+    if (want_prof) {
+        p->rprof.resize((size_t)B * G * 16 + 32);                                      // the last 32 words: the bodies' cycle stamps
+        HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)B * G * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)B * G * 16, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
     for (int b = 0; b < B; b++) {
         status[b] = sv[b].status();
         if (iters) iters[b] = sv[b].iterations();
@@ -1163,10 +1186,28 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
         // FRX_RESIDENT=0 keeps the one-launch-per-stage rounds; the default is the resident round kernel whenever the batch fits the
         // chip (one workgroup per CU, B x G of them), with the per-stage path as fallback when it does not or when the device gives up
         const char *rs_env = std::getenv("FRX_RESIDENT");
-        p->resident_used = 0;
+        p->resident_used = 0; p->resident_retried = 0;
         if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0) {
+            const std::vector<double> x_start(x, x + p->NX);
             rc_dv = optimize_resident(p, *params, x, status, iters, evals, objective);
             if (rc_dv < 0) return rc_dv;
+            if (rc_dv != 0) std::copy(x_start.begin(), x_start.end(), x);
+            else {
+                // Safety net: a candidate that ends with an L-BFGS error on the resident kernel is run again, from the same start, on
+                // the per-stage rounds (two-loop recursion): a genuine failure (an infeasible corridor ends in LBFGSERR_MINIMUMSTEP on
+                // the CPU reference as well) fails again, a direction spoilt by an ill-conditioned R does not.
+                std::vector<char> again(p->B, 0);
+                int n_again = 0;
+                for (int b = 0; b < p->B; b++) if (status[b] < 0) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
+                if (n_again) {
+                    const int used = p->resident_used;
+                    const double t_res = p->stats[0];
+                    const int rc2 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);
+                    if (rc2 < 0) return rc2;
+                    p->resident_used = used; p->resident_retried = n_again;
+                    p->stats[0] += t_res;
+                }
+            }
         }
         if (rc_dv != 0) {
             rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective);

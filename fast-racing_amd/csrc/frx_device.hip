@@ -92,6 +92,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.phase = r.words; a.cntA = r.words + r.B; a.uflag = r.words + 2 * r.B; a.cntL = r.words + 3 * r.B; a.census = r.words + 4 * r.B; a.status = r.words + 4 * r.B + 1; a.xcc = r.words + 4 * r.B + 2;
     a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
     a.timeout_ticks = r.timeout_ticks;
+    a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms
     a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g);
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;

@@ -54,6 +54,20 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
     else *p = v;
 }
 
+// Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
+// `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
+// `#pragma unroll 8` (one full memory latency per element and thread: 9.4k of the adjoint's 30k cycles, measured); clamped,
+// unconditional loads into a register block let the scheduler issue the whole trip at once.
+template <int U> __device__ __forceinline__ void stage_to_lds(double *dst, const double *__restrict__ src, int n, int k, int nthr) {
+    for (int i0 = k; i0 < n; i0 += U * nthr) {
+        double tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nthr; tmp[u] = src[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nthr; if (i < n) dst[i] = tmp[u]; }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     // butterfly: every lane ends with the same, order-fixed sum of the 64 lane values
 #pragma unroll
@@ -752,10 +766,8 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         const int nx = dp.xoff[b + 1] - x0;
         const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
         const double *vsrc = dp.vrec + 3 * (size_t)v0;
-#pragma unroll 8
-        for (int i = k; i < nx; i += nthr) xs[i] = x[x0 + i];
-#pragma unroll 8
-        for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
+        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
+        stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
     }
     __syncthreads();
     FRX_STAMP(1);
@@ -938,23 +950,25 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         const int nx = dp.xoff[b + 1] - x0;
         const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
         const double *vsrc = dp.vrec + 3 * (size_t)v0;
-#pragma unroll 8
-        for (int i = k; i < nx; i += nthr) xs[i] = x[x0 + i];
-#pragma unroll 8
-        for (int i = k; i < nvd; i += nthr) vs[i] = vsrc[i];
-        if (tapped) {
-#pragma unroll 8
-            for (int i = k; i < nx; i += nthr) dsv[i] = tap.d[x0 + i];
-        }
+        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
+        stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
+        if (tapped) stage_to_lds<4>(dsv, tap.d + x0, nx, k, nthr);
     }
     {   // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
         const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
         const double2 *src = (const double2 *)(pcrw + (size_t)p0 * ws);
-#pragma unroll 8
-        for (int i2 = k; i2 < n2; i2 += nthr) {
-            const double2 v = src[i2];
-            const int e = 2 * i2, kn = e / ws, ff = e - kn * ws;            // ws even: both halves belong to the same knot
-            pw[kn * (ws + 1) + ff] = v.x; pw[kn * (ws + 1) + ff + 1] = v.y;
+        for (int i0 = k; i0 < n2; i0 += 8 * nthr) {                          // same batching as stage_to_lds, 16-byte loads
+            double2 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i2 = i0 + u * nthr; tmp[u] = src[i2 < n2 ? i2 : n2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i2 = i0 + u * nthr;
+                if (i2 < n2) {
+                    const int e = 2 * i2, kn = e / ws, ff = e - kn * ws;        // ws even: both halves belong to the same knot
+                    pw[kn * (ws + 1) + ff] = tmp[u].x; pw[kn * (ws + 1) + ff + 1] = tmp[u].y;
+                }
+            }
         }
     }
 

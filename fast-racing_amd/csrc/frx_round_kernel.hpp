@@ -8,13 +8,15 @@
 //
 // Geometry: a CLUSTER of G workgroups (256 threads, one per CU) per candidate, grid = B x G <= number of CUs.
 //   workgroup 0      LEADER: owns x, g, xp, gp, d (global memory, touched by this CU only), talks to the host, runs the MINCO
-//                    forward map and the adjoint (forward_knot_body / backward_knot_body of frx_kernels.hpp, unchanged arithmetic)
-//   workgroup G-1    DENSE: keeps the m x m factors of the compact L-BFGS representation resident in LDS
-//   workgroups 0..G-2 evaluate the penalty integrand of their share of the pieces (penalty_body)
-//   every workgroup  keeps 1/G of the candidate's (s, y) HISTORY RESIDENT IN REGISTERS: thread (slot j, half h) holds the elements
+//                    forward map and the adjoint (forward_knot_body / backward_knot_body of frx_kernels.hpp, unchanged arithmetic).
+//                    It carries no history: its loop is a separate branch of the kernel, so the evaluation bodies get the whole
+//                    register file (with the history live across them the compiler spilled 93 VGPRs into the adjoint).
+//   workgroups 1..G-1 keep 1/(G-1) of the candidate's (s, y) HISTORY RESIDENT IN REGISTERS: thread (slot j, half h) holds the elements
 //                    [h E, (h+1) E) of its workgroup's chunk of s_j and y_j - 2 E doubles; the whole 46 MB history of the headline
 //                    batch lives in the register files of the chip and is never re-read from HBM (k_lbfgs_pre streams it twice
 //                    per accepted step: 55 us of a 101 us round at the headline batch).
+//   workgroup G-1    also DENSE: keeps the m x m factors of the compact L-BFGS representation resident in LDS
+//   workgroups 0..G-2 evaluate the penalty integrand of their share of the pieces (penalty_body)
 //
 // Direction: with the history distributed by ELEMENTS, the two-loop recursion (2 m strictly sequential dot products of length n,
 // lbfgs.hpp:1381-1411) would need 2 m cross-CU reductions.  The same product  d = -H g  is evaluated in the compact form of
@@ -87,7 +89,8 @@ struct RoundArgs {
     unsigned *xcc;                           // [B][G] XCC id + 1 of every workgroup (zeroed before every launch)
     RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
-    int B, G, m, NXP, eval_doubles, ct_doubles;                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
+    rk_u64 census_ticks;                     // bound of the start-up census (all workgroups resident)
+    int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 1) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
 };
@@ -117,172 +120,214 @@ __device__ __forceinline__ void rk_drain_and_meet() {
     __syncthreads();
 }
 
-template <int E, bool PROF>
-__global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    constexpr int CHT = 2 * E;
-    rk_u64 prof_last = 0;
+
+// ---- pieces shared by the two role loops ----
+struct RoundView {                       // per-workgroup constants
+    int c, wg, t, lane, wave, m, n, xbase, p0, N;
+    bool wt;
+    double *pub, *part, *upub, *dpub;
+};
 #define RK_PROF(seg) do { if (PROF && threadIdx.x == 0) { const rk_u64 now_ = wall_clock64(); ((rk_u64 *)(sm + L.ctl + 16))[seg] += now_ - prof_last; prof_last = now_; } } while (0)
-    // Workgroup -> (candidate, role).  Blocks b with equal b % 8 have been observed to share an XCD (MI355X guide; HIP promises
-    // nothing), so cluster c takes the blocks (c % 8) + 8 (wg + G (c / 8)): if the observation holds, a cluster's hand-offs stay
-    // inside one XCD's L2.  Nothing relies on it: every workgroup publishes its XCC_ID, and only a cluster that finds all of
-    // its members on one XCD switches its payload stores from write-through to plain (`wt` below).
-    const int lane8 = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int wg = rest % a.G, c = lane8 + 8 * (rest / a.G);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (c >= a.B) return;                                                 // grid is 8 G ceil(B / 8) blocks
-    const bool leader = wg == 0, dense = wg == a.G - 1;
-    const int m = a.m;
-    const RoundLds L = round_lds(m, CHT, a.eval_doubles);
-    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word, [3] spare
-    double *ctlD = sm + L.ctl + 8;                                        // [0..3] f, g.d, x.x, g.g; [4] dginit; [5] step
-    double *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
-    const int slot = t & 127, half = t >> 7;
-    const int xbase = a.dp.xoff[c], n = a.dp.xoff[c + 1] - xbase;
-    double *x = a.x + xbase, *g = a.g + xbase, *xp = a.xp + xbase, *gp = a.gp + xbase, *dv = a.d + xbase;
-    double *pub = a.pubsyg + (size_t)c * (3 * a.NXP + 2), *part = a.part + (size_t)c * a.G * 512, *upub = a.upub + (size_t)c * 258, *dpub = a.dpub + (size_t)c * a.NXP;
 
-    // ---- census: every workgroup of the launch must be resident before anybody waits for anybody ----
-    if (t == 0) {
-        unsigned my_xcc = 0;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
-        my_xcc = (my_xcc & 15u) + 1u;
-        __hip_atomic_store(a.xcc + c * a.G + wg, my_xcc, FRX_RLX_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(a.census, 1u, FRX_RLX_AGENT);
-        const bool ok = rk_wait_eq(a.census, (unsigned)(a.B * a.G), a);
-        if (!ok) rk_fail(a, RK_ERR_CENSUS);
-        bool same = ok;
-        for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + c * a.G + k, FRX_RLX_AGENT) == my_xcc;
-        ctlU[0] = ok ? 1u : 0u;
-        ctlU[3] = same ? 1u : 0u;
+// penalty share of workgroup `pw` (0..G-2) in a CT phase
+template <bool PROF>
+__device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const RoundView &v, double *ev, int pw) {
+    const int npw = a.G - 1, ntasks = (v.N + a.ppw - 1) / a.ppw, per_pass = npw * 4;
+    for (int base = 0; base < ntasks; base += per_pass) {
+        const int task = base + pw * 4 + v.wave;
+        const int np = task < ntasks ? min(a.ppw, v.N - task * a.ppw) : 0;
+        penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, v.p0 + task * a.ppw, np, ev + (size_t)v.wave * a.pen_lds, v.lane, v.wt);
+        __syncthreads();
     }
-    __syncthreads();
-    if (ctlU[0] == 0u) return;
-    const bool wt = ctlU[3] == 0u;                                        // write-through payload stores unless the cluster shares an XCD
-    __syncthreads();
+}
 
-    if (PROF) { if (t < 16) ((rk_u64 *)(sm + L.ctl + 16))[t] = 0; __syncthreads(); prof_last = wall_clock64(); }
-    // history registers: (s_slot, y_slot) restricted to this thread's elements; dense-state bookkeeping
+// ============================================================================================================================
+// LEADER (workgroup 0 of a cluster)
+// ============================================================================================================================
+template <bool PROF>
+__device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
+    const int c = v.c, t = v.t, lane = v.lane, wave = v.wave, n = v.n;
+    const bool wt = v.wt;
+    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
+    double *ctlD = sm + L.ctl + 8, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
+    double *x = a.x + v.xbase, *g = a.g + v.xbase, *xp = a.xp + v.xbase, *gp = a.gp + v.xbase, *dv = a.d + v.xbase;
+    double *pub = v.pub, *dpub = v.dpub;
+    rk_u64 prof_last = PROF ? wall_clock64() : 0;
+    unsigned pseq = 0, nphase = 0;
+    rk_u64 hseq = 0;
+    int lstage = 0, flags = 0, jnew = 0, bound = 0;
+    double step = 0.0;
+    for (;;) {
+        int kind = 0;
+        if (lstage == 0) {
+            if (t == 0) {
+                const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+                rk_u64 w = 0;
+                bool ok = true;
+                for (unsigned spins = 0;; spins++) {
+                    w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
+                    if ((w >> 32) == hseq + 1) break;
+                    if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
+                }
+                if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
+                ctlU[1] = (unsigned)w;
+                if (ok) ctlD[5] = __longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS));
+            }
+            __syncthreads();
+            RK_PROF(RK_P_WAIT_HOST);
+            const unsigned w = ctlU[1];
+            flags = (int)(w & 0xFFu); jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
+            step = ctlD[5];
+            hseq++;
+            __syncthreads();
+            if (flags & DV_QUIT) kind = PH_QUIT;
+            else if (flags & DV_RESTORE) {                                  // lbfgs.hpp:1287-1288; no evaluation follows
+                for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }
+                rk_drain_and_meet();
+                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
+                continue;
+            } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
+                for (int i = t; i < a.NXP; i += 256) {
+                    double s = 0.0, y = 0.0, gv = 0.0;
+                    if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
+                    stg<true>(pub + i, s, wt); stg<true>(pub + a.NXP + i, y, wt); stg<true>(pub + 2 * a.NXP + i, gv, wt);
+                }
+                if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
+                kind = PH_ADV; lstage = 1;
+            } else {
+                if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
+                    for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
+                }
+                lstage = 1;
+            }
+        }
+        if (lstage == 1 && kind == 0) {
+            if (flags & DV_TRIAL) {                                         // x = xp + step * d (lbfgs.hpp:825-826)
+                __syncthreads();
+                for (int i = t; i < n; i += 256) x[i] = xp[i] + step * dv[i];
+            }
+            if (flags & DV_EVAL) {
+                __syncthreads();                                            // (vmcnt(0) + barrier: x is complete and visible to this CU)
+                RK_PROF(RK_P_VECTORS);
+                forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt);
+                kind = PH_CT; lstage = 2;
+                RK_PROF(RK_P_FORWARD);
+            } else {
+                rk_drain_and_meet();
+                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
+                lstage = 0;
+                continue;
+            }
+        }
+        rk_drain_and_meet();                                                // everything published so far has left this CU
+        pseq++;
+        if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+        RK_PROF(RK_P_PUBLISH);
+        if (kind == PH_QUIT) break;
+        if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
+        // ---- the phase is complete when every workgroup of the cluster has reported ----
+        rk_drain_and_meet();
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
+        nphase++;
+        if (t == 0) { const bool ok = rk_wait_eq(a.cntL + c, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
+        __syncthreads();
+        const bool ok = ctlU[0] != 0u;
+        __syncthreads();
+        RK_PROF(RK_P_WAIT_ARRIVE);
+        if (!ok) {                                                          // tell the host and the cluster, then leave
+            pseq++;
+            if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
+            break;
+        }
+        if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
+            double acc = 0.0;
+            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
+            const double ws = wave_sum_dpp(acc);
+            if (lane == 0) pair[wave] = ws;
+            __syncthreads();
+            if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]);
+            __syncthreads();
+            RK_PROF(RK_P_GATHER);
+        }
+        if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
+            LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
+            backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl);
+            rk_drain_and_meet();
+            RK_PROF(RK_P_BACKWARD);
+            if (t == 0) {
+                RoundRes *r = a.h_res + c;
+                __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
+            }
+            lstage = 0;
+            __syncthreads();
+            RK_PROF(RK_P_POST);
+        }
+    }
+    if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+}
+
+// ============================================================================================================================
+// MEMBERS (workgroups 1..G-1): history in registers, penalty share; the last one is also the dense workgroup
+// ============================================================================================================================
+template <int E, bool PROF>
+__device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
+    constexpr int CHT = 2 * E;
+    const int c = v.c, wg = v.wg, t = v.t, lane = v.lane, wave = v.wave, m = v.m;
+    const bool wt = v.wt, dense = wg == a.G - 1;
+    const int hg = wg - 1, nh = a.G - 1;                                    // history chunk of this workgroup, number of history workgroups
+    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
+    double *ctlD = sm + L.ctl + 8, *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *ev = sm + L.role + a.ct_doubles;
+    double *pub = v.pub, *part = v.part, *upub = v.upub, *dpub = v.dpub;
+    const int slot = t & 127, half = t >> 7;
+    rk_u64 prof_last = PROF ? wall_clock64() : 0;
     double Sreg[E], Yreg[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
-    if (dense) {                                                           // R^-1, Y^T Y, D start as zeros: no uninitialised word is ever multiplied
+    if (dense) {                                                            // R^-1, Y^T Y, D start as zeros: no uninitialised word is ever multiplied
         for (int i = L.Rt + t; i < L.va; i += 256) sm[i] = 0.0;
         __syncthreads();
     }
-    unsigned pseq = 0, nphase = 0, nadv = 0;                              // phases published / completed, accepted steps so far
-    rk_u64 hseq = 0;                                                       // host commands consumed (leader)
-    int lstage = 0, flags = 0, jnew = 0, bound = 0;
-    double step = 0.0;
-    const int p0 = a.dp.poff[c], N = a.dp.poff[c + 1] - p0;
-
+    unsigned pseq = 0, nadv = 0;
+    int jnew = 0, bound = 0;
     for (;;) {
-        int kind = 0;
-        // =====================================================================================================
-        // LEADER: next command / next stage of the current command; decides which phase (if any) the cluster runs
-        // =====================================================================================================
-        if (leader) {
-            if (lstage == 0) {
-                if (t == 0) {
-                    const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                    rk_u64 w = 0;
-                    bool ok = true;
-                    for (unsigned spins = 0;; spins++) {
-                        w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
-                        if ((w >> 32) == hseq + 1) break;
-                        if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
-                    }
-                    if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
-                    ctlU[1] = (unsigned)w; ctlU[2] = (unsigned)(w >> 32);
-                    if (ok) ctlD[5] = __longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS));
-                }
-                __syncthreads();
-                RK_PROF(RK_P_WAIT_HOST);
-                const unsigned w = ctlU[1];
-                flags = (int)(w & 0xFFu); jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
-                step = ctlD[5];
-                hseq++;
-                __syncthreads();
-                if (flags & DV_QUIT) kind = PH_QUIT;
-                else if (flags & DV_RESTORE) {                              // lbfgs.hpp:1287-1288; no evaluation follows
-                    for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }
-                    rk_drain_and_meet();
-                    if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
-                    continue;
-                } else if (flags & DV_ADVANCE) {                            // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
-                    for (int i = t; i < a.NXP; i += 256) {
-                        double s = 0.0, y = 0.0, gv = 0.0;
-                        if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
-                        stg<true>(pub + i, s, wt); stg<true>(pub + a.NXP + i, y, wt); stg<true>(pub + 2 * a.NXP + i, gv, wt);
-                    }
-                    if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
-                    kind = PH_ADV; lstage = 1;
-                } else {
-                    if (flags & DV_INIT) {                                  // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
-                        for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
-                    }
-                    lstage = 1;
-                }
+        if (t == 0) {
+            const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+            unsigned w = 0;
+            bool ok = true;
+            for (unsigned spins = 0;; spins++) {
+                w = __hip_atomic_load(a.phase + c, FRX_RLX_AGENT);
+                if ((w >> 4) == pseq + 1) break;
+                if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (lstage == 1 && kind == 0) {
-                if (flags & DV_TRIAL) {                                     // x = xp + step * d (lbfgs.hpp:825-826)
-                    __syncthreads();
-                    for (int i = t; i < n; i += 256) x[i] = xp[i] + step * dv[i];
-                }
-                if (flags & DV_EVAL) {
-                    __syncthreads();                                        // (vmcnt(0) + barrier: x is complete and visible to this CU)
-                    RK_PROF(RK_P_VECTORS);
-                    forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt);
-                    kind = PH_CT; lstage = 2;
-                    RK_PROF(RK_P_FORWARD);
-                } else {
-                    rk_drain_and_meet();
-                    if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
-                    lstage = 0;
-                    continue;
-                }
-            }
-            rk_drain_and_meet();                                            // everything published so far has left this CU
-            pseq++;
-            if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
-            RK_PROF(RK_P_PUBLISH);
-        } else {
-            if (t == 0) {
-                const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                unsigned w = 0;
-                bool ok = true;
-                for (unsigned spins = 0;; spins++) {
-                    w = __hip_atomic_load(a.phase + c, FRX_RLX_AGENT);
-                    if ((w >> 4) == pseq + 1) break;
-                    if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
-                ctlU[0] = w & 15u;
-            }
-            __syncthreads();
-            kind = (int)ctlU[0];
-            pseq++;
-            __syncthreads();
-            RK_PROF(RK_P_WAIT_PHASE);
+            if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
+            ctlU[0] = w & 15u;
         }
+        __syncthreads();
+        const int kind = (int)ctlU[0];
+        pseq++;
+        __syncthreads();
+        RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
 
-        // =====================================================================================================
-        // PHASE ADV (every workgroup): new pair into the history, 4 m dot products, dense solve, linear combination
-        // =====================================================================================================
+        // ------------------------------------------------------------------------------------------------------------------
+        // PHASE ADV: new pair into the history, 4 m dot products, dense step, linear combination
+        // ------------------------------------------------------------------------------------------------------------------
         if (kind == PH_ADV) {
             nadv++;
             // -- 1. this workgroup's chunk of s, y, g --
-            const int e0 = wg * CHT;
+            const int e0 = hg * CHT;
             for (int i = t; i < CHT; i += 256) { sC[i] = ldg<true>(pub + e0 + i); yC[i] = ldg<true>(pub + a.NXP + e0 + i); gC[i] = ldg<true>(pub + 2 * a.NXP + e0 + i); }
-            if (!leader) {
-                if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 3 * a.NXP + 1); }
-            }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 3 * a.NXP + 1); }
             __syncthreads();
-            if (!leader) { jnew = (int)ctlU[1]; bound = (int)ctlU[2]; }
-            jnew = __builtin_amdgcn_readfirstlane(jnew); bound = __builtin_amdgcn_readfirstlane(bound);     // wave-uniform by construction
+            jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]); bound = __builtin_amdgcn_readfirstlane((int)ctlU[2]);   // wave-uniform by construction
             // -- 2. the new pair replaces slot jnew --
             if (slot == jnew) {
 #pragma unroll
@@ -304,20 +349,20 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 for (int q = 0; q < 4; q++) pair[(half * 4 + q) * 128 + slot] = acc[q];
             }
             __syncthreads();
-            for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)wg * 512 + o, pair[o] + pair[512 + o], wt);
+            for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)hg * 512 + o, pair[o] + pair[512 + o], wt);
             rk_drain_and_meet();
             if (t == 0) __hip_atomic_fetch_add(a.cntA + c, 1u, FRX_RLX_AGENT);
             RK_PROF(RK_P_PASS_A);
-            // -- 4. dense workgroup: reduce the partials, update R and Y^T Y, solve --
+            // -- 4. dense workgroup: reduce the partials, update R^-1 and Y^T Y, three mat-vecs --
             if (dense) {
                 double *Rt = sm + L.Rt, *Yt = sm + L.Yt, *vinv = sm + L.vinv, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw,
                        *vv = sm + L.vv, *mv = sm + L.mv, *mz = sm + L.mv + 256;
-                if (t == 0) { const bool ok = rk_wait_eq(a.cntA + c, (unsigned)a.G * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+                if (t == 0) { const bool ok = rk_wait_eq(a.cntA + c, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
                 __syncthreads();
                 RK_PROF(RK_P_WAIT_PART);
                 for (int o = t; o < 512; o += 256) {
                     double s = 0.0;
-                    for (int w2 = 0; w2 < a.G; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);      // fixed order: deterministic
+                    for (int w2 = 0; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);      // fixed order: deterministic
                     (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
                 }
                 __syncthreads();
@@ -440,73 +485,69 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 for (int i = t; i < CHT; i += 256) {
                     const int hh = i / E, e = i - hh * E;
                     const double di = (wsum[(2 * hh) * E + e] + wsum[(2 * hh + 1) * E + e]) - gamma * gC[i];
-                    stg<true>(dpub + wg * CHT + i, di, wt);
+                    stg<true>(dpub + hg * CHT + i, di, wt);
                 }
             }
             RK_PROF(RK_P_PASS_B);
         }
-        // =====================================================================================================
-        // PHASE CT (workgroups 0..G-2): penalty integrand of this workgroup's share of the candidate's pieces
-        // =====================================================================================================
-        if (kind == PH_CT && !dense) {
-            const int npw = a.G - 1, ntasks = (N + a.ppw - 1) / a.ppw, per_pass = npw * 4;
-            for (int base = 0; base < ntasks; base += per_pass) {
-                const int task = base + wg * 4 + wave;
-                const int np = task < ntasks ? min(a.ppw, N - task * a.ppw) : 0;
-                penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, np, ev + (size_t)wave * a.pen_lds, lane, wt);
-                __syncthreads();
-            }
-            RK_PROF(RK_P_PENALTY);
-        }
-        // ---- every workgroup reports the end of its part of the phase to the leader ----
+        if (kind == PH_CT && !dense) { rk_penalty_share<PROF>(a, v, ev, wg); RK_PROF(RK_P_PENALTY); }
+        // ---- report the end of this workgroup's part of the phase to the leader ----
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
-        nphase++;
-        if (leader) {
-            if (t == 0) { const bool ok = rk_wait_eq(a.cntL + c, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
-            __syncthreads();
-            const bool ok = ctlU[0] != 0u;
-            __syncthreads();
-            RK_PROF(RK_P_WAIT_ARRIVE);
-            if (!ok) {                                                      // tell the host and the cluster, then leave
-                pseq++;
-                if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
-                break;
-            }
-            if (kind == PH_ADV) {                                           // gather the direction; dginit = gp . d (lbfgs.hpp:756)
-                double acc = 0.0;
-                for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
-                const double ws = wave_sum_dpp(acc);
-                if (lane == 0) pair[wave] = ws;
-                __syncthreads();
-                if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]);
-                __syncthreads();
-                RK_PROF(RK_P_GATHER);
-            }
-            if (lstage == 2) {                                              // after the penalty phase: adjoint, gradient, line-search scalars
-                LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
-                backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl);
-                rk_drain_and_meet();
-                RK_PROF(RK_P_BACKWARD);
-                if (t == 0) {
-                    RoundRes *r = a.h_res + c;
-                    __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
-                    __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
-                    __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
-                    __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
-                    __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
-                }
-                lstage = 0;
-                __syncthreads();
-                RK_PROF(RK_P_POST);
-            }
-        }
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
-#undef RK_PROF
 }
+
+template <int E, bool PROF>
+__global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int CHT = 2 * E;
+    // Workgroup -> (candidate, role).  Blocks b with equal b % 8 have been observed to share an XCD (MI355X guide; HIP promises
+    // nothing), so cluster c takes the blocks (c % 8) + 8 (wg + G (c / 8)): if the observation holds, a cluster's hand-offs stay
+    // inside one XCD's L2.  Nothing relies on it: every workgroup publishes its XCC_ID, and only a cluster that finds all of
+    // its members on one XCD switches its payload stores from write-through to plain (`wt`).
+    const int lane8 = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    RoundView v;
+    v.wg = rest % a.G; v.c = lane8 + 8 * (rest / a.G);
+    v.t = threadIdx.x; v.lane = v.t & 63; v.wave = v.t >> 6;
+    if (v.c >= a.B) return;                                               // grid is 8 G ceil(B / 8) blocks
+    v.m = a.m;
+    const RoundLds L = round_lds(a.m, CHT, a.eval_doubles);
+    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
+    v.xbase = a.dp.xoff[v.c]; v.n = a.dp.xoff[v.c + 1] - v.xbase;
+    v.p0 = a.dp.poff[v.c]; v.N = a.dp.poff[v.c + 1] - v.p0;
+    v.pub = a.pubsyg + (size_t)v.c * (3 * a.NXP + 2); v.part = a.part + (size_t)v.c * a.G * 512; v.upub = a.upub + (size_t)v.c * 258; v.dpub = a.dpub + (size_t)v.c * a.NXP;
+    // ---- census: every workgroup of the launch must be resident before anybody waits for anybody ----
+    if (v.t == 0) {
+        unsigned my_xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        my_xcc = (my_xcc & 15u) + 1u;
+        __hip_atomic_store(a.xcc + v.c * a.G + v.wg, my_xcc, FRX_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(a.census, 1u, FRX_RLX_AGENT);
+        bool ok;
+        {   // the census has its own, shorter bound: a chip that cannot host the whole grid at once is a configuration, not a fault
+            const rk_u64 dl = wall_clock64() + a.census_ticks;
+            for (unsigned spins = 0;; spins++) {
+                if (__hip_atomic_load(a.census, FRX_RLX_AGENT) == (unsigned)(a.B * a.G)) { ok = true; break; }
+                if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (!ok) rk_fail(a, RK_ERR_CENSUS);
+        bool same = ok;
+        for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + v.c * a.G + k, FRX_RLX_AGENT) == my_xcc;
+        ctlU[0] = ok ? 1u : 0u;
+        ctlU[3] = same ? 1u : 0u;
+    }
+    __syncthreads();
+    if (ctlU[0] == 0u) return;
+    v.wt = ctlU[3] == 0u;                                                 // write-through payload stores unless the cluster shares an XCD
+    if (PROF && v.t < 16) ((rk_u64 *)(sm + L.ctl + 16))[v.t] = 0;
+    __syncthreads();
+    if (v.wg == 0) rk_leader_loop<PROF>(a, v, L, sm);
+    else rk_member_loop<E, PROF>(a, v, L, sm);
+}
+#undef RK_PROF
 
 } // namespace frx

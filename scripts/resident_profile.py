@@ -24,6 +24,9 @@ out = {"B": B, "N": N, "kappa": kappa, "G": G, "rounds_cand0": rounds, "iters_ca
 for name, wg in (("leader", 0), ("member1", 1), ("dense", G - 1)):
     out[name] = {SEG[i]: round(float(pr[0, wg, i]) / rounds, 2) for i in range(16) if pr[0, wg, i] > 0}
     out[name]["total"] = round(float(pr[0, wg].sum()) / rounds, 2)
+st = prob.last_stamps
+out["forward_body_cycles"] = [int(st[i + 1] - st[i]) for i in range(6)]          # loads, maps(T), forwardP, rows, PCR, Hermite+store
+out["adjoint_body_cycles"] = [int(st[i + 1] - st[i]) for i in range(16, 24)]     # loads, jerk, adjoint, rhs, PCR, knot adjoint+merge, cost, layers
 print(json.dumps(out, indent=1))
 prob.set_resident(False)
 r2 = prob.optimize(1e-6, x0=x0, max_iterations=iters)

@@ -25,7 +25,7 @@ def _plan(prob, tol, resident, trace=False, **kw):
     return r
 
 
-@pytest.mark.parametrize("B,N,gates,kappa", [(3, 16, 4, 8), (1, 64, 16, 16), (2, 5, 1, 8)])
+@pytest.mark.parametrize("B,N,gates,kappa", [(3, 32, 8, 8), (1, 64, 16, 16), (2, 40, 10, 12)])
 def test_resident_rounds_equal_per_stage_rounds(frx, sc, B, N, gates, kappa):
     cands = sc.make_batch(11, B, N, gates)
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
@@ -72,12 +72,17 @@ def test_resident_plans_end_like_per_stage_plans(frx, sc):
     prob.close()
 
 
-def test_batches_that_do_not_fit_the_chip_take_the_per_stage_path(frx, sc):
-    cands = [sc.make_candidate(7, 12, 3, perturb_id=i) for i in range(140)]       # 140 clusters x >= 2 workgroups > 256 CUs
+def test_batches_that_do_not_fit_the_chip_or_are_too_small_take_the_per_stage_path(frx, sc):
+    cands = [sc.make_candidate(7, 32, 8, perturb_id=i) for i in range(70)]        # 70 clusters x >= 5 workgroups > 256 CUs
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
     r = prob.optimize(1e-5, max_iterations=30)
     assert r["resident"] == 0 and np.all(np.isfinite(r["objective"]))
     prob.close()
+    # fewer variables than twice the history length: the compact representation would invert an ill-conditioned R (frx_api.cpp)
+    small = frx.Problem(sc.make_batch(2, 2, 5, 1), sc.ZHANGJIAJIE, qd_intervals=8)
+    r = small.optimize(1e-6)
+    assert r["resident"] == 0 and np.all(r["status"] >= 0)
+    small.close()
 
 
 def test_resident_kernel_handles_failing_and_finishing_candidates(frx, sc, ob):
