@@ -988,18 +988,18 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
-    int G = 1 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each)
+    int G = 2 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each) + dense
     {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them
         const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
         const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(B, 1)});
         G = std::max(G, want);
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
-    G = std::max(G, 2);
+    G = std::max(G, 3);
     if ((long)8 * G * ((B + 7) / 8) > cus) return 1;                                  // every workgroup must be resident at once (one per CU; grid = 8 G ceil(B/8))
     const size_t lds = frx::round_lds_bytes(p->geo, m, E);
     if (lds == 0 || lds > 160 * 1024) return 1;
-    const int NXP = (G - 1) * 2 * E;
+    const int NXP = (G - 2) * 2 * E;
     hipError_t e = hipSuccess;
     if (p->rk_B != B || p->rk_G != G || p->rk_NXP != NXP) {
         p->rk_B = 0;
@@ -1035,6 +1035,8 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
+    rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_max_linesearch = pm.max_linesearch;
+    { const char *sp = std::getenv("FRX_RESIDENT_SPECULATE"); rl.speculate = !(sp && sp[0] == '0') && pm.min_step <= 1.0 && 1.0 <= pm.max_step; }   // the predicted command carries step 1 (lbfgs.hpp:1418)
     struct StampGuard { frx_problem *q; ~StampGuard() { q->dp.stamps = nullptr; } } stamp_guard{p};
     if (want_prof) {                                                                  // phase stamps of candidate 0's forward / adjoint bodies (last evaluation)
         if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(32));
@@ -1194,11 +1196,11 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
             if (rc_dv != 0) std::copy(x_start.begin(), x_start.end(), x);
             else {
                 // Safety net: a candidate that ends with an L-BFGS error on the resident kernel is run again, from the same start, on
-                // the per-stage rounds (two-loop recursion): a genuine failure (an infeasible corridor ends in LBFGSERR_MINIMUMSTEP on
+                // the per-stage rounds (two-loop recursion; an iteration limit is not an error): a genuine failure (an infeasible corridor ends in LBFGSERR_MINIMUMSTEP on
                 // the CPU reference as well) fails again, a direction spoilt by an ill-conditioned R does not.
                 std::vector<char> again(p->B, 0);
                 int n_again = 0;
-                for (int b = 0; b < p->B; b++) if (status[b] < 0) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
+                for (int b = 0; b < p->B; b++) if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
                 if (n_again) {
                     const int used = p->resident_used;
                     const double t_res = p->stats[0];

@@ -93,6 +93,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
     a.timeout_ticks = r.timeout_ticks;
     a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms
+    a.ls_ftol = r.ls_ftol; a.ls_gtol = r.ls_gtol; a.ls_min_step = r.ls_min_step; a.ls_max_step = r.ls_max_step; a.ls_max_linesearch = r.ls_max_linesearch; a.speculate = r.speculate;
     a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g);
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;

@@ -86,8 +86,10 @@ struct RoundLaunch {
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
     int B, G, m, E, NXP;
+    double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
+    int ls_max_linesearch = 40, speculate = 1;
 };
-enum { ROUND_E = 48 };                                             // history doubles per thread and array of the instantiated kernel
+enum { ROUND_E = 56 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E);
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream);

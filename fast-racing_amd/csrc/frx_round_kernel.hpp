@@ -11,11 +11,11 @@
 //                    forward map and the adjoint (forward_knot_body / backward_knot_body of frx_kernels.hpp, unchanged arithmetic).
 //                    It carries no history: its loop is a separate branch of the kernel, so the evaluation bodies get the whole
 //                    register file (with the history live across them the compiler spilled 93 VGPRs into the adjoint).
-//   workgroups 1..G-1 keep 1/(G-1) of the candidate's (s, y) HISTORY RESIDENT IN REGISTERS: thread (slot j, half h) holds the elements
+//   workgroups 1..G-2 keep 1/(G-2) of the candidate's (s, y) HISTORY RESIDENT IN REGISTERS: thread (slot j, half h) holds the elements
 //                    [h E, (h+1) E) of its workgroup's chunk of s_j and y_j - 2 E doubles; the whole 46 MB history of the headline
 //                    batch lives in the register files of the chip and is never re-read from HBM (k_lbfgs_pre streams it twice
 //                    per accepted step: 55 us of a 101 us round at the headline batch).
-//   workgroup G-1    also DENSE: keeps the m x m factors of the compact L-BFGS representation resident in LDS
+//   workgroup G-1    DENSE: the m x m factors of the compact L-BFGS representation, resident in LDS (R^-1) and registers (Y^T Y)
 //   workgroups 0..G-2 evaluate the penalty integrand of their share of the pieces (penalty_body)
 //
 // Direction: with the history distributed by ELEMENTS, the two-loop recursion (2 m strictly sequential dot products of length n,
@@ -44,7 +44,7 @@ typedef unsigned long long rk_u64;
 #define FRX_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
 enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3 };
-enum { RK_OK = 0, RK_ERR_CENSUS = 1, RK_ERR_HOST = 2, RK_ERR_PHASE = 3, RK_ERR_ARRIVE = 4, RK_ERR_DENSE = 5, RK_ERR_UFLAG = 6, RK_ERR_HOST_ABORT = 7 };
+enum { RK_OK = 0, RK_ERR_CENSUS = 1, RK_ERR_HOST = 2, RK_ERR_PHASE = 3, RK_ERR_ARRIVE = 4, RK_ERR_DENSE = 5, RK_ERR_UFLAG = 6, RK_ERR_HOST_ABORT = 7, RK_ERR_SPECULATION = 8 };
 enum { DV_QUIT = 128 };                        // extra command flag of the resident kernel (frx_lbfgs.hpp: DV_* are < 32)
 
 // host -> device: word = seq << 32 | bound << 20 | slot << 8 | flags (written last); step first.  device -> host: seq written last.
@@ -54,25 +54,25 @@ static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 
 // LDS layout (doubles), shared by the kernel and the host-side size computation
 struct RoundLds {
-    int ctl, sC, yC, gC, pair, cS, cY, role, total;      // offsets; role = eval scratch | dense state
-    int Rt, Yt, vinv, va, vb, vc, ve, vw, vv, mv;        // dense state (offsets from 0): Rt = packed R^-1, Yt = packed Y^T Y, vinv = diag(R)
+    int ctl, sC, yC, gC, pair, role, total;              // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
+    int Rf, vd, va, vb, vc, ve, vw, vv, mv;              // dense state: Rf = R^-1 as [128][129] (row stride 129: conflict-free by row AND by column)
 };
+enum { RK_RS = 129 };                                    // row stride of Rf
 __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) {
     RoundLds L;
     int o = 0;
     L.ctl = o; o += 48;                                   // 16 unsigned | 8 doubles | 16 profile accumulators
     L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT;
     L.pair = o; o += 2 * 4 * 128;
-    L.cS = o; o += 128; L.cY = o; o += 128;
     o = (o + 1) & ~1;
     L.role = o;
-    const int tri = m * (m + 1) / 2;
     int d = o;
-    L.Rt = d; d += tri; L.Yt = d; d += tri;
-    L.vinv = d; d += 128; L.va = d; d += 128; L.vb = d; d += 128; L.vc = d; d += 128; L.ve = d; d += 128; L.vw = d; d += 128; L.vv = d; d += 128;
-    L.mv = d; d += 512;                                  // two [2][128] half-sum buffers
+    L.Rf = d; d += 128 * RK_RS;
+    L.vd = d; d += 128; L.va = d; d += 128; L.vb = d; d += 128; L.vc = d; d += 128; L.ve = d; d += 128; L.vw = d; d += 128; L.vv = d; d += 128;
+    L.mv = d; d += 512;                                   // two [2][128] half-sum buffers
     const int e = o + eval_doubles;
     L.total = (d > e ? d : e) + 2;
+    (void)m;
     return L;
 }
 
@@ -90,7 +90,9 @@ struct RoundArgs {
     RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
     rk_u64 census_ticks;                     // bound of the start-up census (all workgroups resident)
-    int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 1) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
+    double ls_ftol, ls_gtol, ls_min_step, ls_max_step;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
+    int ls_max_linesearch, speculate;
+    int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
 };
@@ -157,9 +159,34 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     rk_u64 hseq = 0;
     int lstage = 0, flags = 0, jnew = 0, bound = 0;
     double step = 0.0;
+    // Optimistic acceptance.  The host's verdict on the FIRST trial of a line search is a two-line test on numbers the leader already
+    // holds (lbfgs.hpp:835-850: sufficient decrease and curvature), and an accepted step is always followed by the same command:
+    // ADVANCE | TRIAL | EVAL with the next history slot and step 1 (lbfgs.hpp:1418).  When the test holds the leader starts that command
+    // at once instead of idling for the mailbox round trip (3-9 us of a ~55 us round, measured) and CONFIRMS it against the command the
+    // host actually sent before the next result is posted.  The host keeps every decision: if it stopped instead (convergence,
+    // iteration limit) the leader restores the accepted point and leaves; any other disagreement ends the launch with
+    // RK_ERR_SPECULATION and the plan is re-run on the per-stage path.
+    bool unconfirmed = false, spec_ready = false;
+    rk_u64 pred_word = 0;
+    double f_acc = 0.0, gg0 = 0.0;
+    int last_slot = -1, last_bound = 0;
     for (;;) {
         int kind = 0;
-        if (lstage == 0) {
+        if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
+            spec_ready = false; unconfirmed = true;
+            hseq++;
+            flags = (int)(pred_word & 0xFFu); jnew = (int)((pred_word >> 8) & 0xFFFu); bound = (int)((pred_word >> 20) & 0xFFFu);
+            step = 1.0;
+            f_acc = ctlD[0];
+            last_slot = jnew; last_bound = bound;
+            for (int i = t; i < a.NXP; i += 256) {                          // same as the DV_ADVANCE branch below
+                double s = 0.0, y = 0.0, gv = 0.0;
+                if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
+                stg<true>(pub + i, s, wt); stg<true>(pub + a.NXP + i, y, wt); stg<true>(pub + 2 * a.NXP + i, gv, wt);
+            }
+            if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }
+            kind = PH_ADV; lstage = 1;
+        } else if (lstage == 0) {
             if (t == 0) {
                 const rk_u64 dl = wall_clock64() + a.timeout_ticks;
                 rk_u64 w = 0;
@@ -187,6 +214,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
                 continue;
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
+                f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
                 for (int i = t; i < a.NXP; i += 256) {
                     double s = 0.0, y = 0.0, gv = 0.0;
                     if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
@@ -196,6 +224,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 kind = PH_ADV; lstage = 1;
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
+                    f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
                     for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
                 }
                 lstage = 1;
@@ -254,6 +283,35 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl);
             rk_drain_and_meet();
             RK_PROF(RK_P_BACKWARD);
+            if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
+                if (t == 0) {
+                    const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+                    rk_u64 w = 0;
+                    bool ok = true;
+                    for (unsigned spins = 0;; spins++) {
+                        w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
+                        if ((w >> 32) == hseq) break;
+                        if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
+                    }
+                    unsigned verdict = 0u;                                   // 0 confirmed, 1 host stopped (QUIT), 2 anything else
+                    if (!ok) { rk_fail(a, RK_ERR_HOST); verdict = 2u; }
+                    else if ((unsigned)w != (unsigned)pred_word) verdict = ((unsigned)w & (unsigned)DV_QUIT) ? 1u : 2u;
+                    else if (__longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS)) != 1.0) verdict = 2u;
+                    if (verdict == 2u) { rk_fail(a, RK_ERR_SPECULATION); __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
+                    ctlU[1] = verdict;
+                }
+                __syncthreads();
+                const unsigned verdict = ctlU[1];
+                __syncthreads();
+                unconfirmed = false;
+                if (verdict != 0u) {
+                    if (verdict == 1u) { for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; } }     // the accepted point is the result
+                    rk_drain_and_meet();
+                    pseq++;
+                    if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT);
+                    break;
+                }
+            }
             if (t == 0) {
                 RoundRes *r = a.h_res + c;
                 __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
@@ -267,6 +325,18 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             }
             lstage = 0;
             __syncthreads();
+            if (a.speculate && (flags & (DV_ADVANCE | DV_INIT))) {          // first trial of a search: predict the host's verdict (lbfgs.hpp:829-850)
+                const double fv = ctlD[0], dgv = ctlD[1];
+                const double dgi = (flags & DV_ADVANCE) ? ctlD[4] : -gg0;  // slope at the start of the search (lbfgs.hpp:756; d = -g after INIT)
+                const double dgtest = a.ls_ftol * dgi, ftest1 = f_acc + step * dgtest;
+                const bool accept = !(isnan(fv) || isinf(fv)) && !(0.0 < dgi) && step != a.ls_max_step && step != a.ls_min_step && a.ls_max_linesearch > 1 &&
+                                    fv <= ftest1 && fabs(dgv) <= a.ls_gtol * (-dgi);
+                if (accept) {
+                    const int nslot = last_slot < 0 ? 0 : (last_slot + 1 == v.m ? 0 : last_slot + 1), nbound = min(v.m, last_bound + 1);
+                    pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL);
+                    spec_ready = true;
+                }
+            }
             RK_PROF(RK_P_POST);
         }
     }
@@ -280,8 +350,8 @@ template <int E, bool PROF>
 __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
     constexpr int CHT = 2 * E;
     const int c = v.c, wg = v.wg, t = v.t, lane = v.lane, wave = v.wave, m = v.m;
-    const bool wt = v.wt, dense = wg == a.G - 1;
-    const int hg = wg - 1, nh = a.G - 1;                                    // history chunk of this workgroup, number of history workgroups
+    const bool wt = v.wt;
+    const int hg = wg - 1;                                                  // history chunk of this workgroup (workgroups 1 .. G-2)
     volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
     double *ctlD = sm + L.ctl + 8, *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *ev = sm + L.role + a.ct_doubles;
     double *pub = v.pub, *part = v.part, *upub = v.upub, *dpub = v.dpub;
@@ -290,10 +360,6 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
     double Sreg[E], Yreg[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
-    if (dense) {                                                            // R^-1, Y^T Y, D start as zeros: no uninitialised word is ever multiplied
-        for (int i = L.Rt + t; i < L.va; i += 256) sm[i] = 0.0;
-        __syncthreads();
-    }
     unsigned pseq = 0, nadv = 0;
     int jnew = 0, bound = 0;
     for (;;) {
@@ -353,117 +419,6 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             rk_drain_and_meet();
             if (t == 0) __hip_atomic_fetch_add(a.cntA + c, 1u, FRX_RLX_AGENT);
             RK_PROF(RK_P_PASS_A);
-            // -- 4. dense workgroup: reduce the partials, update R^-1 and Y^T Y, three mat-vecs --
-            if (dense) {
-                double *Rt = sm + L.Rt, *Yt = sm + L.Yt, *vinv = sm + L.vinv, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw,
-                       *vv = sm + L.vv, *mv = sm + L.mv, *mz = sm + L.mv + 256;
-                if (t == 0) { const bool ok = rk_wait_eq(a.cntA + c, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
-                __syncthreads();
-                RK_PROF(RK_P_WAIT_PART);
-                for (int o = t; o < 512; o += 256) {
-                    double s = 0.0;
-                    for (int w2 = 0; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);      // fixed order: deterministic
-                    (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
-                }
-                __syncthreads();
-                RK_PROF(RK_P_DENSE_IN);
-                // The dense step keeps R^-1 itself (packed by slot pair: entry (i, j), i not newer than j, at tri(i, j)), not R: when the
-                // oldest pair is dropped R^-1 loses its first row and column and nothing else changes; a new pair appends the column
-                // (-R22^-1 c / rho, 1 / rho) with c = S^T y_new, rho = s_new . y_new.  Every product is then a masked mat-vec over all
-                // 256 threads instead of a 128-step substitution issued by one wave (measured: 2 x 128 dependent steps = 20 of a round's
-                // 78 us).  Checked on a complete headline optimisation (3500 accepted steps, cond(R) up to 1e6): the direction stays
-                // within 3e-13 of the two-loop recursion, no drift (scripts/lbfgs_inverse_stability.py).
-                auto off_of = [&](int q) { return (q * (2 * m - q + 1)) >> 1; };
-                auto tri2 = [&](int sl, int offl, int sk, int offk) { return sl < sk ? offl + (sk - sl) : offk + (sl - sk); };
-                auto age_of = [&](int j) { int ag = jnew - j; return ag < 0 ? ag + m : ag; };
-                const int pp = t & 127, hq = t >> 7, opp = off_of(pp), app = age_of(pp);
-                const bool vpp = pp < m && app < bound;
-                // Three passes over the packed matrices, 16 columns per trip (all 32 LDS reads of a trip are issued before the first FMA
-                // needs one; a trip of 4 was latency-bound: ~4 us per pass, measured).  Thread (p, hq) sums the columns [64 hq, 64 hq + 64).
-                //   pass 1  rows of the OLD R^-1 without slot jnew, two right-hand sides at once: z = R22^-1 c and t = R22^-1 a
-                //           => new column (-z / rho, 1 / rho), and w = (t - z a_new / rho, a_new / rho)
-                //   pass 2  (Y^T Y) w        (no mask: entries without a pair are zero, and so is w there)
-                //   pass 3  columns of the new R^-1: u = R^-T v
-                const int q0 = 64 * hq;
-                if (t < m && age_of(t) < bound) Yt[tri2(t, off_of(t), jnew, off_of(jnew))] = ve[t];
-                const double rho = vc[jnew], gamma = rho / ve[jnew];        // y.s, and y.s / y.y of the newest pair (lbfgs.hpp:1403)
-                if (t == 0) vinv[jnew] = rho;                               // diagonal of R (the array keeps D, despite its name)
-                {
-                    double sz = 0.0, st = 0.0;
-                    if (vpp && pp != jnew) {
-#pragma unroll 1
-                        for (int qb = 0; qb < 64; qb += 16) {
-                            double e[16], cq[16], aqv[16];
-#pragma unroll
-                            for (int u = 0; u < 16; u++) {
-                                const int q = min(q0 + qb + u, m - 1);
-                                e[u] = Rt[tri2(pp, opp, q, off_of(q))]; cq[u] = vc[q]; aqv[u] = va[q];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 16; u++) {
-                                const int q = q0 + qb + u, aq = age_of(min(q, m - 1));
-                                const double em = (q < m && q != jnew && aq < bound && aq <= app) ? e[u] : 0.0;
-                                sz += em * cq[u]; st += em * aqv[u];
-                            }
-                        }
-                    }
-                    mv[hq * 128 + pp] = sz; mz[hq * 128 + pp] = st;
-                    __syncthreads();
-                }
-                if (t < 128) {
-                    const double wl = va[jnew] / rho;
-                    double wp = 0.0;
-                    if (vpp) {
-                        if (pp == jnew) { Rt[tri2(pp, opp, jnew, off_of(jnew))] = 1.0 / rho; wp = wl; }
-                        else { const double z = mv[pp] + mv[128 + pp]; Rt[tri2(pp, opp, jnew, off_of(jnew))] = -z / rho; wp = (mz[pp] + mz[128 + pp]) - z * wl; }
-                    }
-                    vw[t] = wp;
-                }
-                __syncthreads();
-                {
-                    double sacc = 0.0;
-                    if (pp < m) {
-#pragma unroll 1
-                        for (int qb = 0; qb < 64; qb += 16) {
-                            double e[16], xq[16];
-#pragma unroll
-                            for (int u = 0; u < 16; u++) { const int q = min(q0 + qb + u, m - 1); e[u] = Yt[tri2(pp, opp, q, off_of(q))]; xq[u] = (q0 + qb + u < m) ? vw[q] : 0.0; }
-#pragma unroll
-                            for (int u = 0; u < 16; u++) sacc += e[u] * xq[u];
-                        }
-                    }
-                    mv[hq * 128 + pp] = sacc;
-                    __syncthreads();
-                }
-                if (t < 128) vv[t] = vpp ? (vinv[t] * vw[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t]) : 0.0;
-                __syncthreads();
-                {
-                    double sacc = 0.0;
-                    if (vpp) {
-#pragma unroll 1
-                        for (int qb = 0; qb < 64; qb += 16) {
-                            double e[16], xq[16];
-#pragma unroll
-                            for (int u = 0; u < 16; u++) { const int q = min(q0 + qb + u, m - 1); e[u] = Rt[tri2(pp, opp, q, off_of(q))]; xq[u] = vv[q]; }
-#pragma unroll
-                            for (int u = 0; u < 16; u++) {
-                                const int q = q0 + qb + u, aq = age_of(min(q, m - 1));
-                                sacc += ((q < m && aq < bound && aq >= app) ? e[u] : 0.0) * xq[u];
-                            }
-                        }
-                    }
-                    mz[hq * 128 + pp] = sacc;
-                    __syncthreads();
-                }
-                if (t < 128) {
-                    stg<true>(upub + t, vpp ? -(mz[t] + mz[128 + t]) : 0.0, wt);
-                    stg<true>(upub + 128 + t, vpp ? gamma * vw[t] : 0.0, wt);
-                }
-                if (t == 128) stg<true>(upub + 256, gamma, wt);
-                rk_drain_and_meet();
-                if (t == 0) __hip_atomic_store(a.uflag + c, nadv, FRX_RLX_AGENT);
-                RK_PROF(RK_P_SOLVE);
-            }
             // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
             if (t == 0) { const bool ok = rk_wait_eq(a.uflag + c, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
             __syncthreads();
@@ -490,12 +445,142 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             }
             RK_PROF(RK_P_PASS_B);
         }
-        if (kind == PH_CT && !dense) { rk_penalty_share<PROF>(a, v, ev, wg); RK_PROF(RK_P_PENALTY); }
+        if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, wg); RK_PROF(RK_P_PENALTY); }
         // ---- report the end of this workgroup's part of the phase to the leader ----
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+}
+
+
+// ============================================================================================================================
+// DENSE (workgroup G-1): the m x m part of the compact representation, nothing else
+//   R^-1 in LDS as a full [128][129] square indexed by SLOT (entry (i, j) is non-zero only when pair i is not newer than pair j;
+//   the odd row stride makes a row sweep and a column sweep both conflict-free, and the zeros replace every age test), Y^T Y in
+//   registers (thread (p, hq) holds row p, columns [64 hq, 64 hq + 64)).  When the oldest pair is dropped R^-1 loses that row and
+//   column and nothing else changes; a new pair appends the column (-R22^-1 c / rho, 1 / rho), c = S^T y_new, rho = s_new . y_new.
+//   Checked on a complete headline optimisation (3500 accepted steps, cond(R) up to 1e6): the direction stays within 3e-13 of the
+//   two-loop recursion, no drift (scripts/lbfgs_inverse_stability.py).
+// ============================================================================================================================
+template <bool PROF>
+__device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
+    const int c = v.c, t = v.t;
+    const bool wt = v.wt;
+    const int nh = a.G - 2;                                                 // history workgroups
+    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
+    double *Rf = sm + L.Rf, *vd = sm + L.vd, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw, *vv = sm + L.vv,
+           *mv = sm + L.mv, *mz = sm + L.mv + 256;
+    double *pub = v.pub, *part = v.part, *upub = v.upub;
+    const int pp = t & 127, hq = t >> 7, q0 = 64 * hq;
+    rk_u64 prof_last = PROF ? wall_clock64() : 0;
+    double Ya[32], Yb[32];                                                  // (Y^T Y)[pp][q0 .. q0 + 31], [q0 + 32 .. q0 + 63]: two arrays the compiler keeps in registers
+#pragma unroll
+    for (int u = 0; u < 32; u++) { Ya[u] = 0.0; Yb[u] = 0.0; }
+    for (int i = L.Rf + t; i < L.mv + 512; i += 256) sm[i] = 0.0;           // no uninitialised word is ever multiplied
+    __syncthreads();
+    unsigned pseq = 0, nadv = 0;
+    for (;;) {
+        if (t == 0) {
+            const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+            unsigned w = 0;
+            bool ok = true;
+            for (unsigned spins = 0;; spins++) {
+                w = __hip_atomic_load(a.phase + c, FRX_RLX_AGENT);
+                if ((w >> 4) == pseq + 1) break;
+                if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
+            ctlU[0] = w & 15u;
+        }
+        __syncthreads();
+        const int kind = (int)ctlU[0];
+        pseq++;
+        __syncthreads();
+        RK_PROF(RK_P_WAIT_PHASE);
+        if (kind == PH_QUIT) break;
+        if (kind == PH_ADV) {
+            nadv++;
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); const bool ok = rk_wait_eq(a.cntA + c, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+            __syncthreads();
+            const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
+            RK_PROF(RK_P_WAIT_PART);
+            for (int o = t; o < 512; o += 256) {
+                double s = 0.0;
+                for (int w2 = 0; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);          // fixed order: deterministic
+                (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
+            }
+            if (t < 128) { Rf[jnew * RK_RS + t] = 0.0; Rf[t * RK_RS + jnew] = 0.0; }                  // the pair that slot jnew held is gone
+            __syncthreads();
+            RK_PROF(RK_P_DENSE_IN);
+            // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are)
+            {
+                const int uj = jnew - q0;
+                const double colv = ve[pp];
+                const bool isrow = pp == jnew;
+#pragma unroll
+                for (int u = 0; u < 32; u++) {
+                    const double r0 = ve[q0 + u], r1 = ve[q0 + 32 + u];
+                    Ya[u] = isrow ? r0 : (u == uj ? colv : Ya[u]);
+                    Yb[u] = isrow ? r1 : (u + 32 == uj ? colv : Yb[u]);
+                }
+            }
+            RK_PROF(RK_P_VECTORS);                                          // (dense workgroup: Y^T Y update)
+            const double rho = vc[jnew], gamma = rho / ve[jnew], wl = va[jnew] / rho;      // y.s, y.s / y.y of the newest pair (lbfgs.hpp:1403)
+            // pass 1: rows of the old R^-1, two right-hand sides at once: z = R22^-1 c, tt = R22^-1 a (row and column jnew are zero)
+            {
+                double sz = 0.0, st = 0.0;
+                const double *row = Rf + pp * RK_RS + q0;
+#pragma unroll 16
+                for (int u = 0; u < 64; u++) { const double e = row[u]; sz += e * vc[q0 + u]; st += e * va[q0 + u]; }
+                mv[hq * 128 + pp] = sz; mz[hq * 128 + pp] = st;
+            }
+            __syncthreads();
+            RK_PROF(RK_P_PASS_A);                                           // (dense workgroup: pass 1)
+            if (t < 128) {                                                  // new column of R^-1, and w = R^-1 a
+                double wp;
+                if (pp == jnew) { Rf[pp * RK_RS + jnew] = 1.0 / rho; wp = wl; vd[jnew] = rho; }
+                else { const double z = mv[pp] + mv[128 + pp]; Rf[pp * RK_RS + jnew] = -z / rho; wp = (mz[pp] + mz[128 + pp]) - z * wl; }
+                vw[t] = wp;
+            }
+            __syncthreads();
+            // pass 2: (Y^T Y) w from registers
+            {
+                double sacc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 32; u++) sacc += Ya[u] * vw[q0 + u];
+#pragma unroll
+                for (int u = 0; u < 32; u++) sacc += Yb[u] * vw[q0 + 32 + u];
+                mv[hq * 128 + pp] = sacc;
+            }
+            __syncthreads();
+            RK_PROF(RK_P_FORWARD);                                          // (dense workgroup: column update + pass 2)
+            if (t < 128) vv[t] = vd[t] * vw[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t];
+            __syncthreads();
+            // pass 3: columns of the new R^-1: u = R^-T v
+            {
+                double sacc = 0.0;
+                const double *col = Rf + q0 * RK_RS + pp;
+#pragma unroll 16
+                for (int u = 0; u < 64; u++) sacc += col[u * RK_RS] * vv[q0 + u];
+                mz[hq * 128 + pp] = sacc;
+            }
+            __syncthreads();
+            RK_PROF(RK_P_PASS_B);                                           // (dense workgroup: pass 3)
+            if (t < 128) {
+                stg<true>(upub + t, -(mz[t] + mz[128 + t]), wt);
+                stg<true>(upub + 128 + t, gamma * vw[t], wt);
+            }
+            if (t == 128) stg<true>(upub + 256, gamma, wt);
+            rk_drain_and_meet();
+            if (t == 0) __hip_atomic_store(a.uflag + c, nadv, FRX_RLX_AGENT);
+            RK_PROF(RK_P_SOLVE);
+        }
+        rk_drain_and_meet();
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
+    }
+    if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }
 
 template <int E, bool PROF>
@@ -546,6 +631,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     if (PROF && v.t < 16) ((rk_u64 *)(sm + L.ctl + 16))[v.t] = 0;
     __syncthreads();
     if (v.wg == 0) rk_leader_loop<PROF>(a, v, L, sm);
+    else if (v.wg == a.G - 1) rk_dense_loop<PROF>(a, v, L, sm);
     else rk_member_loop<E, PROF>(a, v, L, sm);
 }
 #undef RK_PROF
