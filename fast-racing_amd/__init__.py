@@ -64,6 +64,7 @@ ABI_SYMBOLS = [
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
     "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace", "frx_resident_profile",
+    "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
 ]
 
 _lib = None
@@ -99,6 +100,14 @@ def lib():
         L.frx_optimize_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
         L.frx_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.frx_resident_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
+        L.frx_multi_destroy.argtypes = [C.c_void_p]
+        L.frx_multi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        L.frx_multi_layout.argtypes = [C.c_void_p, _ip, _ip]
+        L.frx_multi_initial_guess.argtypes = [C.c_void_p, _dp]
+        L.frx_multi_optimize.argtypes = [C.c_void_p, C.POINTER(LbfgsParams), _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                         _dp, _dp, C.POINTER(C.c_int)]
+        L.frx_multi_last_exchange.argtypes = [C.c_void_p]
         L.frx_problem_destroy.argtypes = [C.c_void_p]
         L.frx_problem_set_solver.argtypes = [C.c_void_p, C.c_int]
         L.frx_problem_set_lbfgs_mode.argtypes = [C.c_void_p, C.c_int]
@@ -222,6 +231,58 @@ def msg_sample(msg, t: float):
     p = np.zeros(3); v = np.zeros(3); a = np.zeros(3); j = np.zeros(3)
     _check(lib().frx_msg_sample(len(tm), cx, cy, cz, tm, od, float(t), p, v, a, j))
     return p, v, a, j
+
+
+class MultiProblem:
+    """A batch sharded over several devices behind the C ABI (frx_multi_*): one host thread and handle per device, RCCL winner exchange."""
+
+    def __init__(self, cands, params: dict, devices=None, n_devices: int = 0, **override):
+        self.cfg = FrxConfig.from_params(params, **override)
+        coarse_n, ini, fin, h_off, h_rec, v_off, v_rec = pack_batch(cands)
+        h = C.c_void_p()
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        nd = n_devices if devices is None else len(devices)
+        _check(lib().frx_multi_create(C.byref(self.cfg), nd, None if dev is None else dev.ctypes.data, len(cands), coarse_n, ini, fin, h_off, h_rec, v_off, v_rec, C.byref(h)))
+        self.h = h
+        self.B = len(cands)
+        g = C.c_int(); r = C.c_int()
+        _check(lib().frx_multi_info(self.h, C.byref(g), C.byref(r), None, None))
+        self.n_shards, self.uses_rccl = int(g.value), bool(r.value)
+        self.shard_lo = np.zeros(self.n_shards + 1, np.int32); self.shard_device = np.zeros(self.n_shards, np.int32)
+        _check(lib().frx_multi_info(self.h, None, None, self.shard_lo.ctypes.data, self.shard_device.ctypes.data))
+        self.piece_off = np.zeros(self.B + 1, np.int32); self.x_off = np.zeros(self.B + 1, np.int32)
+        _check(lib().frx_multi_layout(self.h, self.piece_off, self.x_off))
+        self.P, self.NX = int(self.piece_off[-1]), int(self.x_off[-1])
+        self.maxN = int(np.diff(self.piece_off).max())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().frx_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def initial_guess(self):
+        x = np.zeros(self.NX)
+        _check(lib().frx_multi_initial_guess(self.h, x))
+        return x
+
+    def optimize(self, rel_cost_tol: float, x0=None, max_iterations: int = 0):
+        x = self.initial_guess() if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        pm = gcopter_lbfgs_params(rel_cost_tol, max_iterations)
+        Cf = np.zeros(self.P * 18); T = np.zeros(self.P); jc = np.zeros(self.B); obj = np.zeros(self.B)
+        st = np.zeros(self.B, np.int32); it = np.zeros(self.B, np.int32); ev = np.zeros(self.B, np.int32)
+        wid = C.c_int(); wobj = C.c_double(); wn = C.c_int()
+        wC = np.zeros(self.maxN * 18); wT = np.zeros(self.maxN)
+        _check(lib().frx_multi_optimize(self.h, C.byref(pm), x, Cf, T, jc, obj, st, it, ev, C.byref(wid), C.byref(wobj), wC, wT, C.byref(wn)))
+        n = int(wn.value)
+        return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev, winner_id=int(wid.value),
+                    winner_objective=float(wobj.value), winner_C=wC[:18 * n].reshape(-1, 3).copy(), winner_T=wT[:n].copy(),
+                    exchange="rccl" if lib().frx_multi_last_exchange(self.h) else "host")
 
 
 class Problem:

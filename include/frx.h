@@ -264,6 +264,31 @@ int frx_optimize_stats(const frx_problem *p, double *out4);
  */
 int frx_problem_set_resident(frx_problem *p, int enable);
 int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device_status);
+/*
+ * Multi-GPU plans (the reference is pinned to device 0, cc.cu:414).  The batch is block-partitioned over the devices:
+ * one host thread + one frx_problem handle per device runs its shard exactly like frx_optimize - candidates are independent, an
+ * evaluation needs no collective - and the plan ends with the winner exchange over RCCL (ncclCommInitAll over the devices of this
+ * process): all-gather of (objective, candidate id), 16 bytes per device, then a broadcast of the winner's 6N x 3 coefficients and
+ * N durations from the device that owns it.  librccl.so is loaded on first use.  n_devices = 0 takes every visible device (never
+ * more shards than candidates); `devices` may be NULL (0, 1, ...).  When several shards share a physical device (tests on a 1-GPU
+ * box; RCCL refuses duplicates), or with FRX_MULTI_COMM=host, the same two operations run through an in-process communicator.
+ * Arrays of frx_multi_optimize are packed over the WHOLE batch in candidate order (offsets: frx_multi_layout); C, T, jerk_cost,
+ * objective, iters, evals and the winner_* outputs may be NULL.  Failed candidates (status < 0) and non-finite objectives never win,
+ * ties go to the lowest id; winner_C / winner_T hold winner_n pieces (18 doubles each / one duration each).
+ */
+typedef struct frx_multi frx_multi;
+int frx_multi_create(const frx_config *cfg, int n_devices, const int *devices, int B, const int *coarse_n, const double *ini_state,
+                     const double *fin_state, const int *h_off, const double *h_rec, const int *v_off, const double *v_rec, frx_multi **out);
+void frx_multi_destroy(frx_multi *m);
+int frx_multi_info(const frx_multi *m, int *n_shards, int *uses_rccl, int *shard_lo, int *shard_device);
+int frx_multi_layout(const frx_multi *m, int *piece_off, int *x_off);
+int frx_multi_initial_guess(frx_multi *m, double *x0);
+int frx_multi_optimize(frx_multi *m, const frx_lbfgs_params *params, double *x, double *C, double *T, double *jerk_cost, double *objective,
+                       int *status, int *iters, int *evals, int *winner_id, double *winner_objective, double *winner_C, double *winner_T,
+                       int *winner_n);
+/* 1 when the last frx_multi_optimize exchanged the winner through RCCL, 0 for the in-process communicator. */
+int frx_multi_last_exchange(const frx_multi *m);
+
 /* Diagnostic (tests): with FRX_TRACE set in the environment, frx_optimize records for candidate 0 one row per evaluated command
  * {flags, step, f, g.d, gp.d_new, x.x, g.g}; returns the number of rows and copies up to cap_rows of them (7 doubles each). */
 int frx_debug_trace(const frx_problem *p, double *out, int cap_rows);

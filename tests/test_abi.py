@@ -70,3 +70,9 @@ def test_cpp_mirror_header_compiles_and_links(frx, tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stdout
     assert ("no HIP device" in r.stdout) != has_gpu()
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_multi_create_fails_loudly_without_device(frx, sc):
+    with pytest.raises(frx.FrxError, match="no HIP device"):
+        frx.MultiProblem(sc.make_batch(0, 2, 8, 2), sc.ZHANGJIAJIE, qd_intervals=8)

@@ -1,0 +1,60 @@
+"""frx_multi_*: a batch sharded over devices behind the C ABI - block partition, one host thread and handle per device,
+winner exchange (all-gather of (objective, id), broadcast of the winner's trajectory) over RCCL, or over the in-process communicator
+when shards share a device.  The GPU box has ONE device: the RCCL path is exercised with one rank, the sharding logic with two shards
+on device 0; no multi-GPU scaling number is claimed anywhere from these tests."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect_winner(objective, status):
+    f = np.where((status < 0) | ~np.isfinite(objective), np.inf, objective)
+    return int(np.argmin(f)), float(f.min())
+
+
+def test_two_shards_on_one_device_equal_two_separate_handles(frx, sc):
+    cands = [sc.make_candidate(0, 32, 8, perturb_id=b) for b in range(5)]          # 5 candidates -> shards of 3 and 2 (block partition)
+    mp = frx.MultiProblem(cands, sc.ZHANGJIAJIE, devices=[0, 0], qd_intervals=8)
+    assert mp.n_shards == 2 and list(mp.shard_lo) == [0, 3, 5] and not mp.uses_rccl          # RCCL cannot take a device twice
+    x0 = mp.initial_guess()
+    r = mp.optimize(1e-5, x0=x0)
+    assert r["exchange"] == "host" and np.all(r["status"] >= 0)
+    for lo, hi in ((0, 3), (3, 5)):                                                # bit-identical to the shard run on its own handle
+        p = frx.Problem(cands[lo:hi], sc.ZHANGJIAJIE, qd_intervals=8)
+        q = p.optimize(1e-5, x0=x0[mp.x_off[lo]:mp.x_off[hi]])
+        assert np.array_equal(q["x"], r["x"][mp.x_off[lo]:mp.x_off[hi]]) and np.array_equal(q["objective"], r["objective"][lo:hi])
+        assert np.array_equal(q["C"], r["C"][6 * mp.piece_off[lo]:6 * mp.piece_off[hi]]) and np.array_equal(q["evals"], r["evals"][lo:hi])
+        p.close()
+    wid, wobj = _expect_winner(r["objective"], r["status"])
+    assert r["winner_id"] == wid and r["winner_objective"] == wobj
+    sl = slice(mp.piece_off[wid], mp.piece_off[wid + 1])
+    assert np.array_equal(r["winner_C"], r["C"][6 * sl.start:6 * sl.stop]) and np.array_equal(r["winner_T"], r["T"][sl])
+    mp.close()
+
+
+def test_rccl_exchange_with_every_visible_device(frx, sc):
+    """n_devices = 0: one shard per visible device (one on this box); the winner travels through ncclAllGather / ncclBroadcast."""
+    cands = [sc.make_candidate(0, 32, 8, perturb_id=b) for b in range(3)] + [sc.make_candidate(170, 64, 16)]     # the last one is infeasible
+    mp = frx.MultiProblem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    assert mp.n_shards == frx.lib().frx_device_count() or mp.n_shards == len(cands)
+    r = mp.optimize(1e-5)
+    if mp.uses_rccl:
+        assert r["exchange"] == "rccl"
+    f = r["objective"].copy()
+    wid, wobj = _expect_winner(f, r["status"])
+    assert r["winner_id"] == wid and r["winner_objective"] == wobj and wid != 3
+    sl = slice(mp.piece_off[wid], mp.piece_off[wid + 1])
+    assert np.array_equal(r["winner_C"], r["C"][6 * sl.start:6 * sl.stop]) and np.array_equal(r["winner_T"], r["T"][sl])
+    print("shards", mp.n_shards, "rccl", mp.uses_rccl, "winner", wid, wobj)
+    mp.close()
+
+
+def test_a_failed_candidate_never_wins(frx, sc):
+    """The infeasible Monte-Carlo scenario 170 ends in LBFGSERR_MINIMUMSTEP; even if its restored objective were the smallest number
+    in the table it must not be selected (rank on status, not on the raw value)."""
+    cands = [sc.make_candidate(170, 64, 16), sc.make_candidate(3, 64, 16)]
+    mp = frx.MultiProblem(cands, sc.ZHANGJIAJIE, devices=[0, 0], qd_intervals=16)
+    r = mp.optimize(sc.ZHANGJIAJIE["opt_rel_tol"])
+    assert r["status"][0] < 0 and r["status"][1] >= 0 and r["winner_id"] == 1
+    mp.close()
