@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6  # FP64 vector peak = half the 157.3 TF FP32 vector peak of the same guide
 
 
 def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
@@ -63,9 +64,9 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
         rs = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"]), oracles))
     plan_batch_ms = (time.perf_counter() - t0) * 1e3
     return {
-        "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "kind": "port",
+        "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "node_cores": cores, "threads": workers, "kind": "port",
         "sample": f"{done} objective evaluations (x->f,grad) of the {len(cands)} headline candidates at the bench state, "
-                  f"{workers} threads, oracle built -O3 -march=x86-64-v3",
+                  f"{workers} threads on a node with {cores} logical cores, oracle built -O3 -march=x86-64-v3",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
         "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
         "plan_ms_batch": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_objective_min": float(min(x["objective"] for x in rs)),
@@ -150,32 +151,54 @@ def main():
         dt = float(t.item())
     samples_per_step = prob.samples()
 
-    # dominant kernel alone, HIP events on the launch stream
+    # the three stage kernels one at a time (HIP events on the library's launch stream, frx_eval_stage_times): the roofline object is
+    # reported for the one that takes longest, the penalty integrator keeps its own sub-object (it is the kernel SURVEY.md 8d prices)
+    stage_us = prob.stage_times(x_state, reps=max(args.steps, 100))
+    # evaluation time along the optimisation (SURVEY.md 8d "kernel-only benchmark state"): the reference initial guess and the iterates
+    # after 10 / 20 / 40 / 80 iterations; the headline `value` is taken at the 60-iteration state above
+    states = []
+    for it in (0, 10, 20, 40, 80):
+        xs = x0 if it == 0 else prob.optimize(params["opt_rel_tol"], x0=x0, max_iterations=it)["x"]
+        st_us = prob.stage_times(xs, reps=50)
+        states.append({"iterations": it, "forward_us": st_us["forward"], "penalty_us": st_us["penalty"], "adjoint_us": st_us["adjoint"],
+                       "samples_per_s": samples_per_step / (sum(st_us.values()) * 1e-6)})
     T_dev = torch.zeros(prob.P, dtype=torch.float64, device="cuda")
     C_dev = torch.zeros(prob.P * 18, dtype=torch.float64, device="cuda")
     T_h, C_h = prob.forward(x_state)
     T_dev.copy_(torch.from_numpy(T_h)); C_dev.copy_(torch.from_numpy(C_h.reshape(-1)))
     out_dev = torch.zeros(prob.P * 20, dtype=torch.float64, device="cuda")
-    for _ in range(10):
-        prob.penalty_device(T_dev.data_ptr(), C_dev.data_ptr(), out_dev.data_ptr(), stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(args.steps, 50)
-    e0.record()
-    for _ in range(reps):
-        prob.penalty_device(T_dev.data_ptr(), C_dev.data_ptr(), out_dev.data_ptr(), stream)
-    e1.record()
-    torch.cuda.synchronize()
-    pen_us = e0.elapsed_time(e1) * 1e3 / reps
+    pen_us = stage_us["penalty"]
     alg_bytes = prob.algorithmic_bytes()
     pairs_per_step = (kappa + 1) * prob.sum_K                        # sum over pieces of (kappa+1) K_i (secondary metric)
     achieved = alg_bytes / (pen_us * 1e-6) / 1e9
+    # algorithmic bytes of the two knot kernels: per candidate x (8 n), waypoint polytopes (24 per vertex), the stage
+    # buffers T, C (152 N), the saved reduction multipliers ((8 steps + 4) 8 N), out20 (160 N), d and g (8 n each)
+    nx = np.diff(prob.x_off).astype(np.int64); npc = np.diff(prob.piece_off).astype(np.int64)
+    nvert = np.array([sum(v.shape[1] for v in c.v_polys[1::2]) for c in cands], dtype=np.int64)
+    steps = np.array([max(int(np.ceil(np.log2(max(n - 1, 1)))), 0) for n in npc], dtype=np.int64)
+    fwd_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + (8 * steps + 4) * 8 * npc))
+    adj_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + 160 * npc + (8 * steps + 4) * 8 * npc + 8 * nx + 8))
+    stage_bytes = {"forward": fwd_bytes, "penalty": alg_bytes, "adjoint": adj_bytes}
+    dominant = max(stage_us, key=stage_us.get)
+    dom_kernel = {"forward": "frx::k_forward_knot", "penalty": "frx::k_penalty", "adjoint": "frx::k_backward_knot"}[dominant]
+    dom_achieved = stage_bytes[dominant] / (stage_us[dominant] * 1e-6) / 1e9
+    # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
+    fp64 = None
+    fc = os.path.join(ROOT, "profiles", "r02_fp64_count_k_penalty.json")
+    if os.path.exists(fc):
+        fj = json.load(open(fc))
+        fl = fj["flops_per_sample_no_violation"]
+        fp64 = {"flops_per_sample": fl, "flops_per_sample_all_corridor_planes_violated": fj["flops_per_sample_all_violated"], "source": "profiles/r02_fp64_count_k_penalty.json",
+                "achieved_tflops": fl * samples_per_step / (pen_us * 1e-6) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
+                "frac": fl * samples_per_step / (pen_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS}
     # HBM traffic per launch of k_penalty from the committed PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # in separate runs, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): profiles/r01_pmc_headline.json
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_headline.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_headline.json")
+    if not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_headline.json")
     if os.path.exists(pmc_file) and args.config == "headline":
         pj = json.load(open(pmc_file))
-        traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_pmc_headline.json"
+        traffic, traffic_src = pj["traffic_bytes_per_launch"], os.path.relpath(pmc_file, ROOT)
 
     # VALU utilisation of the same kernel from the committed counter pass (scripts/gpu_pmc_valu.sh): the path is FP64-issue
     # bound, not HBM bound (SURVEY.md 8d asks for the FP64 VALU fraction next to the HBM one)
@@ -190,6 +213,7 @@ def main():
     # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
     # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
     large = None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if args.large_batch > 0 and rank == 0:
         rep = max(1, args.large_batch // B)
         big = frx.Problem(cands * rep, params, device=local_rank, qd_intervals=kappa)
@@ -205,6 +229,7 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / 30
         large = {"candidates": big.B, "avg_kernel_us": us, "achieved": big.algorithmic_bytes() / (us * 1e-6) / 1e9, "unit": "GB/s",
                  "frac": big.algorithmic_bytes() / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_samples_per_s": big.samples() / (us * 1e-6)}
+        if fp64: large["fp64_frac"] = fp64["flops_per_sample"] * big.samples() / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS
         big.close(); del Tb, Cb, ob_
 
     # the HBM-bound kernel of the path: the L-BFGS two-loop recursion (k_lbfgs_pre) streams every candidate's (s, y) history twice
@@ -235,6 +260,14 @@ def main():
         t_guess = (time.perf_counter() - t_s) * 1e3
         p2.close()
         r = prob.optimize(params["opt_rel_tol"], x0=x0)
+        if rank == 0:
+            # the same plan with one launch per stage and round (the round-1 path), and the reference's real use: ONE candidate
+            prob.set_resident(False)
+            r_ps = prob.optimize(params["opt_rel_tol"], x0=x0)
+            prob.set_resident(True)
+            p1 = frx.Problem(cands[:1], params, device=local_rank, qd_intervals=kappa)
+            r_b1 = p1.optimize(params["opt_rel_tol"])
+            p1.close()
         if dist:                                                         # the job's plan time is the slowest rank's
             tm = torch.tensor([r["ms_total"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -242,7 +275,13 @@ def main():
         plan = {"plan_setup_ms": t_setup, "plan_initial_guess_ms": t_guess, "plan_ms_with_setup": r["ms_total"] + t_setup + t_guess,
                 "plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
-                "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min())}
+                "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min()),
+                "plan_path": ("resident round kernel, %d workgroups per candidate" % r["resident"]) if r["resident"] else "one launch per stage and round",
+                "plan_us_per_round": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
+        if rank == 0:
+            plan.update({"plan_ms_per_stage_path": r_ps["ms_total"], "plan_rounds_per_stage_path": r_ps["rounds"],
+                         "plan_ms_one_candidate": r_b1["ms_total"], "plan_rounds_one_candidate": r_b1["rounds"],
+                         "plan_path_one_candidate": "resident" if r_b1["resident"] else "per-stage"})
         # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
         from fast_racing_amd.dist import select_winner
         ids = np.arange(rank * B, rank * B + B)
@@ -253,7 +292,7 @@ def main():
         plan.update({"winner_id": gid, "winner_rank": owner, "winner_objective": obj, "winner_total_time_s": float(wT.sum())})
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cands, params, kappa, x_state, prob.x_off)
 
     if rank == 0:
@@ -266,11 +305,14 @@ def main():
                        "step": "one batched objective evaluation x->(f,grad): k_forward + k_penalty + k_backward, inputs resident in HBM",
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "frx::k_penalty", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_kernel_us": pen_us, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
-                         "traffic_source": traffic_src, "large_batch": large, "valu": valu, "hbm_bound_kernel": hbm_kernel,
-                         "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)},
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "selected_by": "longest of the three stage kernels (HIP events)", "achieved": dom_achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom_achieved / HBM_PEAK_GBS, "traffic": traffic if dominant == "penalty" else None,
+                         "algorithmic_bytes_per_launch": stage_bytes[dominant], "avg_kernel_us": stage_us[dominant],
+                         "stage_kernels_us": stage_us, "stage_algorithmic_bytes": stage_bytes,
+                         "penalty": {"kernel": "frx::k_penalty", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_kernel_us": pen_us, "traffic": traffic,
+                                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
+                                     "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6), "fp64": fp64, "large_batch": large, "valu": valu},
+                         "hbm_bound_kernel": hbm_kernel, "states": states},
             "cpu_baseline": cpu,
         }
         out.update(plan)

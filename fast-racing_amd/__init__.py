@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
     "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace", "frx_resident_profile",
-    "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
+    "frx_eval_stage_times", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def lib():
         L.frx_optimize_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
         L.frx_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.frx_resident_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.frx_eval_stage_times.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_multi_destroy.argtypes = [C.c_void_p]
         L.frx_multi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
@@ -393,6 +394,12 @@ class Problem:
         resident, dev_status = self.optimize_path()
         return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
                     ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status)
+
+    def stage_times(self, x, reps: int = 100):
+        """Average microseconds of the forward, penalty and adjoint kernels at x (HIP events inside the library)."""
+        out = np.zeros(3)
+        _check(lib().frx_eval_stage_times(self.h, np.ascontiguousarray(x, dtype=np.float64), reps, out))
+        return {"forward": float(out[0]), "penalty": float(out[1]), "adjoint": float(out[2])}
 
     def algorithmic_bytes(self) -> int:
         """Penalty-kernel bytes per evaluation, SURVEY.md §8d: sum over pieces of 312 + 48 K_i."""

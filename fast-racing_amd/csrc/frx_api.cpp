@@ -664,6 +664,41 @@ int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4
     return FRX_OK;
 }
 
+// Diagnostic (bench): average duration of each stage kernel of an evaluation at x, HIP events on the handle's stream around `reps`
+// back-to-back launches of ONE kernel at a time (the other stages run once before, so every kernel sees valid inputs).
+int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3_us) {
+    if (!p || !x || !out3_us || reps < 1) return fail(FRX_ERR_INVALID_ARG, "null argument or reps < 1");
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<double> f(p->B), g(p->NX);
+    int rc = frx_objective_eval(p, x, f.data(), g.data());               // d_x, d_T, d_C, d_out20, pcrw all valid afterwards
+    if (rc != FRX_OK) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    auto time_it = [&](int which, double &us) -> int {
+        for (int w = 0; w < 3; w++) {                                    // warm
+            hipError_t e = hipSuccess;
+            if (which == 0) e = (hipError_t)frx::launch_forward(p->dp, p->geo, p->d_x.p, p->d_T.p, p->d_C.p, p->d_band.p, p->stream);
+            if (which == 1) e = (hipError_t)frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, p->stream);
+            if (which == 2) e = (hipError_t)frx::launch_backward(p->dp, p->geo, p->d_x.p, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, p->d_f.p, p->d_g.p, p->stream);
+            if (e != hipSuccess) return fail(FRX_ERR_HIP, hipGetErrorString(e));
+        }
+        if (hipEventRecord(e0, p->stream) != hipSuccess) return fail(FRX_ERR_HIP, "hipEventRecord");
+        for (int r = 0; r < reps; r++) {
+            if (which == 0) (void)frx::launch_forward(p->dp, p->geo, p->d_x.p, p->d_T.p, p->d_C.p, p->d_band.p, p->stream);
+            if (which == 1) (void)frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, p->stream);
+            if (which == 2) (void)frx::launch_backward(p->dp, p->geo, p->d_x.p, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, p->d_f.p, p->d_g.p, p->stream);
+        }
+        if (hipEventRecord(e1, p->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return fail(FRX_ERR_HIP, "hipEventSynchronize");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return fail(FRX_ERR_HIP, "hipEventElapsedTime");
+        us = 1e3 * ms / reps;
+        return FRX_OK;
+    };
+    for (int k = 0; k < 3; k++) if ((rc = time_it(k, out3_us[k])) != FRX_OK) break;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int frx_problem_totals(const frx_problem *p, int *out6) {
     if (!p || !out6) return fail(FRX_ERR_INVALID_ARG, "null argument");
     out6[0] = p->B; out6[1] = p->P; out6[2] = p->Pc; out6[3] = p->NX; out6[4] = p->Kmax; out6[5] = p->sumKfine;

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
@@ -14,6 +15,7 @@ int launch_set_limits(const LaunchGeom &g) {
     if ((e = hipFuncSetAttribute((const void *)k_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_penalty, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
+    if ((e = hipFuncSetAttribute((const void *)k_penalty_occ4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_forward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_backward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
     return 0;
@@ -26,8 +28,9 @@ int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, d
     return (int)hipGetLastError();
 }
 int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, const double *C, double *out20, void *stream) {
-    hipLaunchKernelGGL(k_penalty, dim3((dp.P + g.ppw - 1) / g.ppw), dim3(64), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp,
-                       g.ppw, g.Kmax);
+    static const bool occ4 = [] { const char *e = std::getenv("FRX_PENALTY_WAVES"); return e && e[0] == '4'; }();
+    if (occ4) hipLaunchKernelGGL(k_penalty_occ4, dim3((dp.P + g.ppw - 1) / g.ppw), dim3(64), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppw, g.Kmax);
+    else hipLaunchKernelGGL(k_penalty, dim3((dp.P + g.ppw - 1) / g.ppw), dim3(64), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppw, g.Kmax);
     return (int)hipGetLastError();
 }
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,

@@ -247,9 +247,20 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     {
         const double *csrc = C + (size_t)gp0 * 18, *hsrc = dp.hblk + (size_t)gp0 * hstride;
         const int nc = npieces * 18, nh = npieces * hstride;
+        // 16-byte loads (corridor blocks and coefficient blocks are 16-byte multiples and 16-byte aligned in HBM); the LDS side is written
+        // as two 8-byte stores because a wave's private LDS region may start on an odd double
+        {
+            const double2 *h2 = (const double2 *)hsrc;
+            const int nh2 = nh >> 1;
 #pragma unroll 4
-        for (int i = lane; i < nh; i += 64) hS[i] = hsrc[i];
-        for (int i = lane; i < nc; i += 64) cS[i] = ldg<SH>(csrc + i);
+            for (int i = lane; i < nh2; i += 64) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }
+        }
+        if (SH) { for (int i = lane; i < nc; i += 64) cS[i] = ldg<SH>(csrc + i); }
+        else {
+            const double2 *c2p = (const double2 *)csrc;
+            const int nc2 = nc >> 1;
+            for (int i = lane; i < nc2; i += 64) { const double2 v = c2p[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }
+        }
         if (lane < npieces) tS[lane] = ldg<SH>(T + gp0 + lane);
     }
     __syncthreads();
@@ -300,6 +311,14 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
 }
 __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
                                                    double *__restrict__ out20, int lpp, int ppw, int Kmax) {
+    extern __shared__ double sm[];
+    const int gp0 = blockIdx.x * ppw;
+    penalty_body<false>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
+}
+// The same kernel under a 128-VGPR budget (4 waves per SIMD instead of 3; the compiler spills 30 VGPRs = 124 bytes of scratch per lane to
+// get there).  Selected with FRX_PENALTY_WAVES=4 for measurement; DESIGN.md 6 has the numbers and the default.
+__global__ __launch_bounds__(64, 4) void k_penalty_occ4(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                        double *__restrict__ out20, int lpp, int ppw, int Kmax) {
     extern __shared__ double sm[];
     const int gp0 = blockIdx.x * ppw;
     penalty_body<false>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);

@@ -194,6 +194,10 @@ int frx_problem_set_lbfgs_mode(frx_problem *p, int mode);
 #define FRX_SOLVER_BANDED_LU 1
 int frx_problem_set_solver(frx_problem *p, int solver);
 
+/* Diagnostic (bench): average microseconds of each stage kernel of an evaluation at x - {forward, penalty, adjoint} - over `reps`
+ * back-to-back launches of one kernel at a time, HIP events on the handle's stream. */
+int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3_us);
+
 /* Diagnostic: runs one evaluation at x and returns shader-clock stamps taken at the phase boundaries of candidate 0's
  * k_forward_knot (out32[0..6]) and k_backward_knot (out32[16..24]). */
 int frx_profile_phases(frx_problem *p, const double *x, long long *out32);
