@@ -1089,6 +1089,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         std::memcpy((void *)(hc + 2 * b + 1), &step, sizeof(double));
         std::atomic_thread_fence(std::memory_order_release);
         ++seq[b];
+        if (step == 1.0 && !(flags & 128)) flags |= 64;                                // DV_STEP_IS_ONE: lets the leader confirm a predicted command from this word alone
         hc[2 * b] = (seq[b] << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
         ncmd[b]++;
     };

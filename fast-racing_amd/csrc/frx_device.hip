@@ -73,7 +73,11 @@ int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void
     return (int)hipGetLastError();
 }
 
-static int round_ct_doubles(const LaunchGeom &g) { return (g.maxN * 19 + 1) & ~1; }
+// leader's resident LDS operands: (C, T) copy, x, waypoint polytopes, direction, reduction multipliers (ResidentOps)
+static int round_ct_doubles(const LaunchGeom &g) {
+    const int xpad = (g.maxXb + 1) & ~1, vpad = (g.maxVb + 1) & ~1, pw = (g.pcr_steps * 8 + 5) * g.knot_threads;
+    return ((g.maxN * 19 + 1) & ~1) + 2 * xpad + vpad + ((pw + 1) & ~1);
+}
 static int round_eval_doubles(const LaunchGeom &g) {
     const size_t pen = (size_t)g.ppw * 19 + (size_t)g.ppw * (g.Kmax + 1) * 4 + 64 * 21;              // doubles per wave (LaunchGeom::lds_pen)
     size_t e = std::max(g.lds_kfwd, g.lds_kbwd) / sizeof(double) + 2;
@@ -97,7 +101,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.timeout_ticks = r.timeout_ticks;
     a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms
     a.ls_ftol = r.ls_ftol; a.ls_gtol = r.ls_gtol; a.ls_min_step = r.ls_min_step; a.ls_max_step = r.ls_max_step; a.ls_max_linesearch = r.ls_max_linesearch; a.speculate = r.speculate;
-    a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g);
+    a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g); a.maxN19 = g.maxN * 19;
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;
     const void *fn = r.prof ? (const void *)k_round<ROUND_E, true> : (const void *)k_round<ROUND_E, false>;

@@ -54,6 +54,12 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
     else *p = v;
 }
 
+// Operands that a RESIDENT caller (frx_round_kernel.hpp, leader workgroup) keeps in LDS from round to round, so that the evaluation
+// bodies neither stage them from global memory nor send the reduction multipliers through it: xs = the candidate's variables,
+// vs = its waypoint polytopes, dsv = the search direction, pw = [nrow][8 steps + 5] multipliers (only used by the wave-specialised
+// reduction, nrow == 64).  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
+struct ResidentOps { double *xs, *vs, *dsv, *pw; };
+
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
 // `#pragma unroll 8` (one full memory latency per element and thread: 9.4k of the adjoint's 30k cycles, measured); clamped,
@@ -716,13 +722,15 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
                     MR2(buf ^ 1, 4, kk) = make_double2(U[0], U[1]); MR2(buf ^ 1, 5, kk) = make_double2(U[2], U[3]);
 #pragma unroll
                     for (int i = 0; i < 4; i++) { pw[kk * pws + it * 8 + i] = al[i]; pw[kk * pws + it * 8 + 4 + i] = be[i]; }
-                    double2 *sp = (double2 *)(save + (gk0 + kk) * sstride);
-                    sp[it * 4 + 0] = make_double2(al[0], al[1]); sp[it * 4 + 1] = make_double2(al[2], al[3]);
-                    sp[it * 4 + 2] = make_double2(be[0], be[1]); sp[it * 4 + 3] = make_double2(be[2], be[3]);
+                    double2 *sp = save ? (double2 *)(save + (gk0 + kk) * sstride) : nullptr;     // null: the multipliers stay in LDS (resident caller)
+                    if (sp) {
+                        sp[it * 4 + 0] = make_double2(al[0], al[1]); sp[it * 4 + 1] = make_double2(al[2], al[3]);
+                        sp[it * 4 + 2] = make_double2(be[0], be[1]); sp[it * 4 + 3] = make_double2(be[2], be[3]);
+                    }
                     if (it == nst - 1) {
 #pragma unroll
                         for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
-                        sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]);
+                        if (sp) { sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]); }
                     }
                 }
             }
@@ -735,10 +743,9 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
     if (wave == 0 && with_matrix && nst == 0 && act) {              // a single interior knot: no step, D^-1 straight away
         double I[4];
         m2_inv(D, I);
-        double2 *sp = (double2 *)(save + (gk0 + kk) * sstride);
 #pragma unroll
         for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
-        sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]);
+        if (save) { double2 *sp = (double2 *)(save + (gk0 + kk) * sstride); sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]); }
     }
     if (with_matrix && nst == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (wave >= 1 && act) {
@@ -753,7 +760,7 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
 // SH: T and C are consumed by OTHER workgroups of the same launch (see ldg / stg above).
 template <bool SH>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true) {
+                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr) {
     // ct_lds (optional, LDS, 19 doubles per piece: 18 coefficients + duration): a copy for the backward pass of the same workgroup
     const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
@@ -768,6 +775,8 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     double *xs = Tc + maxCN;                          // this candidate's variables (tau, xi), staged once
     double *vs = xs + maxXb;                          // this candidate's waypoint polytopes [v0, edges], waypoint order
     double *pwf = vs + maxVb;                          // [nrow][nsteps*8+5] reduction multipliers (wave-specialised path)
+    const bool wsp_path = nrow == 64 && nthr == 256;
+    if (ro) { xs = ro->xs; vs = ro->vs; if (wsp_path) pwf = ro->pw; }
 #define KN(arr, axis, idx) arr[(axis) * (nrow + 1) + (idx)]
     FRX_STAMP(0);
     // Every global read of the kernel is issued here, before the first barrier, so the whole kernel pays ONE memory
@@ -785,8 +794,10 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         const int nx = dp.xoff[b + 1] - x0;
         const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
         const double *vsrc = dp.vrec + 3 * (size_t)v0;
-        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
-        stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
+        if (!ro) {
+            stage_to_lds<4>(xs, x + x0, nx, k, nthr);
+            stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
+        }
     }
     __syncthreads();
     FRX_STAMP(1);
@@ -888,7 +899,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = me.r[i];
         }
         __syncthreads();
-        pcr_waves_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
+        pcr_waves_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
     } else {
         pcr_solve_wg(rowbuf, nrow, k, N, me, vk, ak, pcrw, (size_t)(nsteps * 8 + 4), (size_t)(p0 + k), nsteps);
         if (k >= 1 && k <= N - 1) {
@@ -923,7 +934,7 @@ template <bool SH>
 __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
-                                const LineSearchTap &tap, int b, double *sm, const double *ct_lds = nullptr) {
+                                const LineSearchTap &tap, int b, double *sm, const double *ct_lds = nullptr, const ResidentOps *ro = nullptr) {
     const int k = threadIdx.x, nthr = blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
@@ -940,6 +951,8 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     double *vs = xs + maxXb;
     double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by k_forward_knot
     double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
+    const bool pw_resident = ro && nrow == 64 && nthr == 256;
+    if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; if (pw_resident) pw = ro->pw; }
     const bool tapped = tap.d != nullptr;
     const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
     double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
@@ -969,11 +982,13 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         const int nx = dp.xoff[b + 1] - x0;
         const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
         const double *vsrc = dp.vrec + 3 * (size_t)v0;
-        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
-        stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
-        if (tapped) stage_to_lds<4>(dsv, tap.d + x0, nx, k, nthr);
+        if (!ro) {
+            stage_to_lds<4>(xs, x + x0, nx, k, nthr);
+            stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
+            if (tapped) stage_to_lds<4>(dsv, tap.d + x0, nx, k, nthr);
+        }
     }
-    {   // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
+    if (!pw_resident) {   // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
         const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
         const double2 *src = (const double2 *)(pcrw + (size_t)p0 * ws);
         for (int i0 = k; i0 < n2; i0 += 8 * nthr) {                          // same batching as stage_to_lds, 16-byte loads

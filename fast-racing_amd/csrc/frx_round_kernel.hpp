@@ -45,7 +45,8 @@ typedef unsigned long long rk_u64;
 
 enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3 };
 enum { RK_OK = 0, RK_ERR_CENSUS = 1, RK_ERR_HOST = 2, RK_ERR_PHASE = 3, RK_ERR_ARRIVE = 4, RK_ERR_DENSE = 5, RK_ERR_UFLAG = 6, RK_ERR_HOST_ABORT = 7, RK_ERR_SPECULATION = 8 };
-enum { DV_QUIT = 128 };                        // extra command flag of the resident kernel (frx_lbfgs.hpp: DV_* are < 32)
+enum { DV_QUIT = 128, DV_STEP_IS_ONE = 64 };   // extra command flags of the resident kernel (frx_lbfgs.hpp: DV_* are < 32); the second one lets the
+                                               // leader confirm a predicted command from the command WORD alone (no second read over PCIe)
 
 // host -> device: word = seq << 32 | bound << 20 | slot << 8 | flags (written last); step first.  device -> host: seq written last.
 struct RoundCmd { rk_u64 word; double step; };
@@ -92,7 +93,8 @@ struct RoundArgs {
     rk_u64 census_ticks;                     // bound of the start-up census (all workgroups resident)
     double ls_ftol, ls_gtol, ls_min_step, ls_max_step;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
     int ls_max_linesearch, speculate;
-    int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copy of (C, T) at the head of the eval scratch
+    int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
+    int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
 };
@@ -154,6 +156,18 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     double *ctlD = sm + L.ctl + 8, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
     double *x = a.x + v.xbase, *g = a.g + v.xbase, *xp = a.xp + v.xbase, *gp = a.gp + v.xbase, *dv = a.d + v.xbase;
     double *pub = v.pub, *dpub = v.dpub;
+    // operands the evaluation bodies find in LDS instead of staging them every call (ResidentOps): at the head of the leader's
+    // role region behind the (C, T) copy - x, the waypoint polytopes (constant), the direction, the reduction multipliers
+    const int xpad = (a.maxXb + 1) & ~1, vpad = (a.maxVb + 1) & ~1;
+    ResidentOps ro;
+    ro.xs = sm + L.role + ((a.maxN19 + 1) & ~1); ro.vs = ro.xs + xpad; ro.dsv = ro.vs + vpad; ro.pw = ro.dsv + xpad;
+    {
+        const int v0 = a.dp.cvoff[c], nvd = 3 * (a.dp.cvoff[c + 1] - v0);
+        const double *vsrc = a.dp.vrec + 3 * (size_t)v0;
+        for (int i = t; i < nvd; i += 256) ro.vs[i] = vsrc[i];
+        for (int i = t; i < n; i += 256) { ro.xs[i] = x[i]; ro.dsv[i] = 0.0; }
+        __syncthreads();
+    }
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
     unsigned pseq = 0, nphase = 0;
     rk_u64 hseq = 0;
@@ -175,7 +189,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
             spec_ready = false; unconfirmed = true;
             hseq++;
-            flags = (int)(pred_word & 0xFFu); jnew = (int)((pred_word >> 8) & 0xFFFu); bound = (int)((pred_word >> 20) & 0xFFFu);
+            flags = (int)(pred_word & 0xFFu) & ~(int)DV_STEP_IS_ONE; jnew = (int)((pred_word >> 8) & 0xFFFu); bound = (int)((pred_word >> 20) & 0xFFFu);
             step = 1.0;
             f_acc = ctlD[0];
             last_slot = jnew; last_bound = bound;
@@ -203,13 +217,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             __syncthreads();
             RK_PROF(RK_P_WAIT_HOST);
             const unsigned w = ctlU[1];
-            flags = (int)(w & 0xFFu); jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
+            flags = (int)(w & 0xFFu) & ~(int)DV_STEP_IS_ONE; jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
             step = ctlD[5];
             hseq++;
             __syncthreads();
             if (flags & DV_QUIT) kind = PH_QUIT;
             else if (flags & DV_RESTORE) {                                  // lbfgs.hpp:1287-1288; no evaluation follows
-                for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }
+                for (int i = t; i < n; i += 256) { const double xv = xp[i]; x[i] = xv; ro.xs[i] = xv; g[i] = gp[i]; }
                 rk_drain_and_meet();
                 if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
                 continue;
@@ -225,7 +239,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
                     f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
-                    for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
+                    for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; ro.dsv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
                 }
                 lstage = 1;
             }
@@ -233,12 +247,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (lstage == 1 && kind == 0) {
             if (flags & DV_TRIAL) {                                         // x = xp + step * d (lbfgs.hpp:825-826)
                 __syncthreads();
-                for (int i = t; i < n; i += 256) x[i] = xp[i] + step * dv[i];
+                for (int i = t; i < n; i += 256) { const double xv = xp[i] + step * dv[i]; x[i] = xv; ro.xs[i] = xv; }
             }
             if (flags & DV_EVAL) {
                 __syncthreads();                                            // (vmcnt(0) + barrier: x is complete and visible to this CU)
                 RK_PROF(RK_P_VECTORS);
-                forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt);
+                forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt, &ro);
                 kind = PH_CT; lstage = 2;
                 RK_PROF(RK_P_FORWARD);
             } else {
@@ -270,7 +284,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         }
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
             double acc = 0.0;
-            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
+            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; ro.dsv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
             const double ws = wave_sum_dpp(acc);
             if (lane == 0) pair[wave] = ws;
             __syncthreads();
@@ -279,24 +293,24 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             RK_PROF(RK_P_GATHER);
         }
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
+            rk_u64 early_w = 0;                                             // the host's command for a predicted round: read it while the adjoint runs
+            if (unconfirmed && t == 0) early_w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
-            backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl);
+            backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             rk_drain_and_meet();
             RK_PROF(RK_P_BACKWARD);
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
                     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                    rk_u64 w = 0;
+                    rk_u64 w = early_w;
                     bool ok = true;
-                    for (unsigned spins = 0;; spins++) {
+                    for (unsigned spins = 0; (w >> 32) != hseq; spins++) {
                         w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
-                        if ((w >> 32) == hseq) break;
                         if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                     }
                     unsigned verdict = 0u;                                   // 0 confirmed, 1 host stopped (QUIT), 2 anything else
                     if (!ok) { rk_fail(a, RK_ERR_HOST); verdict = 2u; }
                     else if ((unsigned)w != (unsigned)pred_word) verdict = ((unsigned)w & (unsigned)DV_QUIT) ? 1u : 2u;
-                    else if (__longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS)) != 1.0) verdict = 2u;
                     if (verdict == 2u) { rk_fail(a, RK_ERR_SPECULATION); __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
                     ctlU[1] = verdict;
                 }
@@ -333,7 +347,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                                     fv <= ftest1 && fabs(dgv) <= a.ls_gtol * (-dgi);
                 if (accept) {
                     const int nslot = last_slot < 0 ? 0 : (last_slot + 1 == v.m ? 0 : last_slot + 1), nbound = min(v.m, last_bound + 1);
-                    pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL);
+                    pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL | DV_STEP_IS_ONE);
                     spec_ready = true;
                 }
             }
