@@ -22,6 +22,7 @@
 #include "frx_device.hpp"
 #include "frx_minco.hpp"
 #include "frx_lbfgs.hpp"
+#include "frx_wave.hpp"
 
 namespace frx {
 
@@ -754,6 +755,119 @@ __device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, in
         KA[ax * (nrow + 1) + kk] = Di[2] * r0 + Di[3] * r1;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same wave specialisation for 65 .. 128 pieces (nrow = 128): TWO knots per lane (kk = lane and lane + 64).  Wave 0 reduces the
+// matrix rows of both its knots per step (two independent dependency chains: better issue utilisation than one), waves 1-3 carry
+// one axis each for both knots through LDS (pcr_axis_step), one step behind.  The adjoint solve (with_matrix = false) runs the
+// right-hand sides alone with the saved multipliers, also through LDS (lane shuffles would have to cross the two knot halves).
+// Before: 65+ pieces fell back to the one-lane-per-knot reduction with every wave idle but one per step.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pcr_waves2_wg(double *rowbuf, int nrow, int t, int N, bool with_matrix, double *pw, int pws, double *save, size_t sstride,
+                                              size_t gk0, int nsteps, double *KV, double *KA) {
+    double *rsb = rowbuf + (size_t)24 * nrow;
+    const int wave = t >> 6, lane = t & 63, ax = wave - 1;
+    int nst = 0;
+    for (int s = 1; s < N - 1; s <<= 1) nst++;
+    double D[2][4], L[2][4], U[2][4], r0[2] = {0.0, 0.0}, r1[2] = {0.0, 0.0};
+    bool act[2]; int kc[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) { const int kk = lane + 64 * h; act[h] = kk >= 1 && kk <= N - 1; kc[h] = act[h] ? kk : 1; }
+    if (wave == 0 && with_matrix) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double2 l0 = MR2(0, 2, kc[h]), l1 = MR2(0, 3, kc[h]), u0 = MR2(0, 4, kc[h]), u1 = MR2(0, 5, kc[h]), d0 = MR2(0, 0, kc[h]), d1 = MR2(0, 1, kc[h]);
+            L[h][0] = l0.x; L[h][1] = l0.y; L[h][2] = l1.x; L[h][3] = l1.y; U[h][0] = u0.x; U[h][1] = u0.y; U[h][2] = u1.x; U[h][3] = u1.y;
+            D[h][0] = d0.x; D[h][1] = d0.y; D[h][2] = d1.x; D[h][3] = d1.y;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double I[4];
+            m2_inv(D[h], I);
+            if (act[h]) { MR2(0, 0, lane + 64 * h) = make_double2(I[0], I[1]); MR2(0, 1, lane + 64 * h) = make_double2(I[2], I[3]); }
+        }
+    } else if (wave >= 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) { r0[h] = RS(0, ax, kc[h]); r1[h] = RS(0, 3 + ax, kc[h]); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int lag = with_matrix ? 1 : 0;                            // the right-hand side runs one step behind the matrix
+    for (int it = 0; it < nst + lag; it++) {
+        if (wave == 0) {
+            if (with_matrix && it < nst) {
+                const int s = 1 << it, buf = it & 1;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int kk = lane + 64 * h;
+                    const bool inlo = act[h] && kk - s >= 1, inhi = act[h] && kk + s <= N - 1;
+                    const int klo = inlo ? kk - s : kc[h], khi = inhi ? kk + s : kc[h];
+                    double2 q[12];
+#pragma unroll
+                    for (int f = 0; f < 6; f++) { q[f] = MR2(buf, f, klo); q[6 + f] = MR2(buf, f, khi); }
+                    double iLo[4], lL[4], lU[4], iHi[4], hL[4], hU[4], al[4], be[4], tt[4];
+                    iLo[0] = inlo ? q[0].x : 1.0; iLo[1] = inlo ? q[0].y : 0.0; iLo[2] = inlo ? q[1].x : 0.0; iLo[3] = inlo ? q[1].y : 1.0;
+                    lL[0] = inlo ? q[2].x : 0.0; lL[1] = inlo ? q[2].y : 0.0; lL[2] = inlo ? q[3].x : 0.0; lL[3] = inlo ? q[3].y : 0.0;
+                    lU[0] = inlo ? q[4].x : 0.0; lU[1] = inlo ? q[4].y : 0.0; lU[2] = inlo ? q[5].x : 0.0; lU[3] = inlo ? q[5].y : 0.0;
+                    iHi[0] = inhi ? q[6].x : 1.0; iHi[1] = inhi ? q[6].y : 0.0; iHi[2] = inhi ? q[7].x : 0.0; iHi[3] = inhi ? q[7].y : 1.0;
+                    hL[0] = inhi ? q[8].x : 0.0; hL[1] = inhi ? q[8].y : 0.0; hL[2] = inhi ? q[9].x : 0.0; hL[3] = inhi ? q[9].y : 0.0;
+                    hU[0] = inhi ? q[10].x : 0.0; hU[1] = inhi ? q[10].y : 0.0; hU[2] = inhi ? q[11].x : 0.0; hU[3] = inhi ? q[11].y : 0.0;
+                    m2_mul(L[h], iLo, al);                              // pcr_step_inv, matrix part
+                    m2_mul(U[h], iHi, be);
+                    m2_mul(al, lU, tt);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) D[h][i] = D[h][i] - tt[i];
+                    m2_mul(be, hL, tt);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) D[h][i] -= tt[i];
+                    m2_mul(al, lL, tt);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) L[h][i] = -tt[i];
+                    m2_mul(be, hU, tt);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) U[h][i] = -tt[i];
+                    double I[4];
+                    m2_inv(D[h], I);
+                    if (act[h]) {
+                        MR2(buf ^ 1, 0, kk) = make_double2(I[0], I[1]); MR2(buf ^ 1, 1, kk) = make_double2(I[2], I[3]);
+                        MR2(buf ^ 1, 2, kk) = make_double2(L[h][0], L[h][1]); MR2(buf ^ 1, 3, kk) = make_double2(L[h][2], L[h][3]);
+                        MR2(buf ^ 1, 4, kk) = make_double2(U[h][0], U[h][1]); MR2(buf ^ 1, 5, kk) = make_double2(U[h][2], U[h][3]);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { pw[kk * pws + it * 8 + i] = al[i]; pw[kk * pws + it * 8 + 4 + i] = be[i]; }
+                        double2 *sp = save ? (double2 *)(save + (gk0 + kk) * sstride) : nullptr;
+                        if (sp) {
+                            sp[it * 4 + 0] = make_double2(al[0], al[1]); sp[it * 4 + 1] = make_double2(al[2], al[3]);
+                            sp[it * 4 + 2] = make_double2(be[0], be[1]); sp[it * 4 + 3] = make_double2(be[2], be[3]);
+                        }
+                        if (it == nst - 1) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
+                            if (sp) { sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]); }
+                        }
+                    }
+                }
+            }
+        } else {
+            const int st = it - lag;
+            if (st >= 0 && st < nst) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) pcr_axis_step(rsb, nrow, lane + 64 * h, ax, N, 1 << st, st, pw, pws, r0[h], r1[h]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (wave >= 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int kk = lane + 64 * h;
+            if (act[h]) {
+                const double *Di = pw + kk * pws + nsteps * 8;
+                KV[ax * (nrow + 1) + kk] = Di[0] * r0[h] + Di[1] * r1[h];
+                KA[ax * (nrow + 1) + kk] = Di[2] * r0[h] + Di[3] * r1[h];
+            }
+        }
+    }
+}
 #undef MR2
 #undef RS
 
@@ -848,8 +962,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 q0 += V[3 * (a + 1)] * x2; q1 += V[3 * (a + 1) + 1] * x2; q2 += V[3 * (a + 1) + 2] * x2;
             }
         }
-        nrm += __shfl_xor(nrm, 1, 64); q0 += __shfl_xor(q0, 1, 64); q1 += __shfl_xor(q1, 1, 64); q2 += __shfl_xor(q2, 1, 64);
-        nrm += __shfl_xor(nrm, 2, 64); q0 += __shfl_xor(q0, 2, 64); q1 += __shfl_xor(q1, 2, 64); q2 += __shfl_xor(q2, 2, 64);
+        nrm = quad_sum(nrm); q0 = quad_sum(q0); q1 = quad_sum(q1); q2 = quad_sum(q2);
         if (wact && sub == 0) {
             const double sc = 2.0 / (1.0 + nrm), sc2 = sc * sc;
             KN(KP, 0, w + 1) = sc2 * q0 + V[0]; KN(KP, 1, w + 1) = sc2 * q1 + V[1]; KN(KP, 2, w + 1) = sc2 * q2 + V[2];
@@ -889,7 +1002,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         }
     }
     FRX_STAMP(4);
-    if (nrow == 64 && nthr == 256) {                               // wave-specialised reduction (pcr_waves_wg)
+    if ((nrow == 64 || nrow == 128) && nthr == 256) {              // wave-specialised reduction (pcr_waves_wg; two knots per lane above 64 pieces)
         if (k >= 1 && k <= N - 1) {
             double2 *mr = (double2 *)rowbuf;
             mr[(0 * 6 + 0) * nrow + k] = make_double2(me.D[0], me.D[1]); mr[(0 * 6 + 1) * nrow + k] = make_double2(me.D[2], me.D[3]);
@@ -899,7 +1012,8 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = me.r[i];
         }
         __syncthreads();
-        pcr_waves_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
+        if (nrow == 64) pcr_waves_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
+        else pcr_waves2_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
     } else {
         pcr_solve_wg(rowbuf, nrow, k, N, me, vk, ak, pcrw, (size_t)(nsteps * 8 + 4), (size_t)(p0 + k), nsteps);
         if (k >= 1 && k <= N - 1) {
@@ -1067,14 +1181,15 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
             }
         }
     FRX_STAMP(20);
-        const bool wsp = nrow == 64 && nthr == 256;                 // one wave per axis (pcr_waves_wg) writes mu to KV / KA itself
+        const bool wsp = (nrow == 64 || nrow == 128) && nthr == 256; // one wave per axis (pcr_waves_wg / pcr_waves2_wg) writes mu to KV / KA itself
         if (wsp) {
             if (k >= 1 && k <= N - 1) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = rr[i];
             }
             __syncthreads();
-            pcr_waves_wg(rowbuf, nrow, k, N, false, pw, nsteps * 8 + 5, nullptr, 0, 0, nsteps, KV, KA);
+            if (nrow == 64) pcr_waves_wg(rowbuf, nrow, k, N, false, pw, nsteps * 8 + 5, nullptr, 0, 0, nsteps, KV, KA);
+            else pcr_waves2_wg(rowbuf, nrow, k, N, false, pw, nsteps * 8 + 5, nullptr, 0, 0, nsteps, KV, KA);
         } else {
             pcr_apply_wg(rowbuf, nrow, k, N, rr, pw, nsteps);
         }
@@ -1126,7 +1241,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         sumTc += tt;
     }
     {
-        const double wc = wave_sum(costAcc), wt = wave_sum(sumTc);
+        const double wc = wave_sum_dpp(costAcc), wt = wave_sum_dpp(sumTc);
         const int nw = nthr >> 6, w = k >> 6;
         if ((k & 63) == 0) { red[w] = wc; red[nw + w] = wt; }
         __syncthreads();
@@ -1184,14 +1299,14 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
             g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
             for (int a = sub; a < nv1; a += 4) qn += xi[a] * xi[a];
         }
-        qn += __shfl_xor(qn, 1, 64); qn += __shfl_xor(qn, 2, 64);
+        qn = quad_sum(qn);
         const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;
         if (wact)
             for (int a = sub; a < nv1; a += 4) {
                 const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
                 gdq += gdr * xi[a];
             }
-        gdq += __shfl_xor(gdq, 1, 64); gdq += __shfl_xor(gdq, 2, 64);
+        gdq = quad_sum(gdq);
         if (wact)
             for (int a = sub; a < nv1; a += 4) {
                 const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
@@ -1202,7 +1317,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     }
     // ---- line-search tap: what lbfgs.hpp:830 (g.d) and :1296-1297 (|x|, |g|) need, reduced here instead of in a separate launch ----
     if (tap.d != nullptr) {                                           // uniform over the grid
-        const double w0 = wave_sum(t_dg), w1 = wave_sum(t_xx), w2 = wave_sum(t_gg);
+        const double w0 = wave_sum_dpp(t_dg), w1 = wave_sum_dpp(t_xx), w2 = wave_sum_dpp(t_gg);
         const int nw = nthr >> 6, w = k >> 6;
         __syncthreads();                                              // red[] was last read for f[b]
         double *red3 = rowbuf;                                        // row buffer is dead by now
