@@ -318,3 +318,65 @@ def test_zero_volume_and_unbounded_polytopes_are_rejected_like_the_reference(frx
     for bad in (touching, octant):
         with pytest.raises(RuntimeError):
             ob.Reference(sc.Candidate(st, fin, [bad], [box_v]), sc.ZHANGJIAJIE, override_vs=False, qd_intervals=8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU parity of the "next" rows against the oracle / the compiled reference (the -m gpu tests of f1-f3 were
+# self-comparisons)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_handle_built_from_h_polytopes_matches_the_oracle_on_the_device(frx, sc, ob):
+    """f1 end to end: the handle gets H-polytopes only (frx_problem_create_from_h enumerates cells and overlaps), the CPU oracle
+    gets the generator's V-polytopes: initial guess, objective and gradient agree to the per-evaluation tolerance, and a plan ends
+    with the reference's verdict."""
+    cands = sc.make_batch(6, 3, 24, 6, obstacles=True)
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=12, enumerate_v=True)
+    x0 = prob.initial_guess()
+    oracles = [ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=12) for c in cands]
+    for o in oracles: o.set_abscissa_mode(False)
+    f, g = prob.objective(x0)
+    for b, o in enumerate(oracles):
+        sl = slice(prob.x_off[b], prob.x_off[b + 1])
+        assert np.abs(x0[sl] - o.initial_guess()).max() < 1e-9
+        f_ref, g_ref = o.objective(x0[sl])
+        assert abs(f[b] - f_ref) <= 1e-9 * abs(f_ref)
+        assert np.abs(g[sl] - g_ref).max() <= 1e-9 * max(np.abs(g_ref).max(), abs(f_ref))
+    r = prob.optimize(1e-5)
+    for b, o in enumerate(oracles):
+        assert r["status"][b] == o.optimize(1e-5)["status"]
+    prob.close()
+
+
+@pytest.mark.gpu
+def test_device_plan_through_the_wire_format_matches_reference_types(frx, sc, ob):
+    """f3 end to end: a trajectory optimised ON THE DEVICE goes through frx_traj_to_msg / frx_msg_sample / frx_traj_max_rates and is
+    compared with the reference's own Trajectory / Piece code (trajectory.hpp + root_finder.hpp compiled unmodified,
+    oracle/_ref/libref_traj.so) evaluating the same coefficients: normalised coefficients 1e-13, sampled p/v/a/j 1e-9, max rates 1e-6."""
+    if ob.ref_traj() is None:
+        pytest.skip("oracle/_ref/libref_traj.so not built")
+    cands = sc.make_batch(8, 2, 32, 8)
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    r = prob.optimize(1e-5)
+    assert np.all(r["status"] >= 0)
+    for b in range(2):
+        sl = slice(prob.piece_off[b], prob.piece_off[b + 1])
+        T, Cf = r["T"][sl], r["C"][6 * sl.start:6 * sl.stop]
+        pl = ob.piece_layout(Cf)
+        cx, cy, cz, tm, od = msg = frx.traj_to_msg(T, Cf)
+        for i in range(len(T)):
+            out = np.zeros(18)
+            ob.ref_traj().ref_piece_normalized(float(T[i]), np.ascontiguousarray(pl[i].reshape(-1)), out)
+            got = np.stack([cx[6 * i:6 * i + 6], cy[6 * i:6 * i + 6], cz[6 * i:6 * i + 6]])
+            assert np.abs(got - out.reshape(3, 6)).max() <= 1e-13 * max(np.abs(out).max(), 1.0)
+        rng = np.random.default_rng(b)
+        for t in list(rng.uniform(0, T.sum(), 40)) + [0.0, float(T.sum())]:
+            want = [np.zeros(3) for _ in range(4)]
+            ob.ref_traj().ref_traj_eval(len(T), np.ascontiguousarray(T), np.ascontiguousarray(pl.reshape(-1)), float(t), *want)
+            for gv, w in zip(frx.msg_sample(msg, t), want):
+                assert np.abs(gv - w).max() <= 1e-9 * max(np.abs(w).max(), 1.0)
+        mv, ma = frx.traj_max_rates(T, Cf)
+        out3 = np.zeros(3)
+        ob.ref_traj().ref_traj_max_rates(len(T), np.ascontiguousarray(T), np.ascontiguousarray(pl.reshape(-1)), out3)
+        assert abs(mv.max() - out3[0]) <= 1e-6 * out3[0] and abs(ma.max() - out3[1]) <= 1e-6 * out3[1]
+        assert mv.max() <= 1.05 * sc.ZHANGJIAJIE["vel_max"]                  # the optimiser kept the speed limit (soft penalty)
+    prob.close()
