@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
     "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace", "frx_resident_profile",
-    "frx_eval_stage_times", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
+    "frx_eval_stage_times", "frx_dilate_batch", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def lib():
         L.frx_optimize_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
         L.frx_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.frx_resident_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.frx_dilate_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
         L.frx_eval_stage_times.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_multi_destroy.argtypes = [C.c_void_p]
@@ -192,6 +193,18 @@ def line_segment_dilate(p1, p2, bbox, obs, offset: float = 0.0):
     rec = np.zeros(6 * n.value); Cm = np.zeros(9); d = np.zeros(3)
     _check(lib().frx_line_segment_dilate(p1, p2, bbox, len(obs), op, offset, n.value, C.byref(n), rec.ctypes.data, Cm.ctypes.data, d.ctypes.data))
     return rec.reshape(-1, 6).T.copy(), Cm.reshape(3, 3), d
+
+
+def dilate_batch(p1, p2, bbox, obs, offset: float = 0.0, cap_planes: int = 96, device: int = 0):
+    """Corridor cells of a batch of segments on the device (frx_dilate_batch): list of (H 6 x K, C 3x3, d) per segment."""
+    p1 = np.ascontiguousarray(p1, dtype=np.float64).reshape(-1, 3); p2 = np.ascontiguousarray(p2, dtype=np.float64).reshape(-1, 3)
+    obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+    S = len(p1)
+    npl = np.zeros(S, np.int32); rec = np.zeros(S * cap_planes * 6); Cm = np.zeros(S * 9); d = np.zeros(S * 3)
+    _check(lib().frx_dilate_batch(device, S, p1.reshape(-1), p2.reshape(-1), np.ascontiguousarray(bbox, dtype=np.float64), len(obs),
+                                  obs.ctypes.data if len(obs) else None, offset, cap_planes, npl, rec, Cm, d))
+    rec = rec.reshape(S, cap_planes, 6)
+    return [(rec[s, :npl[s]].T.copy(), Cm[9 * s:9 * s + 9].reshape(3, 3).copy(), d[3 * s:3 * s + 3].copy()) for s in range(S)]
 
 
 def corridor_generate(path, obs, bbox, map_height: float, max_seg: float = 4.0, blocked=None, cap_polys: int = 4096, cap_planes: int = 1 << 18):

@@ -7,6 +7,7 @@
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
 #include "frx_round_kernel.hpp"
+#include "frx_corridor_kernels.hpp"
 
 namespace frx {
 
@@ -109,6 +110,19 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     if (e != hipSuccess) return (int)e;
     if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(8 * r.G * ((r.B + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(8 * r.G * ((r.B + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+size_t dilate_lds_bytes(int pcap) { return sizeof(double) * ((size_t)3 * pcap + 32 + 36 + 16) + sizeof(int) * ((size_t)2 * pcap + 257 + 3); }
+int launch_dilate(const DilateLaunch &d, void *stream) {
+    DilateArgs a;
+    a.p1 = d.p1; a.p2 = d.p2; a.obs = d.obs; a.bbox[0] = d.bbox[0]; a.bbox[1] = d.bbox[1]; a.bbox[2] = d.bbox[2]; a.offset = d.offset;
+    a.S = d.S; a.n_obs = d.n_obs; a.cap_planes = d.cap_planes; a.pcap = d.pcap;
+    a.n_planes = d.n_planes; a.h_rec = d.h_rec; a.ell_C = d.ell_C; a.ell_d = d.ell_d;
+    const size_t lds = dilate_lds_bytes(d.pcap);
+    hipError_t e = hipFuncSetAttribute((const void *)k_dilate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_dilate, dim3(d.S), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -95,4 +95,14 @@ size_t round_lds_bytes(const LaunchGeom &g, int m, int E);
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream);
 int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream);
 
+// ---- corridor cells on the device (frx_corridor_kernels.hpp) ----
+struct DilateLaunch {
+    const double *p1, *p2, *obs;            // device pointers: [S][3], [S][3], [n_obs][3]
+    double bbox[3], offset;
+    int S, n_obs, cap_planes, pcap;         // pcap: candidate points a workgroup can hold in LDS
+    int *n_planes; double *h_rec, *ell_C, *ell_d;
+};
+size_t dilate_lds_bytes(int pcap);
+int launch_dilate(const DilateLaunch &d, void *stream);
+
 } // namespace frx

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/frx.h"
+#include "frx_device.hpp"
 #include "frx_internal.hpp"
 
 namespace {
@@ -308,5 +309,44 @@ int frx_multi_optimize(frx_multi *m, const frx_lbfgs_params *params, double *x, 
 }
 
 int frx_multi_last_exchange(const frx_multi *m) { return m ? m->last_comm : 0; }
+
+// Device form of frx_line_segment_dilate for a batch of segments against one obstacle cloud (frx_corridor_kernels.hpp): host
+// buffers in and out, one workgroup per segment.  n_planes[s] = number of half-space records of segment s (tangent planes in the
+// reference's order, then the six planes of the local box).
+int frx_dilate_batch(int device, int n_seg, const double *p1, const double *p2, const double *bbox, int n_obs, const double *obs, double offset,
+                     int cap_planes, int *n_planes, double *h_rec, double *ell_C, double *ell_d) {
+    if (n_seg < 1 || !p1 || !p2 || !bbox || n_obs < 0 || (n_obs && !obs) || cap_planes < 6 || !n_planes || !h_rec)
+        return frx::set_error(FRX_ERR_INVALID_ARG, "frx_dilate_batch: null or out-of-range argument");
+    if (frx_device_count() < 1) return frx::set_error(FRX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (hipSetDevice(device) != hipSuccess) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_dilate_batch: device ordinal out of range");
+    const int pcap = 4096;                                                           // 4096 candidate points per cell: 96 KB of LDS + flags
+    double *d_p1 = nullptr, *d_p2 = nullptr, *d_obs = nullptr, *d_h = nullptr, *d_C = nullptr, *d_d = nullptr; int *d_np = nullptr;
+    auto cleanup = [&]() { for (void *q : {(void *)d_p1, (void *)d_p2, (void *)d_obs, (void *)d_h, (void *)d_C, (void *)d_d, (void *)d_np}) if (q) (void)hipFree(q); };
+    const size_t hb = sizeof(double) * 6 * (size_t)cap_planes * n_seg;
+    if (hipMalloc((void **)&d_p1, 24 * (size_t)n_seg) != hipSuccess || hipMalloc((void **)&d_p2, 24 * (size_t)n_seg) != hipSuccess ||
+        hipMalloc((void **)&d_obs, 24 * (size_t)std::max(n_obs, 1)) != hipSuccess || hipMalloc((void **)&d_h, hb) != hipSuccess ||
+        hipMalloc((void **)&d_C, 72 * (size_t)n_seg) != hipSuccess || hipMalloc((void **)&d_d, 24 * (size_t)n_seg) != hipSuccess || hipMalloc((void **)&d_np, 4 * (size_t)n_seg) != hipSuccess) {
+        cleanup();
+        return frx::set_error(FRX_ERR_ALLOC, "frx_dilate_batch: device buffers");
+    }
+    hipError_t e = hipMemcpy(d_p1, p1, 24 * (size_t)n_seg, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_p2, p2, 24 * (size_t)n_seg, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_obs) e = hipMemcpy(d_obs, obs, 24 * (size_t)n_obs, hipMemcpyHostToDevice);
+    frx::DilateLaunch L;
+    L.p1 = d_p1; L.p2 = d_p2; L.obs = d_obs; L.bbox[0] = bbox[0]; L.bbox[1] = bbox[1]; L.bbox[2] = bbox[2]; L.offset = offset;
+    L.S = n_seg; L.n_obs = n_obs; L.cap_planes = cap_planes; L.pcap = pcap; L.n_planes = d_np; L.h_rec = d_h; L.ell_C = d_C; L.ell_d = d_d;
+    if (e == hipSuccess) e = (hipError_t)frx::launch_dilate(L, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(n_planes, d_np, 4 * (size_t)n_seg, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_rec, d_h, hb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ell_C) e = hipMemcpy(ell_C, d_C, 72 * (size_t)n_seg, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ell_d) e = hipMemcpy(ell_d, d_d, 24 * (size_t)n_seg, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return frx::set_error(FRX_ERR_HIP, std::string("frx_dilate_batch: ") + hipGetErrorString(e));
+    for (int s = 0; s < n_seg; s++)
+        if (n_planes[s] < 0) return frx::set_error(FRX_ERR_CAPACITY, n_planes[s] == -1 ? "frx_dilate_batch: more than 4096 obstacle points inside one cell's local box"
+                                                                                         : "frx_dilate_batch: more half-spaces than cap_planes");
+    return FRX_OK;
+}
 
 } // extern "C"

@@ -145,6 +145,14 @@ int frx_corridor_generate(int n_path, const double *path, int n_obs, const doubl
                           double max_seg, frx_blocked_fn blocked, void *user, int cap_polys, int cap_planes, int *n_polys,
                           int *h_off, double *h_rec);
 
+/* The same cell on the DEVICE for a batch of segments against one obstacle cloud (csrc/frx_corridor_kernels.hpp): one workgroup per segment,
+ * the candidate points compacted in cloud order into LDS, every step of find_ellipsoid / find_polyhedron (decomp_util line_segment.h:136-214,
+ * decomp_base.h:63-83) = an arg-min and a filter over them on 256 lanes.  p1, p2: n_seg x 3; h_rec: n_seg x cap_planes x 6 (outer normal, point),
+ * n_planes[s] records of it valid (tangent planes in the reference's order, then the six planes of the local box); ell_C (n_seg x 9),
+ * ell_d (n_seg x 3) may be NULL.  FRX_ERR_CAPACITY when a cell's local box holds more than 4096 points or needs more than cap_planes planes. */
+int frx_dilate_batch(int device, int n_seg, const double *p1, const double *p2, const double *bbox, int n_obs, const double *obs, double offset,
+                     int cap_planes, int *n_planes, double *h_rec, double *ell_C, double *ell_d);
+
 /* Result wire format.  frx_traj_to_msg fills the array fields of quadrotor_msgs/PolynomialTrajectory the way
  * MavGlobalPlanner::traj2msg does (se3_planner.cpp:31-58): per piece 6 duration-normalised coefficients per axis, highest
  * power first (Piece::normalizePosCoeffMat, trajectory.hpp:131-141), time[] = durations, order[] = 5 (num_order = 5,

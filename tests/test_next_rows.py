@@ -380,3 +380,47 @@ def test_device_plan_through_the_wire_format_matches_reference_types(frx, sc, ob
         assert abs(mv.max() - out3[0]) <= 1e-6 * out3[0] and abs(ma.max() - out3[1]) <= 1e-6 * out3[1]
         assert mv.max() <= 1.05 * sc.ZHANGJIAJIE["vel_max"]                  # the optimiser kept the speed limit (soft penalty)
     prob.close()
+
+
+@pytest.mark.gpu
+def test_device_corridor_cells_match_reference_decomp(frx, ob):
+    """f2 on the device (frx_dilate_batch, one workgroup per segment) against the reference's LineSegment3D::dilate compiled from its own
+    headers (oracle/_ref/libref_decomp.so) and against the library's host form: same half-spaces (as sets: planes tangent at points ON the
+    final ellipsoid tie at distance 1), same ellipsoid, for a batch of 24 segments in one 3000-point cloud plus the edge cases of the CPU test
+    (vertical segment, empty cloud, tiny clouds)."""
+    rng = np.random.default_rng(77)
+    base = rng.uniform(-6, 6, (24, 3))
+    p1 = base.copy(); p2 = base + rng.normal(0, 1, (24, 3)) * np.array([3.0, 3.0, 0.6])
+    p2[3] = p1[3] + np.array([0.0, 0.0, 2.0])                                # vertical segment: degenerate branch of add_local_bbox
+    obs = []
+    while len(obs) < 3000:
+        s = rng.integers(24); u = rng.uniform(-0.3, 1.3)
+        q = p1[s] + u * (p2[s] - p1[s]) + rng.normal(0, 2.5, 3)
+        d = [np.linalg.norm(q - (p1[k] + np.clip((q - p1[k]) @ (p2[k] - p1[k]) / ((p2[k] - p1[k]) @ (p2[k] - p1[k])), 0, 1) * (p2[k] - p1[k]))) for k in range(24)]
+        if min(d) > 0.35:
+            obs.append(q)
+    obs = np.array(obs)
+    bbox = np.array([4.0, 4.0, 2.5])
+    cells = frx.dilate_batch(p1, p2, bbox, obs)
+    worst_h = worst_c = 0.0
+    for s in range(24):
+        H, Cm, d = cells[s]
+        Hh, Ch, dh = frx.line_segment_dilate(p1[s], p2[s], bbox, obs)          # host form of the library
+        assert H.shape == Hh.shape and np.abs(_canon(H) - _canon(Hh)).max() < 1e-9 and np.abs(Cm - Ch).max() < 1e-9
+        if ob.ref_decomp() is not None:
+            Hr, Cr, dr = ob.ref_line_segment_dilate(p1[s], p2[s], bbox, obs)
+            assert H.shape == Hr.shape, (s, H.shape, Hr.shape)
+            worst_h = max(worst_h, np.abs(_canon(H) - _canon(Hr)).max()); worst_c = max(worst_c, np.abs(Cm - Cr).max())
+            assert np.abs(d - dr).max() < 1e-12
+        for q in (p1[s], p2[s], 0.5 * (p1[s] + p2[s])):                        # the segment is inside its cell
+            assert np.all(np.einsum("dk,dk->k", H[:3], q[:, None] - H[3:]) <= 1e-9)
+    assert worst_h < 1e-9 and worst_c < 1e-9, (worst_h, worst_c)
+    print(f"24 cells, {sum(c[0].shape[1] for c in cells)} half-spaces: worst difference to the reference {worst_h:.2e} (planes) {worst_c:.2e} (ellipsoid)")
+    for n in (0, 1, 5):                                                      # empty / tiny clouds, zero bounding box
+        o = obs[:n]
+        (H, Cm, d), = frx.dilate_batch(p1[:1], p2[:1], bbox, o)
+        Hh, Ch, dh = frx.line_segment_dilate(p1[0], p2[0], bbox, o)
+        assert H.shape == Hh.shape and np.abs(_canon(H) - _canon(Hh)).max() < 1e-9
+    (H, Cm, d), = frx.dilate_batch(p1[:1], p2[:1], np.zeros(3), obs[:200])
+    Hh, _, _ = frx.line_segment_dilate(p1[0], p2[0], np.zeros(3), obs[:200])
+    assert H.shape == Hh.shape and np.abs(_canon(H) - _canon(Hh)).max() < 1e-9
