@@ -44,19 +44,22 @@ def _share_check(frx, sc, ob, cands, kappa, label):
     tol = sc.ZHANGJIAJIE["opt_rel_tol"]
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
     r = prob.optimize(tol)
-    variants = [(False, 0), (True, 0)]                       # CPU and CPU' (the two abscissa forms: a 1e-16 perturbation)
+    # CPU, CPU' (the two abscissa forms: a 1e-16 perturbation) and two more CPU runs whose x0 is moved by a few ulp: the spread of a
+    # heavy-tailed quantity needs more than two samples
+    variants = [(False, 0), (True, 0), (False, 11), (False, 12)]
     cpu = _cpu_plans(ob, sc, cands, kappa, tol, variants)
     spread, dev, bad_status, n_fail = [], [], [], 0
     for b, plans in enumerate(cpu):
-        sa, sb = plans[0]["status"], plans[1]["status"]
+        sts = [p["status"] for p in plans]
+        sa = sts[0]
         n_fail += sa < 0
-        ok = r["status"][b] == sa or (sa != sb and r["status"][b] == sb)      # path-sensitive candidates may take either CPU verdict
+        ok = r["status"][b] == sa or (len(set(sts)) > 1 and r["status"][b] in sts)   # path-sensitive candidates may take any CPU verdict
         if not ok:
-            bad_status.append((b, int(r["status"][b]), sa, sb))
-        if sa >= 0 and sb >= 0 and r["status"][b] >= 0:
-            oa, obb = plans[0]["objective"], plans[1]["objective"]
-            spread.append(abs(oa - obb) / abs(oa))
-            dev.append(min(abs(r["objective"][b] - oa), abs(r["objective"][b] - obb)) / abs(oa))
+            bad_status.append((b, int(r["status"][b]), sts))
+        if min(sts) >= 0 and r["status"][b] >= 0:
+            objs = np.array([p["objective"] for p in plans])
+            spread.append((objs.max() - objs.min()) / abs(objs[0]))
+            dev.append(np.abs(r["objective"][b] - objs).min() / abs(objs[0]))
     spread, dev = np.array(spread), np.array(dev)
     summary = {"config": label, "candidates": len(cands), "failed_on_cpu": int(n_fail), "status_mismatches": bad_status,
                "cpu_vs_cpu_objective_spread": {"median": float(np.median(spread)), "p95": float(np.percentile(spread, 95)), "max": float(spread.max())},
