@@ -65,6 +65,7 @@ ABI_SYMBOLS = [
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
     "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace", "frx_resident_profile",
     "frx_eval_stage_times", "frx_dilate_batch", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
+    "frx_map_mark_cloud", "frx_map_is_blocked", "frx_grid_search", "frx_jps_tables", "frx_jps_plan", "frx_route_plan",
 ]
 
 _lib = None
@@ -126,6 +127,13 @@ def lib():
         L.frx_optimize_stats.argtypes = [C.c_void_p, _dp]
         L.frx_lbfgs_minimize_batch.argtypes = [C.c_int, _ip, _dp, _dp, _ip, _ip, _ip, C.POINTER(LbfgsParams), BATCH_EVAL_FN,
                                                C.c_void_p, C.c_int]
+        _vp = C.c_void_p
+        L.frx_map_mark_cloud.argtypes = [C.c_double * 3, C.c_int * 3, C.c_double, C.c_int, _vp, _vp]
+        L.frx_map_is_blocked.argtypes = [_vp, _vp, _vp]
+        L.frx_grid_search.argtypes = [_vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+        L.frx_jps_tables.argtypes = [_vp] * 6
+        L.frx_jps_plan.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.frx_route_plan.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
         for name in ABI_SYMBOLS:
             fn = getattr(L, name)
             if name not in ("frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params",
@@ -210,11 +218,85 @@ def dilate_batch(p1, p2, bbox, obs, offset: float = 0.0, cap_planes: int = 96, d
 def corridor_generate(path, obs, bbox, map_height: float, max_seg: float = 4.0, blocked=None, cap_polys: int = 4096, cap_planes: int = 1 << 18):
     """Greedy safe-flight corridor along `path` (n x 3) in the point cloud `obs` (frx_corridor_generate): list of 6 x K_i arrays."""
     path = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, 3); obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
-    cb = BLOCKED_FN(lambda a, b, u: int(bool(blocked(np.array(a[:3]), np.array(b[:3]))))) if blocked else C.cast(None, BLOCKED_FN)
+    user = None
+    if isinstance(blocked, VoxelMap):  # MapUtil::isBlocked on the grid, without a round trip through Python
+        cb = C.cast(lib().frx_map_is_blocked, BLOCKED_FN); user = C.cast(C.pointer(blocked._s), C.c_void_p)
+    else:
+        cb = BLOCKED_FN(lambda a, b, u: int(bool(blocked(np.array(a[:3]), np.array(b[:3]))))) if blocked else C.cast(None, BLOCKED_FN)
     n = C.c_int(); h_off = np.zeros(cap_polys + 1, dtype=np.int32); h_rec = np.zeros(6 * cap_planes)
     _check(lib().frx_corridor_generate(len(path), path.reshape(-1), len(obs), obs.ctypes.data if len(obs) else None, np.ascontiguousarray(bbox, dtype=np.float64),
-                                       map_height, max_seg, cb, None, cap_polys, cap_planes, C.byref(n), h_off, h_rec))
+                                       map_height, max_seg, cb, user, cap_polys, cap_planes, C.byref(n), h_off, h_rec))
     return [h_rec[6 * h_off[k]:6 * h_off[k + 1]].reshape(-1, 6).T.copy() for k in range(n.value)]
+
+
+class VoxelMapStruct(C.Structure):
+    """frx_voxel_map (include/frx.h)."""
+    _fields_ = [("origin", C.c_double * 3), ("dim", C.c_int * 3), ("res", C.c_double), ("cells", C.c_void_p)]
+
+
+class VoxelMap:
+    """The occupancy grid of JPS::MapUtil<3> (map_util.h): origin, dim (cells per axis), res, cells[z][y][x] int8
+    (0 free, 100 occupied, -1 unknown)."""
+
+    def __init__(self, origin, dim, res: float, cells=None):
+        self.origin = np.asarray(origin, dtype=np.float64).copy(); self.dim = np.asarray(dim, dtype=np.int32).copy(); self.res = float(res)
+        n = int(self.dim[0]) * int(self.dim[1]) * int(self.dim[2])
+        self.cells = np.zeros(n, dtype=np.int8) if cells is None else np.ascontiguousarray(cells, dtype=np.int8).reshape(-1)
+        assert self.cells.size == n
+        self._s = VoxelMapStruct((C.c_double * 3)(*self.origin), (C.c_int * 3)(*[int(d) for d in self.dim]), self.res, self.cells.ctypes.data)
+
+    @classmethod
+    def from_params(cls, x_size: float, y_size: float, z_size: float, res: float = 0.1):
+        """MapUtil::setParam (map_util.h:48-70): origin (-x_size/2, -10, 0), dim = int(size / res)."""
+        return cls([-x_size / 2, -10.0, 0.0], [int(x_size / res), int(y_size / res), int(z_size / res)], res)
+
+    def mark_cloud(self, pts) -> int:
+        """frx_map_mark_cloud: the cells holding the points become occupied; returns how many points were inside."""
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        rc = lib().frx_map_mark_cloud(self._s.origin, self._s.dim, self.res, len(pts), pts.ctypes.data if len(pts) else None, self.cells.ctypes.data)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def is_blocked(self, a, b) -> bool:
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        return bool(lib().frx_map_is_blocked(a.ctypes.data, b.ctypes.data, C.byref(self._s)))
+
+    def plan(self, start, goal, eps: float = 1.0, use_jps: bool = False, cap: int = 1 << 16):
+        """frx_jps_plan -> dict(status, raw_path, path, sample_path, expanded)."""
+        start = np.ascontiguousarray(start, dtype=np.float64); goal = np.ascontiguousarray(goal, dtype=np.float64)
+        bufs = [np.zeros((cap, 3)) for _ in range(3)]; ns = [C.c_int() for _ in range(3)]; st = C.c_int(); ex = C.c_int()
+        _check(lib().frx_jps_plan(C.byref(self._s), start.ctypes.data, goal.ctypes.data, float(eps), int(use_jps), cap,
+                                  C.byref(ns[0]), bufs[0].ctypes.data, C.byref(ns[1]), bufs[1].ctypes.data, C.byref(ns[2]), bufs[2].ctypes.data,
+                                  C.byref(st), C.byref(ex)))
+        return dict(status=st.value, raw_path=bufs[0][:ns[0].value].copy(), path=bufs[1][:ns[1].value].copy(),
+                    sample_path=bufs[2][:ns[2].value].copy(), expanded=ex.value)
+
+    def route(self, start, goal, gates=(), eps: float = 1.0, use_jps: bool = False, threads: int = 0, cap: int = 1 << 18):
+        """frx_route_plan -> (path n x 3 (empty when a leg failed), leg_status, leg_expanded)."""
+        start = np.ascontiguousarray(start, dtype=np.float64); goal = np.ascontiguousarray(goal, dtype=np.float64)
+        gates = np.ascontiguousarray(gates, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((cap, 3)); n = C.c_int(); st = np.zeros(len(gates) + 1, dtype=np.int32); ex = np.zeros(len(gates) + 1, dtype=np.int32)
+        _check(lib().frx_route_plan(C.byref(self._s), start.ctypes.data, goal.ctypes.data, len(gates), gates.ctypes.data if len(gates) else None,
+                                    float(eps), int(use_jps), int(threads), cap, C.byref(n), out.ctypes.data, st.ctypes.data, ex.ctypes.data))
+        return out[:n.value].copy(), st, ex
+
+
+def grid_search(cmap, dim, start, goal, eps: float = 1.0, use_jps: bool = False, max_expand: int = -1, cap: int = 1 << 20):
+    """frx_grid_search on an int8 occupancy array (x fastest; dim[2] = 0 for 2-D): (path goal-first k x 3 int, expanded, cost)."""
+    cmap = np.ascontiguousarray(cmap, dtype=np.int8).reshape(-1)
+    dim = np.asarray(dim, dtype=np.int32); start = np.asarray(start, dtype=np.int32); goal = np.asarray(goal, dtype=np.int32)
+    path = np.zeros((cap, 3), dtype=np.int32); n = C.c_int(); ex = C.c_int(); cost = C.c_double()
+    _check(lib().frx_grid_search(cmap.ctypes.data, dim.ctypes.data, start.ctypes.data, goal.ctypes.data, float(eps), int(use_jps), int(max_expand),
+                                 cap, C.byref(n), path.ctypes.data, C.byref(ex), C.byref(cost)))
+    return path[:n.value].copy(), ex.value, cost.value
+
+
+def jps_tables():
+    """The jump-point neighbour tables in the reference's storage order (frx_jps_tables)."""
+    t = [np.zeros(s, dtype=np.int32) for s in ((27, 3, 26), (27, 3, 12), (27, 3, 12), (9, 2, 8), (9, 2, 2), (9, 2, 2))]
+    _check(lib().frx_jps_tables(*[a.ctypes.data for a in t]))
+    return t
 
 
 def dv_selftest(n, B=4, m=128, iters=140, geom=None, seed=0, device=0):

@@ -163,6 +163,47 @@ int frx_traj_to_msg(int n_pieces, const double *T, const double *C, double *coef
 int frx_msg_sample(int n_segment, const double *coef_x, const double *coef_y, const double *coef_z, const double *time,
                    const unsigned *order, double t, double *pos, double *vel, double *acc, double *jerk);
 
+/* Path-search front end on the voxel grid, host code (csrc/frx_search.cpp) -- the step of
+ * MavGlobalPlanner::plan that produces the polyline frx_corridor_generate takes (MinCoPlan_CPU.cpp:13-35).
+ * frx_voxel_map = what JPS::MapUtil<3> holds (map_util.h:48-75, setMap :365): cell (i,j,k) covers
+ * origin + [i,i+1) x [j,j+1) x [k,k+1) * res, stored x fastest; 0 = free, 100 = occupied, -1 = unknown (:322-327). */
+typedef struct frx_voxel_map {
+    double origin[3];
+    int dim[3];
+    double res;
+    const signed char *cells;
+} frx_voxel_map;
+/* MapUtil::GlobalMapBuild / setObs (map_util.h:86-136): mark the cells holding the cloud's points occupied (points outside
+ * the map are dropped).  Returns the number of points inside (>= 0) or a negative frx_status. */
+int frx_map_mark_cloud(const double *origin, const int *dim, double res, int n_pts, const double *pts, signed char *cells);
+/* MapUtil::isBlocked (map_util.h:395-425) with the signature of frx_blocked_fn: pass it to frx_corridor_generate with
+ * user = the frx_voxel_map.  1 when a cell at or above 100 lies on the 0.8-cell ray walk strictly between a and b. */
+int frx_map_is_blocked(const double *a, const double *b, void *map);
+/* JPS::GraphSearch::plan (graph_search.h:129-161, graph_search.cpp:79-236) on a dense occupancy array cmap (0 = free, > 0 =
+ * occupied, x fastest): A* (use_jps = 0; six face neighbours in 3-D, eight in 2-D -- the only mode plan_manage calls,
+ * MinCoPlan_CPU.cpp:15) or jump-point search (26 / 8 neighbours) with heuristic eps * Euclidean distance.  dim[2] = 0 selects
+ * the 2-D search.  The path comes back goal first, as GraphSearch::getPath() holds it, cell for cell the one the reference
+ * returns (same successor order, comparator and heap steps).  *n_path = 0 when the goal is unreachable or max_expand (> 0)
+ * expansions were spent; *cost = g of the goal.  FRX_ERR_CAPACITY when the path holds more than cap cells. */
+int frx_grid_search(const signed char *cmap, const int *dim, const int *start, const int *goal, double eps, int use_jps,
+                    int max_expand, int cap, int *n_path, int *path_xyz, int *n_expanded, double *cost);
+/* The jump-point neighbour tables in the reference's storage order (JPS3DNeib ns[27][3][26], f1/f2[27][3][12]; JPS2DNeib
+ * ns[9][2][8], f1/f2[9][2][2]; graph_search.h:72-127), generated from rules instead of spelled out; for the parity test. */
+int frx_jps_tables(int *ns3, int *f13, int *f23, int *ns2, int *f12, int *f22);
+/* JPSPlanner<3>::plan (jps_planner.cpp:333-420): cells of start and goal (must be free: *status = 1 / 2), grid search on the
+ * occupied/not-occupied view of the map (unknown cells are traversable, updateMap :309-323), *status = -1 when there is no
+ * path; then raw_path (cell centres, start first), path (removeCornerPts forwards and backwards, removeLinePts; :54-117) and
+ * sample_path (the centres of the cells the simplified path crosses, samplePath :118-148 = getSamplePath()).  Any output may
+ * be NULL; each holds up to cap points (3 doubles). */
+int frx_jps_plan(const frx_voxel_map *map, const double *start, const double *goal, double eps, int use_jps, int cap, int *n_raw,
+                 double *raw_path, int *n_path, double *path, int *n_sample, double *sample_path, int *status, int *n_expanded);
+/* The route of MavGlobalPlanner::plan through the gates (MinCoPlan_CPU.cpp:13-35): legs start -> gate 0 -> ... -> goal,
+ * each one frx_jps_plan's sample path, spliced with the shared point kept once.  Legs are independent and run on n_threads
+ * host threads (0 = one per core).  leg_status[n_gates + 1] as *status above; when a leg fails *n_out = 0 (the reference
+ * splices stale samples there). */
+int frx_route_plan(const frx_voxel_map *map, const double *start, const double *goal, int n_gates, const double *gates, double eps,
+                   int use_jps, int n_threads, int cap, int *n_out, double *path_out, int *leg_status, int *leg_expanded);
+
 /* Diagnostic: k_lbfgs_pre (device two-loop recursion) against a host two-loop recursion on random histories, and its
  * duration.  geom4 = {doubles/thread, waves, look-ahead rows, pairs per reduction} or NULL for the library's choice. */
 int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err,
