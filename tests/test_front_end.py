@@ -281,7 +281,7 @@ def test_voxel_map_to_trajectory_on_the_device(frx, sc):
     corridor with the grid's sight-line test (f2) -> vertices (f1) -> device optimiser -> message (f3).  The flown trajectory
     starts and ends where asked, stays inside the corridor (soft-constraint margin) and never enters an occupied cell."""
     rng = np.random.default_rng(11)
-    vm = frx.VoxelMap.from_params(16.0, 46.0, 2.8, 0.1)                          # 160 x 460 x 28 cells, origin (-8, -10, 0)
+    vm = frx.VoxelMap.from_params(16.0, 46.0, 2.8, 0.1)                          # origin (-8, -10, 0)
     pillars = []
     while len(pillars) < 45:
         c = np.array([rng.uniform(-7, 7), rng.uniform(-6, 32)])
@@ -289,7 +289,8 @@ def test_voxel_map_to_trajectory_on_the_device(frx, sc):
             pillars.append(c)
     cloud = np.array([[c[0] + dx, c[1] + dy, z] for c in pillars for dx in np.arange(-0.3, 0.31, 0.1) for dy in np.arange(-0.3, 0.31, 0.1)
                       for z in np.arange(0.05, 2.8, 0.1)])
-    assert vm.mark_cloud(cloud) == len(cloud)
+    assert vm.dim.tolist() == [160, 460, 27]                                     # int(2.8 / 0.1) = 27, as in the reference
+    assert vm.mark_cloud(cloud) == (cloud[:, 2] < 2.7).sum()                      # the top layer of points is above the map
     om = jo.Map(vm.origin, vm.dim, vm.res, vm.cells)
 
     def clear_point(y):
@@ -302,7 +303,7 @@ def test_voxel_map_to_trajectory_on_the_device(frx, sc):
     route, st, expanded = vm.route(start, goal, gates)
     assert st.tolist() == [0, 0, 0, 0] and len(route) > 300
     occ_cloud = np.array([om.int_to_float([int(v) for v in c]) for c in np.argwhere(vm.cells.reshape(vm.dim[::-1]) == 100)[:, ::-1]])
-    polys = frx.corridor_generate(route, occ_cloud, np.array([4.0, 4.0, 2.5]), 2.8, blocked=vm)
+    polys = frx.corridor_generate(route, occ_cloud, np.array([4.0, 4.0, 2.5]), 2.7, blocked=vm)
     assert 4 <= len(polys) <= 60
     ini = np.zeros((3, 3)); ini[:, 0] = route[0]
     fin = np.zeros((3, 3)); fin[:, 0] = route[-1]
