@@ -309,7 +309,7 @@ def test_voxel_map_to_trajectory_on_the_device(frx, sc):
     fin = np.zeros((3, 3)); fin[:, 0] = route[-1]
     cand = sc.Candidate(ini_state=ini, fin_state=fin, h_polys=polys, v_polys=[], gates=np.zeros((0, 3)))
     prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=8, enumerate_v=True)
-    r = prob.optimize(1e-5, max_iterations=2000)
+    r = prob.optimize(1e-5)
     assert r["status"][0] >= 0, r["status"]
     T = r["T"][:prob.P]; Cf = r["C"][:6 * prob.P]
     msg = frx.traj_to_msg(T, Cf)
