@@ -203,12 +203,14 @@ def main():
     # VALU utilisation of the same kernel from the committed counter pass (scripts/gpu_pmc_valu.sh): the path is FP64-issue
     # bound, not HBM bound (SURVEY.md 8d asks for the FP64 VALU fraction next to the HBM one)
     valu = None
-    valu_file = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
+    valu_file = os.path.join(ROOT, "profiles", "r02_pmc_headline.json")
     if os.path.exists(valu_file) and args.config == "headline":
-        vj = json.load(open(valu_file))["launch_classes"]
-        cls = sorted(vj.items(), key=lambda kv: kv[1]["SQ_WAVES"])
-        valu = {"source": "profiles/r01_pmc_valu.json", "headline_valu_busy": cls[0][1]["valu_busy_frac"],
-                "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"], "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"]}
+        vj = json.load(open(valu_file)).get("valu_3_waves_per_simd", {})
+        cls = sorted(vj.items(), key=lambda kv: int(kv[0].split("_")[1]))          # launch classes by grid size: headline, large batch
+        if cls:
+            valu = {"source": "profiles/r02_pmc_headline.json", "headline_valu_busy": cls[0][1]["valu_busy_frac"],
+                    "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"], "large_batch_waves_per_simd": cls[-1][1]["mean_waves_per_simd"],
+                    "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"]}
 
     # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
     # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
