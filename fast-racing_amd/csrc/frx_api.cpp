@@ -516,7 +516,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
 #undef CR
 
     frx::DevProblem &d = p->dp;
-    d.B = B; d.P = p->P; d.kappa = cfg->qd_intervals; d.soft = p->softT ? 1 : 0; d.c2 = cfg->c2_diffeo ? 1 : 0;
+    d.B = B; d.P = p->P; d.kappa = cfg->qd_intervals; d.inv_kappa = 1.0 / cfg->qd_intervals; d.soft = p->softT ? 1 : 0; d.c2 = cfg->c2_diffeo ? 1 : 0;
     d.rho = p->softT ? cfg->rho : 0.0;                                   // CPU.hpp:1098-1107
     d.sumT = p->softT ? 1.0 : cfg->total_t;
     d.pc.ell[0] = cfg->horiz_half_len; d.pc.ell[1] = cfg->horiz_half_len; d.pc.ell[2] = cfg->vert_half_len;

@@ -14,6 +14,7 @@ namespace frx {
 struct DevProblem {
     int B, P, kappa, soft, c2;
     double rho, sumT;
+    double inv_kappa;                         // 1 / kappa (quadrature weight, CPU.hpp:259)
     PenaltyConst pc;
     // per candidate
     const int *poff, *coff, *xoff, *boff;     // [B+1] fine pieces, coarse pieces, variables, band offsets (doubles)

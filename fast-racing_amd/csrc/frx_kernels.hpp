@@ -232,12 +232,23 @@ __global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__r
 // ---------------------------------------------------------------------------------------------
 // k_penalty: ONE WAVE per workgroup; the wave owns ppw = 64/lpp consecutive pieces, lpp = min(kappa+1, 64)
 // lanes per piece, lane = one quadrature sample (strided when kappa+1 > 64).
-// Every global read of the wave is an independent, contiguous, coalesced sweep issued up front (coefficients,
-// durations, and the pieces' corridor blocks hblk[gp] = {origin xyz, K | K x (unit normal, c)} padded to Kmax):
-// no index-dependent second round of loads, no block-wide barrier (PMC on the 4-wave version: 61 % of wave
-// cycles parked on s_waitcnt/s_barrier behind three dependent load rounds).
+// Every global read of the wave is an independent, contiguous, coalesced sweep (coefficients, durations, and the pieces'
+// corridor blocks hblk[gp] = {origin xyz, K | K x (unit normal, c)} padded to Kmax); the first trip of all three sweeps is in
+// flight before the first LDS store (one memory latency, not three): no index-dependent second round of loads, no block-wide
+// barrier (PMC on the 4-wave version: 61 % of wave cycles parked on s_waitcnt/s_barrier behind three dependent load rounds).
 // Dynamic LDS (doubles): cS[ppw*18] | tS[ppw] | hS[ppw*(Kmax+1)*4] | red[64*21]
 // ---------------------------------------------------------------------------------------------
+// View of doubles in LDS for penalty_sample (frx_math.hpp): a 32-bit LDS address, so every read is a ds_read_b64 (pairs merge into
+// ds_read2_b64) whatever the optimiser can or cannot prove about the pointer's address space, and fence() makes the address opaque:
+// what was read before it is not kept in registers across a phase boundary but read again.
+typedef const __attribute__((address_space(3))) double *lds_cdptr;
+struct LdsView {
+    unsigned off;
+    __device__ __forceinline__ explicit LdsView(const double *p) : off((unsigned)(uintptr_t)(lds_cdptr)p) {}
+    __device__ __forceinline__ double operator[](int i) const { return ((lds_cdptr)(uintptr_t)off)[i]; }
+    __device__ __forceinline__ void fence() { asm volatile("" : "+v"(off)); }
+};
+
 // The body works on the pieces [gp0, gp0 + npieces) with one WAVE and `sm` = that wave's private LDS; every wave of the workgroup
 // has to call it (it contains workgroup barriers), idle ones with npieces = 0.
 template <bool SH>
@@ -255,55 +266,69 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
         const double *csrc = C + (size_t)gp0 * 18, *hsrc = dp.hblk + (size_t)gp0 * hstride;
         const int nc = npieces * 18, nh = npieces * hstride;
         // 16-byte loads (corridor blocks and coefficient blocks are 16-byte multiples and 16-byte aligned in HBM); the LDS side is written
-        // as two 8-byte stores because a wave's private LDS region may start on an odd double
-        {
-            const double2 *h2 = (const double2 *)hsrc;
-            const int nh2 = nh >> 1;
-#pragma unroll 4
-            for (int i = lane; i < nh2; i += 64) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }
-        }
-        if (SH) { for (int i = lane; i < nc; i += 64) cS[i] = ldg<SH>(csrc + i); }
-        else {
+        // as two 8-byte stores because a wave's private LDS region may start on an odd double.  Trip 0 of every sweep first, into registers.
+        const double2 *h2 = (const double2 *)hsrc;
+        const int nh2 = nh >> 1, nc2 = nc >> 1;
+        double2 hv0 = make_double2(0.0, 0.0), hv1 = hv0, cv0 = hv0;
+        double ca = 0.0, cb = 0.0, tv = 0.0;
+        if (lane < nh2) hv0 = h2[lane];
+        if (lane + 64 < nh2) hv1 = h2[lane + 64];
+        if (SH) {                                                   // (C, T) come from another workgroup of the same launch: 8-byte L1-bypassing loads
+            if (lane < nc) ca = ldg<SH>(csrc + lane);
+            if (lane + 64 < nc) cb = ldg<SH>(csrc + lane + 64);
+        } else if (lane < nc2) cv0 = ((const double2 *)csrc)[lane];
+        if (lane < npieces) tv = ldg<SH>(T + gp0 + lane);
+        if (lane < nh2) { hS[2 * lane] = hv0.x; hS[2 * lane + 1] = hv0.y; }
+        if (lane + 64 < nh2) { hS[2 * lane + 128] = hv1.x; hS[2 * lane + 129] = hv1.y; }
+        if (SH) {
+            if (lane < nc) cS[lane] = ca;
+            if (lane + 64 < nc) cS[lane + 64] = cb;
+            for (int i = lane + 128; i < nc; i += 64) cS[i] = ldg<SH>(csrc + i);
+        } else {
+            if (lane < nc2) { cS[2 * lane] = cv0.x; cS[2 * lane + 1] = cv0.y; }
             const double2 *c2p = (const double2 *)csrc;
-            const int nc2 = nc >> 1;
-            for (int i = lane; i < nc2; i += 64) { const double2 v = c2p[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }
+            for (int i = lane + 64; i < nc2; i += 64) { const double2 v = c2p[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }
         }
-        if (lane < npieces) tS[lane] = ldg<SH>(T + gp0 + lane);
+        if (lane < npieces) tS[lane] = tv;
+#pragma unroll 2
+        for (int i = lane + 128; i < nh2; i += 64) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }      // corridor blocks beyond 2 KB per wave
     }
     __syncthreads();
 
     const bool active = pl < npieces && (pfl & DV_EVAL);
     double *mine = red + lane * 21;
     if (active) {
-        const double *c = cS + pl * 18;
-        const volatile double *c2 = c;                         // forces the late re-evaluation documented in frx_math.hpp
-        const double *hb = hS + (size_t)pl * hstride;
+        LdsView c(cS + pl * 18), hb(hS + (size_t)pl * hstride);
         const int K = (int)hb[3];
         const int kappa = dp.kappa;
         const double step = tS[pl] / kappa;                      // CPU.hpp:245
-        const double invK = 1.0 / kappa;
+        const double invK = dp.inv_kappa;
         bool first = true;
         for (int j = jl; j <= kappa; j += lpp) {
             const double s1 = step * j;                           // sample abscissa as cc.cu:152
             const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
             double adj[12], Ps, gTa;
-            penalty_sample(c, c2, s1, omg * step, dp.pc, hb, hb + 4, K, adj, Ps, gTa);
+            penalty_sample(c, s1, omg * step, dp.pc, hb, K, adj, Ps, gTa);
+            c.fence();
             FRX_PHASE();
-            // outputs go straight to this lane's LDS slot (nothing is kept in registers across samples)
-            const double v0 = omg * step * Ps, v1 = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
+            // the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates
+            double o[20];
+            o[0] = omg * step * Ps; o[1] = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
             const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
             const double b0[6] = {1.0, s1, s2, s3, s4, s5};
             const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
             const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
             const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
-            if (first) { mine[0] = v0; mine[1] = v1; } else { mine[0] += v0; mine[1] += v1; }
 #pragma unroll
             for (int k = 0; k < 6; k++)
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const double v = b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
-                    if (first) mine[2 + 3 * k + d] = v; else mine[2 + 3 * k + d] += v;
-                }
+                for (int d = 0; d < 3; d++) o[2 + 3 * k + d] = b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
+            if (!first) {
+#pragma unroll
+                for (int i = 0; i < 20; i++) o[i] += mine[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 20; i++) mine[i] = o[i];
             first = false;
         }
     }
@@ -311,8 +336,10 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     // fixed-order reduction over the samples of each piece: lane = (piece-in-wave, value)
     for (int idx = lane; idx < npieces * 20; idx += 64) {
         const int p2 = idx / 20, v = idx - p2 * 20;
+        const double *src = red + (p2 * lpp) * 21 + v;
         double s = 0.0;
-        for (int l = 0; l < lpp; l++) s += red[(p2 * lpp + l) * 21 + v];
+#pragma unroll 4
+        for (int l = 0; l < lpp; l++) s += src[l * 21];
         stg<SH>(out20 + (size_t)gp0 * 20 + idx, s, wt);
     }
 }

@@ -82,22 +82,45 @@ template <int D, class CP> FRX_HD void poly_eval(CP c, double s1, double *out) {
     }
 }
 
+// 1/sqrt(x).  Device: v_rsq_f64 (about 2^-23 relative) refined by one third-order and one second-order step - 9 instructions
+// instead of the ~26 of an IEEE sqrt followed by an IEEE division; relative error < 2^-51 (not correctly rounded: the reference's
+// 1/sqrt differs from it in the last bit at most, far inside the parity tolerances).  Host: the plain expression.
+FRX_HD double rsqrt_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+    e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
+// Read-only view of doubles behind a pointer; fence() is where a device view forgets what it has read (see LdsView in
+// frx_kernels.hpp).  The host and the generic device path use this one.
+struct PtrView {
+    const double *p;
+    FRX_HD double operator[](int i) const { return p[i]; }
+    FRX_HD void fence() {}
+};
+
 // One quadrature sample of piece coefficients c[k*3+d] (k = power, d = axis) at local time s1.
+//   c     = view of the 18 coefficients.  The sample is evaluated in PHASES (attitude -> half-space loop -> one derivative at a
+//           time) and c.fence() is called between them: on the device the view is an LDS address that is made opaque at every
+//           fence, so vel/acc/jer/sna and everything derived from them are evaluated AFTER the half-space loop from fresh
+//           ds_read_b64 pairs instead of being kept live across it (occupancy).  (Until round 2 the same effect came from a
+//           volatile-qualified generic pointer, which compiled to 60 serialised flat loads, each followed by s_waitcnt vmcnt(0).)
 //   ws    = omega * step  (trapezoid weight x step, CPU.hpp:245,306)
-//   hs    = K half-space records, 4 doubles each: (n_x, n_y, n_z, c) with unit normal and
-//           c = n.(p_k - org) - safeMargin, so that  n.(pos - p_k) + safeMargin = n.(pos - org) - c.
-//           `org` is a per-polytope origin (the point of its first half-space): the subtraction pos - org is
-//           done once per sample and keeps the magnitudes at corridor scale (metres), as pos - p_k does in
-//           CPU.hpp:325.
-//   c2    = the same coefficients again; the device passes a volatile-qualified alias of the LDS copy so that
-//           vel/acc/jer/sna and everything derived from them are evaluated AFTER the half-space loop from a
-//           fresh LDS read instead of being kept live across it (occupancy); the host passes c itself.
+//   hb    = view of the piece's corridor block: {origin xyz, K} then K records of 4 doubles (n_x, n_y, n_z, c) with unit normal
+//           and c = n.(p_k - org) - safeMargin, so that  n.(pos - p_k) + safeMargin = n.(pos - org) - c.
+//           The origin (the point of the polytope's first half-space) is subtracted once per sample and keeps the magnitudes at
+//           corridor scale (metres), as pos - p_k does in CPU.hpp:325.
 //   adj   = out: a0,a1,a2,a3 (12 doubles), already weighted by ws
 //   Psum  = out: sum of chi*viol^3 (not weighted)
 //   gTalpha = out: a0.v + a1.a + a2.j + a3.s  (to be multiplied by alpha = j/kappa)
-template <class CPtr2>
-FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, const PenaltyConst &pc, const double *org,
-                           const double *hs, int K, double *adj, double &Psum, double &gTalpha) {
+template <class CV, class HV>
+FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, HV hb, int K, double *adj, double &Psum, double &gTalpha) {
     // ---- phase A: position and attitude only (CPU.hpp:260-279); everything else is evaluated after the loop ----
     double pl[3], zB[3], yB[3], xB[3], invF, invM;
     {
@@ -105,13 +128,14 @@ FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, cons
         poly_eval<0>(c, s1, pos);
         poly_eval<2>(c, s1, acc);
         const double h[3] = {acc[0], acc[1], acc[2] + pc.gAcc};
-        invF = 1.0 / sqrt(dot3(h, h));
+        invF = rsqrt_fast(dot3(h, h));
 #pragma unroll
-        for (int d = 0; d < 3; d++) { zB[d] = h[d] * invF; pl[d] = pos[d] - org[d]; }
-        invM = 1.0 / sqrt(zB[2] * zB[2] + zB[1] * zB[1]);
+        for (int d = 0; d < 3; d++) { zB[d] = h[d] * invF; pl[d] = pos[d] - hb[d]; }
+        invM = rsqrt_fast(zB[2] * zB[2] + zB[1] * zB[1]);
         yB[0] = 0.0; yB[1] = zB[2] * invM; yB[2] = -zB[1] * invM;
         cross3(yB, zB, xB);
     }
+    c.fence();
     FRX_PHASE();
 
     double a0[3] = {0, 0, 0};
@@ -124,19 +148,19 @@ FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, cons
         const double e0 = pc.ell[0], e1 = pc.ell[1], e2 = pc.ell[2];
         double Pcorr = 0.0;
         for (int k = 0; k < K; k++) {
-            const double *rec = hs + 4 * k;
-            const double n[3] = {rec[0], rec[1], rec[2]};
+            const int r = 4 + 4 * k;
+            const double n[3] = {hb[r], hb[r + 1], hb[r + 2]};
             // (R^T n) .* ellipsoid
             const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
             const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
-            const double d0 = dot3(n, pl) - rec[3];                    // n.(pos - p_k) + safeMargin
+            const double d0 = dot3(n, pl) - hb[r + 3];                 // n.(pos - p_k) + safeMargin
             if (d0 >= 0.0 || eN2 > d0 * d0) {
-                const double eNorm = sqrt(eN2);
+                const double ir = rsqrt_fast(eN2), eNorm = eN2 * ir;
                 const double sd = d0 + eNorm;                          // CPU.hpp:325,328
                 if (sd > 0.0) {
                     const double sd2 = sd * sd;
                     const double cw = ws * pc.chi[0] * 3.0 * sd2;
-                    const double ie = cw / eNorm;
+                    const double ie = cw * ir;
                     const double cg0 = w0 * ie * e0, cg1 = w1 * ie * e1, cg2 = w2 * ie * e2;   // cw * eNormGd, CPU.hpp:324,326
 #pragma unroll
                     for (int d = 0; d < 3; d++) {
@@ -162,7 +186,7 @@ FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, cons
     double gT;
     {   // velocity limit (CPU.hpp:347-359)
         double vel[3];
-        poly_eval<1>(c2, s1, vel);
+        poly_eval<1>(c, s1, vel);
         gT = dot3(a0, vel);
         const double violaVel = dot3(vel, vel) - pc.vMaxSqr;
         double wV = 0.0;
@@ -174,15 +198,15 @@ FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, cons
 #pragma unroll
         for (int d = 0; d < 3; d++) adj[3 + d] = wV * vel[d];
     }
+    c.fence();
     FRX_PHASE();
     double h[3], wH = 0.0;                                      // weight on dSqrMagThr = 2h
     {   // thrust limits (CPU.hpp:361-385; both use chi[2])
         double acc[3];
-        poly_eval<2>(c2, s1, acc);
+        poly_eval<2>(c, s1, acc);
         gT += adj[3] * acc[0] + adj[4] * acc[1] + adj[5] * acc[2];
         h[0] = acc[0]; h[1] = acc[1]; h[2] = acc[2] + pc.gAcc;
-        const double fThr = sqrt(dot3(h, h));
-        const double sqrMagThr = fThr * fThr;
+        const double sqrMagThr = dot3(h, h);                   // the reference squares the square root of this (CPU.hpp:285-287): one rounding apart
         const double violaThrl = pc.thrMinSqr - sqrMagThr, violaThrh = sqrMagThr - pc.thrMaxSqr;
         if (violaThrl > 0.0) {
             const double v2 = violaThrl * violaThrl;
@@ -195,11 +219,12 @@ FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, cons
             P += pc.chi[2] * (v2 * violaThrh);
         }
     }
+    c.fence();
     FRX_PHASE();
     double a3[3] = {0, 0, 0};
     {   // body-rate limit (CPU.hpp:285-299, 387-398)
         double jer[3];
-        poly_eval<3>(c2, s1, jer);
+        poly_eval<3>(c, s1, jer);
         const double r0 = dot3(xB, jer), r1 = dot3(yB, jer);
         const double b0 = r0 * invF, b1 = r1 * invF;
         const double sqrMagBdr = b1 * b1 + b0 * b0;
@@ -226,16 +251,26 @@ FRX_HD void penalty_sample(const double *c, CPtr2 c2, double s1, double ws, cons
         for (int d = 0; d < 3; d++) a2[d] += 2.0 * wH * h[d];
         gT += dot3(a2, jer);
     }
+    c.fence();
     FRX_PHASE();
     {
         double sna[3];
-        poly_eval<4>(c2, s1, sna);
+        poly_eval<4>(c, s1, sna);
         gT += dot3(a3, sna);
     }
     Psum = P;
     gTalpha = gT;
 #pragma unroll
     for (int d = 0; d < 3; d++) { adj[d] = a0[d]; adj[6 + d] = a2[d]; adj[9 + d] = a3[d]; }
+}
+// Pointer form (host check, tests/hostcheck): coefficients c, origin org (3 doubles), K records hs (4 doubles each).
+FRX_HD void penalty_sample(const double *c, const double *, double s1, double ws, const PenaltyConst &pc, const double *org,
+                           const double *hs, int K, double *adj, double &Psum, double &gTalpha) {
+    struct Blk {                       // {origin xyz, K} + records, addressed like the device's corridor block
+        const double *org, *hs;
+        FRX_HD double operator[](int i) const { return i < 4 ? org[i < 3 ? i : 0] : hs[i - 4]; }
+    };
+    penalty_sample(PtrView{c}, s1, ws, pc, Blk{org, hs}, K, adj, Psum, gTalpha);
 }
 
 // C2 / exponential time diffeomorphism, forward and derivative (CPU.hpp:639-641, 826-839)

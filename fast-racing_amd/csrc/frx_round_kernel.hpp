@@ -40,6 +40,9 @@
 namespace frx {
 
 typedef unsigned long long rk_u64;
+// control words of a workgroup in LDS: volatile (re-read after every barrier) AND address-space qualified - through a generic volatile
+// pointer every access was a flat_load/flat_store with sc0 sc1 (the slow path to LDS)
+typedef volatile __attribute__((address_space(3))) unsigned *rk_ldsword;
 #define FRX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define FRX_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
@@ -152,7 +155,7 @@ template <bool PROF>
 __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
     const int c = v.c, t = v.t, lane = v.lane, wave = v.wave, n = v.n;
     const bool wt = v.wt;
-    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
+    rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
     double *ctlD = sm + L.ctl + 8, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
     double *x = a.x + v.xbase, *g = a.g + v.xbase, *xp = a.xp + v.xbase, *gp = a.gp + v.xbase, *dv = a.d + v.xbase;
     double *pub = v.pub, *dpub = v.dpub;
@@ -366,7 +369,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
     const int c = v.c, wg = v.wg, t = v.t, lane = v.lane, wave = v.wave, m = v.m;
     const bool wt = v.wt;
     const int hg = wg - 1;                                                  // history chunk of this workgroup (workgroups 1 .. G-2)
-    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
+    rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
     double *ctlD = sm + L.ctl + 8, *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *ev = sm + L.role + a.ct_doubles;
     double *pub = v.pub, *part = v.part, *upub = v.upub, *dpub = v.dpub;
     const int slot = t & 127, half = t >> 7;
@@ -482,7 +485,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
     const int c = v.c, t = v.t;
     const bool wt = v.wt;
     const int nh = a.G - 2;                                                 // history workgroups
-    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);
+    rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
     double *Rf = sm + L.Rf, *vd = sm + L.vd, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw, *vv = sm + L.vv,
            *mv = sm + L.mv, *mz = sm + L.mv + 256;
     double *pub = v.pub, *part = v.part, *upub = v.upub;
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     if (v.c >= a.B) return;                                               // grid is 8 G ceil(B / 8) blocks
     v.m = a.m;
     const RoundLds L = round_lds(a.m, CHT, a.eval_doubles);
-    volatile unsigned *ctlU = (volatile unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
+    rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
     v.xbase = a.dp.xoff[v.c]; v.n = a.dp.xoff[v.c + 1] - v.xbase;
     v.p0 = a.dp.poff[v.c]; v.N = a.dp.poff[v.c + 1] - v.p0;
     v.pub = a.pubsyg + (size_t)v.c * (3 * a.NXP + 2); v.part = a.part + (size_t)v.c * a.G * 512; v.upub = a.upub + (size_t)v.c * 258; v.dpub = a.dpub + (size_t)v.c * a.NXP;
