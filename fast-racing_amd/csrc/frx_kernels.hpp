@@ -664,119 +664,32 @@ __device__ __forceinline__ void pcr_axis_step(double *rsb, int nrow, int kk, int
     r0 = n0; r1 = n1;
     if (act) { RS(buf ^ 1, ax, kk) = r0; RS(buf ^ 1, 3 + ax, kk) = r1; }
 }
-// all 256 threads; `with_matrix`: wave 0 reduces the matrix rows found in MR2(0, ..) (and saves the multipliers to `save`), otherwise
-// pw already holds them.  RS(0, ..) holds the right-hand side.  Solution to KV / KA.
-__device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, int N, bool with_matrix, double *pw, int pws, double *save, size_t sstride,
-                                             size_t gk0, int nsteps, double *KV, double *KA) {
+// Right-hand sides alone with the multipliers in pw (the adjoint solve of <= 64 pieces; all 256 threads call it): RS(0, ..) holds the
+// right-hand side, the solution goes to KV / KA.  Lane = knot, so the neighbours k -+ s are lane shifts: the exchange goes through
+// the LDS crossbar (ds_bpermute, no memory, no barrier) and the three axis waves run their steps without meeting anyone.
+// (The forward reduction of the matrix is pcr_matrix_wave64 below.)
+__device__ __forceinline__ void pcr_waves_wg(double *rowbuf, int nrow, int t, int N, double *pw, int pws, int nsteps, double *KV, double *KA) {
     double *rsb = rowbuf + (size_t)24 * nrow;
     const int wave = t >> 6, kk = t & 63, ax = wave - 1;
     const bool act = kk >= 1 && kk <= N - 1;
     const int kc = act ? kk : 1;
     int nst = 0;
     for (int s = 1; s < N - 1; s <<= 1) nst++;
-    double D[4], L[4], U[4], r0 = 0.0, r1 = 0.0;
-    if (wave == 0 && with_matrix) {                                 // own row: D itself stays in registers, the buffer carries its inverse
-        const double2 l0 = MR2(0, 2, kc), l1 = MR2(0, 3, kc), u0 = MR2(0, 4, kc), u1 = MR2(0, 5, kc), d0 = MR2(0, 0, kc), d1 = MR2(0, 1, kc);
-        L[0] = l0.x; L[1] = l0.y; L[2] = l1.x; L[3] = l1.y; U[0] = u0.x; U[1] = u0.y; U[2] = u1.x; U[3] = u1.y;
-        D[0] = d0.x; D[1] = d0.y; D[2] = d1.x; D[3] = d1.y;       // the builder stored D here; replaced by its inverse below
-        double I[4];
-        m2_inv(D, I);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (act) { MR2(0, 0, kk) = make_double2(I[0], I[1]); MR2(0, 1, kk) = make_double2(I[2], I[3]); }
-    } else if (wave >= 1) {
-        r0 = RS(0, ax, kc); r1 = RS(0, 3 + ax, kc);
+    if (wave < 1) return;
+    double r0 = RS(0, ax, kc), r1 = RS(0, 3 + ax, kc);
+    for (int st = 0; st < nst; st++) {
+        const int s = 1 << st;
+        const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+        double ab[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
+        const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+        const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+        const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);    // pcr_rhs_step
+        const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+        r0 = n0; r1 = n1;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (!with_matrix) {
-        // right-hand sides alone (adjoint solve): lane = knot, so the neighbours k -+ s are lane shifts; the exchange goes through the
-        // LDS crossbar (ds_bpermute, no memory, no barrier) and the three axis waves run their six steps without meeting anyone
-        if (wave >= 1) {
-            for (int st = 0; st < nst; st++) {
-                const int s = 1 << st;
-                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
-                double ab[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
-                const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
-                const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
-                const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);    // pcr_rhs_step
-                const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
-                r0 = n0; r1 = n1;
-            }
-            if (act) {
-                const double *Di = pw + kk * pws + nsteps * 8;
-                KV[ax * (nrow + 1) + kk] = Di[0] * r0 + Di[1] * r1;
-                KA[ax * (nrow + 1) + kk] = Di[2] * r0 + Di[3] * r1;
-            }
-        }
-        return;
-    }
-    const int first_rhs = 1;                                        // the right-hand side lags one step behind the matrix
-    for (int it = 0; it < nst + first_rhs; it++) {
-        if (wave == 0) {
-            if (with_matrix && it < nst) {
-                const int s = 1 << it, buf = it & 1;
-                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
-                const int klo = inlo ? kk - s : kc, khi = inhi ? kk + s : kc;
-                double2 q[12];
-#pragma unroll
-                for (int f = 0; f < 6; f++) { q[f] = MR2(buf, f, klo); q[6 + f] = MR2(buf, f, khi); }
-                double iLo[4], lL[4], lU[4], iHi[4], hL[4], hU[4], al[4], be[4], tt[4];
-                iLo[0] = inlo ? q[0].x : 1.0; iLo[1] = inlo ? q[0].y : 0.0; iLo[2] = inlo ? q[1].x : 0.0; iLo[3] = inlo ? q[1].y : 1.0;
-                lL[0] = inlo ? q[2].x : 0.0; lL[1] = inlo ? q[2].y : 0.0; lL[2] = inlo ? q[3].x : 0.0; lL[3] = inlo ? q[3].y : 0.0;
-                lU[0] = inlo ? q[4].x : 0.0; lU[1] = inlo ? q[4].y : 0.0; lU[2] = inlo ? q[5].x : 0.0; lU[3] = inlo ? q[5].y : 0.0;
-                iHi[0] = inhi ? q[6].x : 1.0; iHi[1] = inhi ? q[6].y : 0.0; iHi[2] = inhi ? q[7].x : 0.0; iHi[3] = inhi ? q[7].y : 1.0;
-                hL[0] = inhi ? q[8].x : 0.0; hL[1] = inhi ? q[8].y : 0.0; hL[2] = inhi ? q[9].x : 0.0; hL[3] = inhi ? q[9].y : 0.0;
-                hU[0] = inhi ? q[10].x : 0.0; hU[1] = inhi ? q[10].y : 0.0; hU[2] = inhi ? q[11].x : 0.0; hU[3] = inhi ? q[11].y : 0.0;
-                m2_mul(L, iLo, al);                                 // pcr_step_inv, matrix part
-                m2_mul(U, iHi, be);
-                m2_mul(al, lU, tt);
-#pragma unroll
-                for (int i = 0; i < 4; i++) D[i] = D[i] - tt[i];
-                m2_mul(be, hL, tt);
-#pragma unroll
-                for (int i = 0; i < 4; i++) D[i] -= tt[i];
-                m2_mul(al, lL, tt);
-#pragma unroll
-                for (int i = 0; i < 4; i++) L[i] = -tt[i];
-                m2_mul(be, hU, tt);
-#pragma unroll
-                for (int i = 0; i < 4; i++) U[i] = -tt[i];
-                double I[4];
-                m2_inv(D, I);
-                if (act) {
-                    MR2(buf ^ 1, 0, kk) = make_double2(I[0], I[1]); MR2(buf ^ 1, 1, kk) = make_double2(I[2], I[3]);
-                    MR2(buf ^ 1, 2, kk) = make_double2(L[0], L[1]); MR2(buf ^ 1, 3, kk) = make_double2(L[2], L[3]);
-                    MR2(buf ^ 1, 4, kk) = make_double2(U[0], U[1]); MR2(buf ^ 1, 5, kk) = make_double2(U[2], U[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { pw[kk * pws + it * 8 + i] = al[i]; pw[kk * pws + it * 8 + 4 + i] = be[i]; }
-                    double2 *sp = save ? (double2 *)(save + (gk0 + kk) * sstride) : nullptr;     // null: the multipliers stay in LDS (resident caller)
-                    if (sp) {
-                        sp[it * 4 + 0] = make_double2(al[0], al[1]); sp[it * 4 + 1] = make_double2(al[2], al[3]);
-                        sp[it * 4 + 2] = make_double2(be[0], be[1]); sp[it * 4 + 3] = make_double2(be[2], be[3]);
-                    }
-                    if (it == nst - 1) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
-                        if (sp) { sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]); }
-                    }
-                }
-            }
-        } else {
-            const int st = it - first_rhs;
-            if (st >= 0 && st < nst) pcr_axis_step(rsb, nrow, kk, ax, N, 1 << st, st, pw, pws, r0, r1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    if (wave == 0 && with_matrix && nst == 0 && act) {              // a single interior knot: no step, D^-1 straight away
-        double I[4];
-        m2_inv(D, I);
-#pragma unroll
-        for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
-        if (save) { double2 *sp = (double2 *)(save + (gk0 + kk) * sstride); sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]); }
-    }
-    if (with_matrix && nst == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (wave >= 1 && act) {
+    if (act) {
         const double *Di = pw + kk * pws + nsteps * 8;
         KV[ax * (nrow + 1) + kk] = Di[0] * r0 + Di[1] * r1;
         KA[ax * (nrow + 1) + kk] = Di[2] * r0 + Di[3] * r1;
@@ -895,6 +808,102 @@ __device__ __forceinline__ void pcr_waves2_wg(double *rowbuf, int nrow, int t, i
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Forward reduction for <= 64 pieces, round-2 form: the matrix wave runs FREE.  All interior knots live in the 64 lanes of wave 0,
+// so its six reduction steps need no workgroup barrier at all (LDS operations of one wave complete in order); it publishes a
+// step counter in LDS behind each step's multipliers, and the three axis waves - which meanwhile evaluate the waypoint map and
+// build their right-hand sides - follow it step by step, exchanging neighbours by lane shifts.  Before, the matrix steps started
+// only after the waypoint map and the row assembly of the whole workgroup and every step ended in a workgroup barrier:
+// 11.1 k of the forward map's 19.4 k cycles.  Per step the wave also (i) takes the rows beyond the ends from an IDENTITY row (row 0,
+// knot 0 is not an unknown) instead of selecting 24 doubles lane by lane, (ii) uses the symmetry of the system, U_{k-s} = L_k^T and
+// L_{k+s} = U_k^T at every level (frx_minco.hpp: K is the Hessian of the jerk energy), instead of reading those blocks, and
+// (iii) inverts the 2x2 diagonal block with rcp_fast.
+// ---------------------------------------------------------------------------------------------
+typedef volatile __attribute__((address_space(3))) unsigned *lds_vuptr;
+__device__ __forceinline__ void lds_wait_ge(lds_vuptr w, unsigned want) {
+    while (*w < want) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+// wave 0 of the workgroup; kk = lane = knot.  hL / hR: durations of the pieces left and right of the knot (1.0 on lanes without a knot).
+// Executes exactly ONE s_barrier (after step 0, or after the final inverse when there is no step): the caller's axis waves meet it
+// there once their knot positions are in LDS.
+__device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N, double hL, double hR, double *pw, int pws, double *save, size_t sstride,
+                                                  size_t gk0, int nsteps, lds_vuptr progress) {
+    const int nrow = 64;
+    const bool act = kk >= 1 && kk <= N - 1;
+    int nst = 0;
+    for (int s = 1; s < N - 1; s <<= 1) nst++;
+    double D[4], L[4], U[4], I[4];
+    {
+        KnotRow me;
+        knot_row_matrix(hL, hR, me);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { D[i] = me.D[i]; L[i] = kk == 1 ? 0.0 : me.L[i]; U[i] = kk == N - 1 ? 0.0 : me.U[i]; }   // fixed end knots: their coupling is on the right-hand side
+    }
+    m2_inv_fast(D, I);
+    if (kk == 0) {                                                  // the identity row, in both buffers
+#pragma unroll
+        for (int buf = 0; buf < 2; buf++) {
+            MR2(buf, 0, 0) = make_double2(1.0, 0.0); MR2(buf, 1, 0) = make_double2(0.0, 1.0);
+#pragma unroll
+            for (int f = 2; f < 6; f++) MR2(buf, f, 0) = make_double2(0.0, 0.0);
+        }
+    } else if (act) {
+        MR2(0, 0, kk) = make_double2(I[0], I[1]); MR2(0, 1, kk) = make_double2(I[2], I[3]);
+        MR2(0, 2, kk) = make_double2(L[0], L[1]); MR2(0, 3, kk) = make_double2(L[2], L[3]);
+        MR2(0, 4, kk) = make_double2(U[0], U[1]); MR2(0, 5, kk) = make_double2(U[2], U[3]);
+    }
+    double2 *sp = save ? (double2 *)(save + (gk0 + kk) * sstride) : nullptr;     // null: the multipliers stay in LDS (resident caller)
+    for (int it = 0; it < nst; it++) {
+        const int s = 1 << it, buf = it & 1;
+        const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+        const int klo = inlo ? kk - s : 0, khi = inhi ? kk + s : 0;
+        const double2 a0 = MR2(buf, 0, klo), a1 = MR2(buf, 1, klo), a2 = MR2(buf, 2, klo), a3 = MR2(buf, 3, klo);
+        const double2 b0 = MR2(buf, 0, khi), b1 = MR2(buf, 1, khi), b4 = MR2(buf, 4, khi), b5 = MR2(buf, 5, khi);
+        const double iLo[4] = {a0.x, a0.y, a1.x, a1.y}, lL[4] = {a2.x, a2.y, a3.x, a3.y};
+        const double iHi[4] = {b0.x, b0.y, b1.x, b1.y}, hU[4] = {b4.x, b4.y, b5.x, b5.y};
+        const double Lt[4] = {L[0], L[2], L[1], L[3]}, Ut[4] = {U[0], U[2], U[1], U[3]};   // = U of the row below / L of the row above
+        double al[4], be[4], tt[4];
+        m2_mul(L, iLo, al);                                         // pcr_step_inv, matrix part
+        m2_mul(U, iHi, be);
+        m2_mul(al, Lt, tt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) D[i] = D[i] - tt[i];
+        m2_mul(be, Ut, tt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) D[i] -= tt[i];
+        m2_mul(al, lL, tt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) L[i] = -tt[i];
+        m2_mul(be, hU, tt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) U[i] = -tt[i];
+        m2_inv_fast(D, I);
+        if (act) {
+            MR2(buf ^ 1, 0, kk) = make_double2(I[0], I[1]); MR2(buf ^ 1, 1, kk) = make_double2(I[2], I[3]);
+            MR2(buf ^ 1, 2, kk) = make_double2(L[0], L[1]); MR2(buf ^ 1, 3, kk) = make_double2(L[2], L[3]);
+            MR2(buf ^ 1, 4, kk) = make_double2(U[0], U[1]); MR2(buf ^ 1, 5, kk) = make_double2(U[2], U[3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { pw[kk * pws + it * 8 + i] = al[i]; pw[kk * pws + it * 8 + 4 + i] = be[i]; }
+            if (sp) {
+                sp[it * 4 + 0] = make_double2(al[0], al[1]); sp[it * 4 + 1] = make_double2(al[2], al[3]);
+                sp[it * 4 + 2] = make_double2(be[0], be[1]); sp[it * 4 + 3] = make_double2(be[2], be[3]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kk == 0) *progress = (unsigned)(it + 1);
+        if (it == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (act) {                                                      // D^-1 of the decoupled rows
+#pragma unroll
+        for (int i = 0; i < 4; i++) pw[kk * pws + nsteps * 8 + i] = I[i];
+        if (sp) { sp[nsteps * 4] = make_double2(I[0], I[1]); sp[nsteps * 4 + 1] = make_double2(I[2], I[3]); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (kk == 0) *progress = (unsigned)(nst + 1);
+    if (nst == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 #undef MR2
 #undef RS
 
@@ -916,8 +925,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     double *xs = Tc + maxCN;                          // this candidate's variables (tau, xi), staged once
     double *vs = xs + maxXb;                          // this candidate's waypoint polytopes [v0, edges], waypoint order
     double *pwf = vs + maxVb;                          // [nrow][nsteps*8+5] reduction multipliers (wave-specialised path)
-    const bool wsp_path = nrow == 64 && nthr == 256;
-    if (ro) { xs = ro->xs; vs = ro->vs; if (wsp_path) pwf = ro->pw; }
+    if (ro) { xs = ro->xs; vs = ro->vs; if (nrow == 64 && nthr == 256) pwf = ro->pw; }
 #define KN(arr, axis, idx) arr[(axis) * (nrow + 1) + (idx)]
     FRX_STAMP(0);
     // Every global read of the kernel is issued here, before the first barrier, so the whole kernel pays ONE memory
@@ -925,11 +933,18 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     int r_pc = 0, r_piv = 1, r_wnv = 1, r_wvb = 0, r_wxb = 0;
     double r_bs[6] = {0, 0, 0, 0, 0, 0};
     if (k < N) { r_pc = dp.piece_coarse[p0 + k]; r_piv = dp.piece_iv[p0 + k]; }
-    if ((k >> 2) < N - 1) { const int gw = p0 - b + (k >> 2); r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }   // quad k>>2 = waypoint
-    if (k < 3) {
+    // waypoint w is handled by the quad k >> 2 - or, when wave 0 is the free-running matrix wave (wsp64 below), by the PAIR (k - 64) >> 1
+    const bool wsp64 = nrow == 64 && nthr == 256;
+    const int t2 = k - 64;                                         // index among the axis waves
+    const int wq = wsp64 ? (t2 >= 0 ? (t2 >> 1) : N) : (k >> 2);
+    if (wq < N - 1) { const int gw = p0 - b + wq; r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }
+    const int kbs = wsp64 ? t2 : k;                                // the three threads that place the fixed end states
+    if (kbs >= 0 && kbs < 3) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) { r_bs[q] = dp.headPVA[b * 9 + 3 * q + k]; r_bs[3 + q] = dp.tailPVA[b * 9 + 3 * q + k]; }
+        for (int q = 0; q < 3; q++) { r_bs[q] = dp.headPVA[b * 9 + 3 * q + kbs]; r_bs[3 + q] = dp.tailPVA[b * 9 + 3 * q + kbs]; }
     }
+    lds_vuptr progress = (lds_vuptr)(unsigned *)(rowbuf + (size_t)24 * nrow);   // step counter of the matrix wave (wsp64; the rhs buffers behind the rows are unused there)
+    if (wsp64 && k == 0) *progress = 0u;
     {   // coalesced staging: every later access is an LDS access (the per-waypoint loops would otherwise serialise
         // one global-memory latency per vertex)
         const int nx = dp.xoff[b + 1] - x0;
@@ -969,6 +984,103 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
     FRX_STAMP(2);
+    if (wsp64) {
+        // ---- <= 64 pieces: wave 0 = matrix wave (pcr_matrix_wave64), waves 1-3 = one axis each ----
+        const int wave = __builtin_amdgcn_readfirstlane(k >> 6), kk = k & 63;
+        const int pws = nsteps * 8 + 5;
+        if (wave == 0) {
+            // durations left and right of knot kk: the left one comes from the neighbouring lane (lane = piece = knot)
+            const double hLs = __shfl_up(hMine, 1, 64);
+            const bool act0 = kk >= 1 && kk <= N - 1;
+            pcr_matrix_wave64(rowbuf, kk, N, act0 ? hLs : 1.0, act0 ? hMine : 1.0, pwf, pws, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, progress);
+            FRX_STAMP(5);
+        } else {
+            const int ax = wave - 1;
+            // forwardP (CPU.hpp:729-747) on PAIRS of lanes of the axis waves: q = v0 + (2/(1+|xi|^2))^2 * sum_a V_a xi_a^2
+            for (int w0 = 0; w0 < N - 1; w0 += 96) {
+                const int w = w0 + (t2 >> 1), sub = t2 & 1;
+                double nrm = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
+                const bool wact = w < N - 1;
+                const double *V = vs, *xi = xs;
+                if (wact) {
+                    int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;          // prefetched for the first (usually only) pass
+                    if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
+                    const int nv1 = wnv - 1;
+                    V = vs + 3 * (wvb - dp.cvoff[b]);
+                    xi = xs + (wxb - x0);
+                    for (int a = sub; a < nv1; a += 2) {
+                        const double x2 = xi[a] * xi[a];
+                        nrm += x2;
+                        q0 += V[3 * (a + 1)] * x2; q1 += V[3 * (a + 1) + 1] * x2; q2 += V[3 * (a + 1) + 2] * x2;
+                    }
+                }
+                nrm += dpp_mov<0xB1>(nrm); q0 += dpp_mov<0xB1>(q0); q1 += dpp_mov<0xB1>(q1); q2 += dpp_mov<0xB1>(q2);   // pair sums
+                if (wact && sub == 0) {
+                    const double sc = 2.0 / (1.0 + nrm), sc2 = sc * sc;
+                    KN(KP, 0, w + 1) = sc2 * q0 + V[0]; KN(KP, 1, w + 1) = sc2 * q1 + V[1]; KN(KP, 2, w + 1) = sc2 * q2 + V[2];
+                }
+            }
+            if (t2 < 3) {                                  // fixed head / tail knot states (CPU.hpp:440-442, 497-499)
+                KN(KP, t2, 0) = r_bs[0]; KN(KV, t2, 0) = r_bs[1]; KN(KA, t2, 0) = r_bs[2];
+                KN(KP, t2, N) = r_bs[3]; KN(KV, t2, N) = r_bs[4]; KN(KA, t2, N) = r_bs[5];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // meets the matrix wave's only barrier: knot positions and Tf are in LDS
+            // right-hand side of knot kk for this axis (knot_row_rhs; the fixed end states move to the right-hand side)
+            const bool act = kk >= 1 && kk <= N - 1;
+            const int kc = act ? kk : 1;
+            double r0 = 0.0, r1 = 0.0;
+            if (act) {
+                const double hL = Tf[kk - 1], hR = Tf[kk];
+                knot_row_rhs(hL, hR, KN(KP, ax, kk) - KN(KP, ax, kk - 1), KN(KP, ax, kk + 1) - KN(KP, ax, kk), r0, r1);
+                if (kk == 1 || kk == N - 1) {
+                    KnotRow m0;
+                    knot_row_matrix(hL, hR, m0);
+                    if (kk == 1) {
+                        r0 -= m0.L[0] * KN(KV, ax, 0) + m0.L[1] * KN(KA, ax, 0);
+                        r1 -= m0.L[2] * KN(KV, ax, 0) + m0.L[3] * KN(KA, ax, 0);
+                    }
+                    if (kk == N - 1) {
+                        r0 -= m0.U[0] * KN(KV, ax, N) + m0.U[1] * KN(KA, ax, N);
+                        r1 -= m0.U[2] * KN(KV, ax, N) + m0.U[3] * KN(KA, ax, N);
+                    }
+                }
+            }
+            int nst = 0;
+            for (int s = 1; s < N - 1; s <<= 1) nst++;
+            for (int st = 0; st < nst; st++) {                             // pcr_rhs_step behind the matrix wave, neighbours by lane shifts
+                lds_wait_ge(progress, (unsigned)(st + 1));
+                const int s = 1 << st;
+                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                double ab[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[i] = pwf[kc * pws + st * 8 + i];
+                const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+                const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+                const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);
+                const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+                r0 = n0; r1 = n1;
+            }
+            lds_wait_ge(progress, (unsigned)(nst + 1));
+            double vK, aK;                                                 // (v, a) of knot kk on this axis
+            {
+                const double *Di = pwf + kc * pws + nsteps * 8;
+                vK = Di[0] * r0 + Di[1] * r1; aK = Di[2] * r0 + Di[3] * r1;
+            }
+            if (kk == 0) { vK = KN(KV, ax, 0); aK = KN(KA, ax, 0); }
+            double vR = __shfl_down(vK, 1, 64), aR = __shfl_down(aK, 1, 64);
+            if (kk == N - 1) { vR = KN(KV, ax, N); aR = KN(KA, ax, N); }
+            // piece coefficients of this axis (quintic Hermite): piece kk between knots kk and kk + 1
+            if (kk < N) {
+                double cq[6];
+                hermite_coeffs(Tf[kk], KN(KP, ax, kk), vK, aK, KN(KP, ax, kk + 1), vR, aR, cq);
+                double *co = Cout + (size_t)(p0 + kk) * 18;
+#pragma unroll
+                for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, cq[q], wt); if (ct_lds) ct_lds[kk * 19 + q * 3 + ax] = cq[q]; }
+            }
+        }
+        FRX_STAMP(6);
+        return;
+    }
     // forwardP (CPU.hpp:729-747): waypoint w (= knot w+1) is handled by a QUAD of lanes, each taking every 4th vertex;
     // q = v0 + (2/(1+|xi|^2))^2 * sum_a V_a xi_a^2 — one pass over the vertices, quad sums by DPP-class shuffles
     for (int w0 = 0; w0 < N - 1; w0 += nthr / 4) {
@@ -1029,7 +1141,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         }
     }
     FRX_STAMP(4);
-    if ((nrow == 64 || nrow == 128) && nthr == 256) {              // wave-specialised reduction (pcr_waves_wg; two knots per lane above 64 pieces)
+    if (nrow == 128 && nthr == 256) {                               // wave-specialised reduction with two knots per lane (<= 64 pieces: wsp64 above)
         if (k >= 1 && k <= N - 1) {
             double2 *mr = (double2 *)rowbuf;
             mr[(0 * 6 + 0) * nrow + k] = make_double2(me.D[0], me.D[1]); mr[(0 * 6 + 1) * nrow + k] = make_double2(me.D[2], me.D[3]);
@@ -1039,8 +1151,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = me.r[i];
         }
         __syncthreads();
-        if (nrow == 64) pcr_waves_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
-        else pcr_waves2_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
+        pcr_waves2_wg(rowbuf, nrow, k, N, true, pwf, nsteps * 8 + 5, pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, KV, KA);
     } else {
         pcr_solve_wg(rowbuf, nrow, k, N, me, vk, ak, pcrw, (size_t)(nsteps * 8 + 4), (size_t)(p0 + k), nsteps);
         if (k >= 1 && k <= N - 1) {
@@ -1215,7 +1326,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
                 for (int i = 0; i < 6; i++) rowbuf[(size_t)24 * nrow + i * nrow + k] = rr[i];
             }
             __syncthreads();
-            if (nrow == 64) pcr_waves_wg(rowbuf, nrow, k, N, false, pw, nsteps * 8 + 5, nullptr, 0, 0, nsteps, KV, KA);
+            if (nrow == 64) pcr_waves_wg(rowbuf, nrow, k, N, pw, nsteps * 8 + 5, nsteps, KV, KA);
             else pcr_waves2_wg(rowbuf, nrow, k, N, false, pw, nsteps * 8 + 5, nullptr, 0, 0, nsteps, KV, KA);
         } else {
             pcr_apply_wg(rowbuf, nrow, k, N, rr, pw, nsteps);
