@@ -99,7 +99,10 @@ def test_coefficient_spread_against_stopping_tolerance(frx, sc, ob, sid, N, gate
     as close to the CPU plans as those are to each other (coefficients and objective); the curve goes to DESIGN.md §4."""
     cand = sc.make_candidate(sid, N, gates)
     prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=kappa)
-    variants = [(False, 0), (True, 0), (False, 11), (False, 12)]
+    # 24 CPU-driven plans per tolerance: the outcome of the reference's stop rule is not just noisy but MULTI-MODAL (measured on the
+    # oracle, N = 32 at delta = 1e-8: 21 of 24 runs take 3900 ... 5400 iterations and end within 4.5e-5 of each other, 3 stop after
+    # 2900 ... 3300 iterations on a plateau 5.1e-4 ... 5.6e-4 higher); four samples miss the rarer mode more often than not
+    variants = [(False, 0), (True, 0)] + [(False, seed) for seed in range(11, 33)]
     rows = []
     for delta in (1e-6, 1e-8, 1e-10, 1e-12):
         r = prob.optimize(delta)
