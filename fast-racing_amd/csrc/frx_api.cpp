@@ -1041,7 +1041,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
         if ((e = p->d_pubsyg.alloc((size_t)B * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)B * G * 512)) != hipSuccess ||
             (e = p->d_upub.alloc((size_t)B * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)B * NXP)) != hipSuccess ||
-            (e = p->d_rwords.alloc((size_t)4 * B + 2 + (size_t)B * G)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)2 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
+            (e = p->d_rwords.alloc((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)2 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
@@ -1058,7 +1058,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     p->rprof.clear();
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
-    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)4 * B + 2 + (size_t)B * G), p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G), p->stream));
     std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 2 * B);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
@@ -1162,7 +1162,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         }
     }
     unsigned st[2] = {0, 0};
-    HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)4 * B, sizeof(st), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * B, sizeof(st), hipMemcpyDeviceToHost));
     p->resident_status = st[1];
     if (rc < 0) return rc;
     if (rc != FRX_OK || st[1] != 0) return 1;

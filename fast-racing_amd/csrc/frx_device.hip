@@ -74,14 +74,18 @@ int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void
     return (int)hipGetLastError();
 }
 
-// leader's resident LDS operands: (C, T) copy, x, waypoint polytopes, direction, reduction multipliers (ResidentOps)
+// leader's resident LDS operands: (C, T) copy, x, waypoint polytopes, direction, reduction multipliers (ResidentOps), then gradient,
+// previous point and previous gradient (rk_leader_loop)
 static int round_ct_doubles(const LaunchGeom &g) {
-    const int xpad = (g.maxXb + 1) & ~1, vpad = (g.maxVb + 1) & ~1, pw = (g.pcr_steps * 8 + 5) * g.knot_threads;
-    return ((g.maxN * 19 + 1) & ~1) + 2 * xpad + vpad + ((pw + 1) & ~1);
+    const int xpad = (g.maxXb + 1) & ~1, vpad = (g.maxVb + g.knot_threads + 1) & ~1, pw = (g.pcr_steps * 8 + 5) * g.knot_threads;
+    return ((g.maxN * 19 + 1) & ~1) + 5 * xpad + vpad + ((pw + 1) & ~1);
 }
 static int round_eval_doubles(const LaunchGeom &g) {
     const size_t pen = (size_t)g.ppw * 19 + (size_t)g.ppw * (g.Kmax + 1) * 4 + 64 * 21;              // doubles per wave (LaunchGeom::lds_pen)
     size_t e = std::max(g.lds_kfwd, g.lds_kbwd) / sizeof(double) + 2;
+    // <= 64 pieces: the evaluation bodies find x, polytopes, direction and multipliers in the resident operands, so their scratch ends
+    // behind the knot arrays (rows | knot arrays | Tf, gT | gCo | cross-wave partials)
+    if (g.knot_threads == 64) e = (size_t)36 * 64 + 9 * 65 + 2 * 64 + g.maxCN + 16;
     e = std::max(e, 4 * pen + 8);
     return (int)((e + 1) & ~(size_t)1) + round_ct_doubles(g);
 }
@@ -97,7 +101,8 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.pen_lds = g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21;
     a.x = r.x; a.g = r.g; a.xp = r.xp; a.gp = r.gp; a.d = r.d; a.f = r.f; a.T = r.T; a.C = r.C; a.out20 = r.out20; a.pcrw = g.pcrw;
     a.pubsyg = r.pubsyg; a.part = r.part; a.upub = r.upub; a.dpub = r.dpub; a.dbg = r.dbg;
-    a.phase = r.words; a.cntA = r.words + r.B; a.uflag = r.words + 2 * r.B; a.cntL = r.words + 3 * r.B; a.census = r.words + 4 * r.B; a.status = r.words + 4 * r.B + 1; a.xcc = r.words + 4 * r.B + 2;
+    a.phase = r.words; a.cntA = r.words + 32; a.uflag = r.words + 64; a.cntL = r.words + 96;                     // one 512-byte block per candidate, one 128-byte line per word
+    a.census = r.words + (size_t)RK_WORDS_PER_CAND * r.B; a.status = a.census + 1; a.xcc = a.census + 2;
     a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
     a.timeout_ticks = r.timeout_ticks;
     a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms

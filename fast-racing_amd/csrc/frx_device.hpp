@@ -82,7 +82,7 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 struct RoundLaunch {
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20;              // leader vectors and stage buffers (the handle's own)
     double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([B][3 NXP + 2], [B][G][512], [B][258], [B][NXP])
-    unsigned *words;                                               // [4 B + 2 + B G]: phase, cntA, uflag, cntL per candidate, then census, status, XCC ids
+    unsigned *words;                                               // [ROUND_WORDS_PER_CAND B + 2 + B G]: a 512-byte block per candidate (phase, cntA, uflag, cntL in separate lines), then census, status, XCC ids
     void *h_cmd, *h_res;                                           // mapped host mailboxes, [B] x 16 B and [B] x 64 B
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
@@ -90,7 +90,7 @@ struct RoundLaunch {
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;
 };
-enum { ROUND_E = 56 };                                             // history doubles per thread and array of the instantiated kernel
+enum { ROUND_E = 56, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E);
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream);

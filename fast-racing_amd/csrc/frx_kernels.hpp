@@ -58,8 +58,11 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
 // Operands that a RESIDENT caller (frx_round_kernel.hpp, leader workgroup) keeps in LDS from round to round, so that the evaluation
 // bodies neither stage them from global memory nor send the reduction multipliers through it: xs = the candidate's variables,
 // vs = its waypoint polytopes, dsv = the search direction, pw = [nrow][8 steps + 5] multipliers (only used by the wave-specialised
-// reduction, nrow == 64).  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
-struct ResidentOps { double *xs, *vs, *dsv, *pw; };
+// reduction, nrow == 64), gs = where the gradient goes.  vskew = 1: the polytope of waypoint w starts w doubles further on than in the
+// packed layout.  The blocks of consecutive waypoints are 3 nv doubles apart (36 for the 12-vertex overlaps of box corridors: a
+// multiple of 4 - the lanes of a wave, one waypoint per lane pair, then hit 8 of the 32 LDS double-banks, a four-way conflict on
+// every read of the waypoint map and of its adjoint, measured 2.7 k cycles for a 12-vertex pass); one double of skew makes the stride odd.  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
+struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g (no global store to drain behind the adjoint)
 
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
@@ -523,6 +526,8 @@ __global__ __launch_bounds__(64) void k_backward(DevProblem dp, const double *__
 // LDS (doubles): rows[2][18][nrow] (SoA, conflict-free) | KP,KV,KA [3][nrow+1] x 3 arrays | Tf[nrow] | Tc[maxCN] | red | xs | vs
 // =============================================================================================
 #define FRX_STAMP(slot) do { if (dp.stamps && b == 0 && k == 0) dp.stamps[slot] = (long long)__builtin_readcyclecounter(); } while (0)
+// the same from the first lane of axis wave 1 (thread 64): the axis waves' own timeline in the wave-specialised bodies
+#define FRX_STAMP_AX(slot) do { if (dp.stamps && b == 0 && k == 64) dp.stamps[slot] = (long long)__builtin_readcyclecounter(); } while (0)
 // Row buffer: [2][9][nrow] double2 - a block row is 18 doubles = 9 pairs (Dinv: 0,1; L: 2,3; U: 4,5; r: 6,7,8), one 16-byte LDS access
 // per pair, consecutive lanes consecutive addresses.  The buffer holds D^-1, not D: a neighbour only ever needs the inverse of this
 // row's diagonal block (alpha = L D_lo^-1), so the owner inverts once instead of both neighbours inverting the same block.
@@ -826,8 +831,9 @@ __device__ __forceinline__ void lds_wait_ge(lds_vuptr w, unsigned want) {
     asm volatile("" ::: "memory");
 }
 // wave 0 of the workgroup; kk = lane = knot.  hL / hR: durations of the pieces left and right of the knot (1.0 on lanes without a knot).
-// Executes exactly ONE s_barrier (after step 0, or after the final inverse when there is no step): the caller's axis waves meet it
-// there once their knot positions are in LDS.
+// Executes exactly ONE s_barrier (after its second step - or its last, or the final inverse, when there are fewer): the caller's axis
+// waves meet it there once their knot positions are in LDS (measured: they arrive ~2.6 k cycles after the durations are known, the
+// matrix wave's build + first step take 1.5 k).
 __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N, double hL, double hR, double *pw, int pws, double *save, size_t sstride,
                                                   size_t gk0, int nsteps, lds_vuptr progress) {
     const int nrow = 64;
@@ -893,7 +899,7 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (kk == 0) *progress = (unsigned)(it + 1);
-        if (it == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it == (nst > 1 ? 1 : 0)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the axis waves need about two steps' time for the waypoint map
     }
     if (act) {                                                      // D^-1 of the decoupled rows
 #pragma unroll
@@ -1006,12 +1012,15 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                     int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;          // prefetched for the first (usually only) pass
                     if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
                     const int nv1 = wnv - 1;
-                    V = vs + 3 * (wvb - dp.cvoff[b]);
+                    V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
                     xi = xs + (wxb - x0);
-                    for (int a = sub; a < nv1; a += 2) {
-                        const double x2 = xi[a] * xi[a];
-                        nrm += x2;
-                        q0 += V[3 * (a + 1)] * x2; q1 += V[3 * (a + 1) + 1] * x2; q2 += V[3 * (a + 1) + 2] * x2;
+                    for (int a0 = sub; a0 < nv1; a0 += 8) {               // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
+                        double xv[4], v0[4], v1[4], v2[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { const int a = min(a0 + 2 * j, nv1 - 1); xv[j] = xi[a]; v0[j] = V[3 * (a + 1)]; v1[j] = V[3 * (a + 1) + 1]; v2[j] = V[3 * (a + 1) + 2]; }
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (a0 + 2 * j < nv1) { const double x2 = xv[j] * xv[j]; nrm += x2; q0 += v0[j] * x2; q1 += v1[j] * x2; q2 += v2[j] * x2; }
                     }
                 }
                 nrm += dpp_mov<0xB1>(nrm); q0 += dpp_mov<0xB1>(q0); q1 += dpp_mov<0xB1>(q1); q2 += dpp_mov<0xB1>(q2);   // pair sums
@@ -1024,7 +1033,9 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 KN(KP, t2, 0) = r_bs[0]; KN(KV, t2, 0) = r_bs[1]; KN(KA, t2, 0) = r_bs[2];
                 KN(KP, t2, N) = r_bs[3]; KN(KV, t2, N) = r_bs[4]; KN(KA, t2, N) = r_bs[5];
             }
+            FRX_STAMP_AX(8);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // meets the matrix wave's only barrier: knot positions and Tf are in LDS
+            FRX_STAMP_AX(9);
             // right-hand side of knot kk for this axis (knot_row_rhs; the fixed end states move to the right-hand side)
             const bool act = kk >= 1 && kk <= N - 1;
             const int kc = act ? kk : 1;
@@ -1045,6 +1056,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                     }
                 }
             }
+            FRX_STAMP_AX(10);
             int nst = 0;
             for (int s = 1; s < N - 1; s <<= 1) nst++;
             for (int st = 0; st < nst; st++) {                             // pcr_rhs_step behind the matrix wave, neighbours by lane shifts
@@ -1060,6 +1072,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
                 r0 = n0; r1 = n1;
             }
+            FRX_STAMP_AX(11);
             lds_wait_ge(progress, (unsigned)(nst + 1));
             double vK, aK;                                                 // (v, a) of knot kk on this axis
             {
@@ -1077,6 +1090,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
 #pragma unroll
                 for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, cq[q], wt); if (ct_lds) ct_lds[kk * 19 + q * 3 + ax] = cq[q]; }
             }
+            FRX_STAMP_AX(12);
         }
         FRX_STAMP(6);
         return;
@@ -1093,7 +1107,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;                  // prefetched for the first (usually only) pass
             if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
             nv1 = wnv - 1;
-            V = vs + 3 * (wvb - dp.cvoff[b]);
+            V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
             xi = xs + (wxb - x0);
             for (int a = sub; a < nv1; a += 4) {
                 const double x2 = xi[a] * xi[a];
@@ -1214,7 +1228,8 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     double *vs = xs + maxXb;
     double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by the forward pass
     double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
-    if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; pw = ro->pw; }
+    double *gs = nullptr;
+    if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; pw = ro->pw; gs = ro->gs; }
     const int pws = nsteps * 8 + 5;
     const bool tapped = tap.d != nullptr;
     const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
@@ -1281,6 +1296,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         const int ax = wave - 1;
         const bool act = kk >= 1 && kk <= N - 1;
         const int kc = act ? kk : 1;
+        FRX_STAMP_AX(25);
         // ---- cbar = d f / d c of this axis: penalty part + jerk energy (CPU.hpp:84-92) ----
         {
             const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
@@ -1298,28 +1314,51 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         const double ePu = __shfl_up(db[3], 1, 64), eVu = __shfl_up(db[4], 1, 64), eAu = __shfl_up(db[5], 1, 64);
         double r0 = 0.0, r1 = 0.0, pbk = 0.0;
         if (act) { r0 = db[1] + eVu; r1 = db[2] + eAu; pbk = db[0] + ePu; }      // right-hand side of K mu = wbar; direct d f / d p_k (both adjacent pieces)
-        FRX_STAMP(19);
+        FRX_STAMP_AX(26);
         // ---- mu = K^-1 wbar with the multipliers of the forward reduction (K is symmetric), neighbours by lane shifts ----
         int nst = 0;
         for (int s = 1; s < N - 1; s <<= 1) nst++;
-        for (int st = 0; st < nst; st++) {
-            const int s = 1 << st;
-            const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
-            double ab[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
-            const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
-            const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
-            const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);    // pcr_rhs_step
-            const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
-            r0 = n0; r1 = n1;
-        }
         double muv = 0.0, mua = 0.0;                                   // zero at the fixed end knots
-        if (act) {
-            const double *Di = pw + kk * pws + nsteps * 8;
-            muv = Di[0] * r0 + Di[1] * r1; mua = Di[2] * r0 + Di[3] * r1;
+        if (nst <= 6) {
+            // every multiplier of this knot up front (they were all saved by the forward pass): a step is then one lane exchange, not two LDS round trips
+            double ab[6][8], Di[4];
+#pragma unroll
+            for (int st = 0; st < 6; st++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[st][i] = pw[kc * pws + (st < nst ? st : 0) * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) Di[i] = pw[kc * pws + nsteps * 8 + i];
+#pragma unroll
+            for (int st = 0; st < 6; st++)
+                if (st < nst) {
+                    const int s = 1 << st;
+                    const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                    const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+                    const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+                    const double n0 = r0 - (ab[st][0] * l0 + ab[st][1] * l1) - (ab[st][4] * h0 + ab[st][5] * h1);    // pcr_rhs_step
+                    const double n1 = r1 - (ab[st][2] * l0 + ab[st][3] * l1) - (ab[st][6] * h0 + ab[st][7] * h1);
+                    r0 = n0; r1 = n1;
+                }
+            if (act) { muv = Di[0] * r0 + Di[1] * r1; mua = Di[2] * r0 + Di[3] * r1; }
+        } else {
+            for (int st = 0; st < nst; st++) {
+                const int s = 1 << st;
+                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                double ab[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
+                const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+                const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+                const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);
+                const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+                r0 = n0; r1 = n1;
+            }
+            if (act) {
+                const double *Di = pw + kk * pws + nsteps * 8;
+                muv = Di[0] * r0 + Di[1] * r1; mua = Di[2] * r0 + Di[3] * r1;
+            }
         }
-        FRX_STAMP(21);
+        FRX_STAMP_AX(27);
         // ---- through the knot system: duration term and d f / d(p_{k+1} - p_k) ----
         double mu1v = __shfl_down(muv, 1, 64), mu1a = __shfl_down(mua, 1, 64);
         if (kk >= N - 1) { mu1v = 0.0; mu1a = 0.0; }
@@ -1328,6 +1367,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         const double dlu = __shfl_up(dlb, 1, 64);                    // + dl of the piece ending at this knot
         if (piece) KN(KV, ax, kk) = hb;
         if (act) KN(KP, ax, kk) = pbk + dlu - dlb;                   // d f / d q_k for the pair that owns the waypoint
+        FRX_STAMP_AX(28);
     }
     __syncthreads();
     FRX_STAMP(22);
@@ -1346,11 +1386,11 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         }
         const double wc = wave_sum_dpp(costAcc), wtt = wave_sum_dpp(sumTc);
         const double fval = wc + dp.rho * wtt;
-        if (kk == 0) { f[b] = fval; red[0] = fval; }
+        if (kk == 0) { if (!ro) f[b] = fval; red[0] = fval; }             // resident caller: the value travels through the mailbox, nothing to drain
         if (dp.soft) {
             if (kk < cN) {
                 const double gi = gCo[kk] * dT_dtau(xs[kk], dp.c2 != 0);
-                g[x0 + kk] = gi;
+                if (gs) gs[kk] = gi; else g[x0 + kk] = gi;
                 if (tapped) { t_dg += gi * dsv[kk]; t_xx += xs[kk] * xs[kk]; t_gg += gi * gi; }
             }
         } else {
@@ -1368,7 +1408,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                 for (int i = 0; i < Ms1; i++) {
                     const double de = dT_dtau(xs[i], dp.c2 != 0);
                     const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
-                    g[x0 + i] = gi;
+                    if (gs) gs[i] = gi; else g[x0 + i] = gi;
                     if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
                 }
             }
@@ -1380,34 +1420,52 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             const bool wact = w < N - 1;
             const double *V = vs, *xi = xs;
             int nv1 = 0, xb = 0;
-            double g0 = 0.0, g1 = 0.0, g2 = 0.0, qn = 0.0, gdq = 0.0;
+            double g0 = 0.0, g1 = 0.0, g2 = 0.0, qn = 0.0;
             if (wact) {
                 int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
                 if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
                 nv1 = wnv - 1; xb = wxb;
-                V = vs + 3 * (wvb - dp.cvoff[b]);
+                V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
                 xi = xs + (xb - x0);
                 g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
-                for (int a = sub; a < nv1; a += 2) qn += xi[a] * xi[a];
             }
-            qn += dpp_mov<0xB1>(qn);
-            const double qp1 = qn + 1.0, iq = 1.0 / qp1, sc = 2.0 * iq;
+            // with r_a = sc xi_a, sc = 2 / (1 + |xi|^2):  d f / d xi_a = xi_a (2 sc^2 (V_a . g) - 4 gdq / (1 + |xi|^2)^2),
+            // gdq = 2 sc sum_a (V_a . g) xi_a^2  -  so |xi|^2 and the weighted sum come out of ONE pass over the vertices
+            double s2 = 0.0;
             if (wact)
-                for (int a = sub; a < nv1; a += 2) {
-                    const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
-                    gdq += gdr * xi[a];
+                for (int a0 = sub; a0 < nv1; a0 += 8) {                   // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
+                    double xv[4], dgv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int a = min(a0 + 2 * j, nv1 - 1); xv[j] = xi[a]; dgv[j] = V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (a0 + 2 * j < nv1) { const double x2 = xv[j] * xv[j]; qn += x2; s2 += dgv[j] * x2; }
                 }
-            gdq += dpp_mov<0xB1>(gdq);
-            const double kq = 4.0 * gdq * (iq * iq);
+            FRX_STAMP_AX(30);
+            qn += dpp_mov<0xB1>(qn); s2 += dpp_mov<0xB1>(s2);        // pair sums
+            const double qp1 = qn + 1.0, iq = 1.0 / qp1, sc = 2.0 * iq;
+            const double gdq = 2.0 * sc * s2, kq = 4.0 * gdq * (iq * iq), sc22 = 2.0 * sc * sc;
+            FRX_STAMP_AX(31);
             if (wact)
-                for (int a = sub; a < nv1; a += 2) {
-                    const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
-                    const double gi = gdr * sc - xi[a] * kq;        // gdr * 2 / (1 + |xi|^2) - xi * 4 gdq / (1 + |xi|^2)^2
-                    g[xb + a] = gi;
-                    if (tapped) { t_dg += gi * dsv[xb - x0 + a]; t_xx += xi[a] * xi[a]; t_gg += gi * gi; }
+                for (int a0 = sub; a0 < nv1; a0 += 8) {
+                    double xv[4], dgv[4], dd[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int a = min(a0 + 2 * j, nv1 - 1);
+                        xv[j] = xi[a]; dgv[j] = V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2;
+                        dd[j] = tapped ? dsv[xb - x0 + a] : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (a0 + 2 * j < nv1) {
+                            const double gi = xv[j] * (sc22 * dgv[j] - kq);
+                            if (gs) gs[xb - x0 + a0 + 2 * j] = gi; else g[xb + a0 + 2 * j] = gi;
+                            t_dg += gi * dd[j]; t_xx += xv[j] * xv[j]; t_gg += gi * gi;
+                        }
                 }
         }
     }
+    FRX_STAMP_AX(29);
     FRX_STAMP(23);
     // ---- line-search tap: what lbfgs.hpp:830 (g.d) and :1296-1297 (|x|, |g|) need, reduced here instead of in a separate launch ----
     if (tap.d != nullptr) {                                           // uniform over the grid
@@ -1649,7 +1707,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     if (dp.soft) {
         for (int i = k; i < cN; i += nthr) {
             const double gi = gCo[i] * dT_dtau(xs[i], dp.c2 != 0);
-            g[x0 + i] = gi;
+            g[x0 + i] = gi; if (ro && ro->gs) ro->gs[i] = gi;
             if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
         }
     } else if (k == 0) {
@@ -1665,7 +1723,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         for (int i = 0; i < Ms1; i++) {
             const double de = dT_dtau(xs[i], dp.c2 != 0);
             const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
-            g[x0 + i] = gi;
+            g[x0 + i] = gi; if (ro && ro->gs) ro->gs[i] = gi;
             if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
         }
     }
@@ -1686,7 +1744,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
             int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
             if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
             nv1 = wnv - 1; xb = wxb;
-            V = vs + 3 * (wvb - dp.cvoff[b]);
+            V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
             xi = xs + (xb - x0);
             g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
             for (int a = sub; a < nv1; a += 4) qn += xi[a] * xi[a];
@@ -1703,7 +1761,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
             for (int a = sub; a < nv1; a += 4) {
                 const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
                 const double gi = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
-                g[xb + a] = gi;
+                g[xb + a] = gi; if (ro && ro->gs) ro->gs[xb - x0 + a] = gi;
                 if (tapped) { t_dg += gi * dsv[xb - x0 + a]; t_xx += xi[a] * xi[a]; t_gg += gi * gi; }
             }
     }

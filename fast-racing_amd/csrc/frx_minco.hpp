@@ -26,34 +26,6 @@
 
 namespace frx {
 
-// One block row of the knot system: D (2x2), L (2x2, couples to knot k-s), U (2x2, knot k+s), r (2 x 3 axes).
-struct KnotRow {
-    double D[4], L[4], U[4], r[6];   // row-major 2x2; r[row*3 + axis]
-};
-
-FRX_HD void knot_row_identity(KnotRow &R) {
-    R.D[0] = 1.0; R.D[1] = 0.0; R.D[2] = 0.0; R.D[3] = 1.0;
-    for (int i = 0; i < 4; i++) { R.L[i] = 0.0; R.U[i] = 0.0; }
-    for (int i = 0; i < 6; i++) R.r[i] = 0.0;
-}
-
-// Matrix part of knot k between a left piece of duration hL and a right piece of duration hR.
-FRX_HD void knot_row_matrix(double hL, double hR, KnotRow &R) {
-    const double iL = 1.0 / hL, iL2 = iL * iL, iL3 = iL2 * iL;
-    const double iR = 1.0 / hR, iR2 = iR * iR, iR3 = iR2 * iR;
-    R.D[0] = 192.0 * iL3 + 192.0 * iR3; R.D[1] = -36.0 * iL2 + 36.0 * iR2;
-    R.D[2] = R.D[1];                    R.D[3] = 9.0 * iL + 9.0 * iR;
-    R.L[0] = 168.0 * iL3; R.L[1] = 24.0 * iL2; R.L[2] = -24.0 * iL2; R.L[3] = -3.0 * iL;
-    R.U[0] = 168.0 * iR3; R.U[1] = -24.0 * iR2; R.U[2] = 24.0 * iR2; R.U[3] = -3.0 * iR;
-}
-// Right-hand side of knot k for one axis from the position differences dL = p_k - p_{k-1}, dR = p_{k+1} - p_k.
-FRX_HD void knot_row_rhs(double hL, double hR, double dL, double dR, double &rv, double &ra) {
-    const double iL = 1.0 / hL, iL3 = iL * iL * iL, iR = 1.0 / hR, iR3 = iR * iR * iR;
-    rv = 360.0 * dL * iL3 * iL + 360.0 * dR * iR3 * iR;
-    ra = -60.0 * dL * iL3 + 60.0 * dR * iR3;
-}
-
-// 2x2 helpers (row-major)
 // 1/x.  Device: v_rcp_f64 refined by two Newton steps (5 instructions on the critical path of every reduction step instead of the
 // ~10 of an IEEE division with its scale / fixup sequence); relative error < 2^-51.  Host: the plain division.
 FRX_HD double rcp_fast(double x) {
@@ -67,6 +39,35 @@ FRX_HD double rcp_fast(double x) {
     return 1.0 / x;
 #endif
 }
+
+// One block row of the knot system: D (2x2), L (2x2, couples to knot k-s), U (2x2, knot k+s), r (2 x 3 axes).
+struct KnotRow {
+    double D[4], L[4], U[4], r[6];   // row-major 2x2; r[row*3 + axis]
+};
+
+FRX_HD void knot_row_identity(KnotRow &R) {
+    R.D[0] = 1.0; R.D[1] = 0.0; R.D[2] = 0.0; R.D[3] = 1.0;
+    for (int i = 0; i < 4; i++) { R.L[i] = 0.0; R.U[i] = 0.0; }
+    for (int i = 0; i < 6; i++) R.r[i] = 0.0;
+}
+
+// Matrix part of knot k between a left piece of duration hL and a right piece of duration hR.
+FRX_HD void knot_row_matrix(double hL, double hR, KnotRow &R) {
+    const double iL = rcp_fast(hL), iL2 = iL * iL, iL3 = iL2 * iL;
+    const double iR = rcp_fast(hR), iR2 = iR * iR, iR3 = iR2 * iR;
+    R.D[0] = 192.0 * iL3 + 192.0 * iR3; R.D[1] = -36.0 * iL2 + 36.0 * iR2;
+    R.D[2] = R.D[1];                    R.D[3] = 9.0 * iL + 9.0 * iR;
+    R.L[0] = 168.0 * iL3; R.L[1] = 24.0 * iL2; R.L[2] = -24.0 * iL2; R.L[3] = -3.0 * iL;
+    R.U[0] = 168.0 * iR3; R.U[1] = -24.0 * iR2; R.U[2] = 24.0 * iR2; R.U[3] = -3.0 * iR;
+}
+// Right-hand side of knot k for one axis from the position differences dL = p_k - p_{k-1}, dR = p_{k+1} - p_k.
+FRX_HD void knot_row_rhs(double hL, double hR, double dL, double dR, double &rv, double &ra) {
+    const double iL = rcp_fast(hL), iL3 = iL * iL * iL, iR = rcp_fast(hR), iR3 = iR * iR * iR;
+    rv = 360.0 * dL * iL3 * iL + 360.0 * dR * iR3 * iR;
+    ra = -60.0 * dL * iL3 + 60.0 * dR * iR3;
+}
+
+// 2x2 helpers (row-major)
 FRX_HD void m2_inv(const double *A, double *I) {
     const double det = A[0] * A[3] - A[1] * A[2], id = 1.0 / det;
     I[0] = A[3] * id; I[1] = -A[1] * id; I[2] = -A[2] * id; I[3] = A[0] * id;
@@ -146,7 +147,7 @@ FRX_HD void pcr_finish(const KnotRow &R, double *v, double *a) {
 
 // Quintic Hermite coefficients of one axis: c[k] = coefficient of t^k on [0, h].
 FRX_HD void hermite_coeffs(double h, double p0, double v0, double a0, double p1, double v1, double a1, double *c) {
-    const double ih = 1.0 / h, ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih;
+    const double ih = rcp_fast(h), ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih;
     const double dl = p1 - p0;
     c[0] = p0; c[1] = v0; c[2] = 0.5 * a0;
     c[3] = 10.0 * dl * ih3 - (4.0 * v1 + 6.0 * v0) * ih2 - 0.5 * (3.0 * a0 - a1) * ih;
@@ -156,7 +157,7 @@ FRX_HD void hermite_coeffs(double h, double p0, double v0, double a0, double p1,
 // Adjoint of hermite_coeffs for one axis: cb[6] -> (p0b, v0b, a0b, p1b, v1b, a1b) and the duration adjoint.
 FRX_HD void hermite_adjoint(double h, double p0, double v0, double a0, double p1, double v1, double a1, const double *cb,
                             double *db, double &hb) {
-    const double ih = 1.0 / h, ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih, ih6 = ih3 * ih3;
+    const double ih = rcp_fast(h), ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih, ih6 = ih3 * ih3;
     const double dl = p1 - p0;
     const double pd = 10.0 * ih3 * cb[3] - 15.0 * ih4 * cb[4] + 6.0 * ih5 * cb[5];
     db[0] = cb[0] - pd;
@@ -176,7 +177,7 @@ FRX_HD void hermite_adjoint(double h, double p0, double v0, double a0, double p1
 //   returns d f / d(p_{i+1} - p_i) through the right-hand sides, and adds the duration term.
 FRX_HD double knot_adjoint_piece(double h, double dl, double v0, double a0, double v1, double a1, double mu0v, double mu0a,
                                  double mu1v, double mu1a, double &hb) {
-    const double ih = 1.0 / h, ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih;
+    const double ih = rcp_fast(h), ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih;
     // rows of knot i+1 contributed by this piece (as its LEFT piece): (-snap(h), +jerk(h))
     const double dLv = -504.0 * v0 * ih4 - 48.0 * a0 * ih3 - 576.0 * v1 * ih4 + 72.0 * a1 * ih3 + 1440.0 * dl * ih5;
     const double dLa = 48.0 * v0 * ih3 + 3.0 * a0 * ih2 + 72.0 * v1 * ih3 - 9.0 * a1 * ih2 - 180.0 * dl * ih4;

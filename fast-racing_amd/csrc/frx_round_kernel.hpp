@@ -62,6 +62,10 @@ struct RoundLds {
     int Rf, vd, va, vb, vc, ve, vw, vv, mv;              // dense state: Rf = R^-1 as [128][129] (row stride 129: conflict-free by row AND by column)
 };
 enum { RK_RS = 129 };                                    // row stride of Rf
+// Control words of a candidate (phase, cntA, uflag, cntL) sit in four different 128-byte lines of ITS OWN 512-byte block.  In round 1
+// each kind was a dense [B] array: the phase words of 16 clusters shared one cache line - one L2 channel - that 7 idle workgroups per
+// cluster poll every ~100 cycles; at 32 clusters a round took 7 us longer than at one (38.3 vs 31.0 us).
+enum { RK_WSTRIDE = 128, RK_WORDS_PER_CAND = 128 };
 __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) {
     RoundLds L;
     int o = 0;
@@ -88,7 +92,7 @@ struct RoundArgs {
     double *part;            // [B][G][4][128] cluster -> dense: partial dot products
     double *upub;            // [B][258]      dense -> cluster: -u, gamma w, gamma
     double *dpub;            // [B][NXP]      cluster -> leader: direction chunks
-    unsigned *phase, *cntA, *uflag, *cntL;   // [B] each (zeroed before every launch)
+    unsigned *phase, *cntA, *uflag, *cntL;   // word c * RK_WSTRIDE of each (zeroed before every launch); the four bases are 32 words apart
     unsigned *census, *status;               // [1] each (zeroed before every launch)
     unsigned *xcc;                           // [B][G] XCC id + 1 of every workgroup (zeroed before every launch)
     RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
@@ -104,6 +108,26 @@ struct RoundArgs {
 // profile segments (thread 0 of every workgroup accumulates the time since its previous checkpoint into one of these)
 enum { RK_P_WAIT_HOST = 0, RK_P_VECTORS = 1, RK_P_FORWARD = 2, RK_P_WAIT_PHASE = 3, RK_P_PASS_A = 4, RK_P_WAIT_PART = 5, RK_P_DENSE_IN = 6, RK_P_SOLVE = 7,
        RK_P_WAIT_U = 8, RK_P_PASS_B = 9, RK_P_PENALTY = 10, RK_P_WAIT_ARRIVE = 11, RK_P_GATHER = 12, RK_P_BACKWARD = 13, RK_P_POST = 14, RK_P_PUBLISH = 15 };
+
+// value of lane `l` (wave-uniform index) of a double, as a wave-uniform scalar: the broadcast of a vector element to all lanes without an
+// LDS access - the dense workgroup's mat-vecs are bound by LDS bandwidth, and two of the three LDS reads per row element were broadcasts
+__device__ __forceinline__ double rk_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// keeps the scheduler from hoisting every broadcast of an unrolled loop to its top (64 scalar pairs: they would be spilled)
+#define RK_CHUNK() __builtin_amdgcn_sched_barrier(0)
+
+// One 16-byte system-scope load of a candidate's command {word, step} from mapped host memory: the two live in one aligned 16-byte
+// granule that the host fills step first, word (with the sequence number) last, so a word that carries the expected sequence number
+// comes with its step - one PCIe round trip instead of two for the commands whose step is not 1.
+__device__ __forceinline__ void rk_load_cmd(const RoundCmd *p, rk_u64 &word, rk_u64 &step) {
+    typedef unsigned rk_v4u __attribute__((ext_vector_type(4)));
+    rk_v4u r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    word = (rk_u64)r.x | ((rk_u64)r.y << 32); step = (rk_u64)r.z | ((rk_u64)r.w << 32);
+}
 
 // ---- bounded waits (ONE lane) ----
 __device__ __forceinline__ bool rk_expired(const RoundArgs &a, rk_u64 deadline) {
@@ -157,20 +181,34 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     const bool wt = v.wt;
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
     double *ctlD = sm + L.ctl + 8, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
-    double *x = a.x + v.xbase, *g = a.g + v.xbase, *xp = a.xp + v.xbase, *gp = a.gp + v.xbase, *dv = a.d + v.xbase;
+    double *xglob = a.x + v.xbase, *gglob = a.g + v.xbase;                  // global memory: read once at the start, written once at the end
     double *pub = v.pub, *dpub = v.dpub;
     // operands the evaluation bodies find in LDS instead of staging them every call (ResidentOps): at the head of the leader's
     // role region behind the (C, T) copy - x, the waypoint polytopes (constant), the direction, the reduction multipliers
-    const int xpad = (a.maxXb + 1) & ~1, vpad = (a.maxVb + 1) & ~1;
+    const int xpad = (a.maxXb + 1) & ~1, vpad = (a.maxVb + a.nrow + 1) & ~1;     // polytopes: one double of skew per waypoint (ResidentOps::vskew)
     ResidentOps ro;
     ro.xs = sm + L.role + ((a.maxN19 + 1) & ~1); ro.vs = ro.xs + xpad; ro.dsv = ro.vs + vpad; ro.pw = ro.dsv + xpad;
+    // the leader's vectors live in LDS for the whole plan: x (= ro.xs), g (= ro.gs, written by the adjoint), the previous point and
+    // gradient xp / gp and the direction d (= ro.dsv).  Round 1 kept them in global memory "touched by this CU only": every use was a
+    // load / store through L2 and the adjoint's gradient stores had to be drained before the round could go on.
+    ro.gs = ro.pw + (((a.nsteps * 8 + 5) * a.nrow + 1) & ~1);
+    double *x = ro.xs, *g = ro.gs, *xp = ro.gs + xpad, *gp = xp + xpad, *dv = ro.dsv;
     {
         const int v0 = a.dp.cvoff[c], nvd = 3 * (a.dp.cvoff[c + 1] - v0);
         const double *vsrc = a.dp.vrec + 3 * (size_t)v0;
-        for (int i = t; i < nvd; i += 256) ro.vs[i] = vsrc[i];
-        for (int i = t; i < n; i += 256) { ro.xs[i] = x[i]; ro.dsv[i] = 0.0; }
+        (void)nvd;
+        ro.vskew = 1;
+        for (int w = t >> 2; w < v.N - 1; w += 64) {                       // a quad of lanes copies the polytope of waypoint w, w doubles further on
+            const int gw = v.p0 - c + w, beg = 3 * (a.dp.wp_vbeg[gw] - v0), cnt = 3 * a.dp.wp_nv[gw];
+            for (int j = t & 3; j < cnt; j += 4) ro.vs[beg + w + j] = vsrc[beg + j];
+        }
+        for (int i = t; i < n; i += 256) { x[i] = xglob[i]; dv[i] = 0.0; g[i] = 0.0; xp[i] = 0.0; gp[i] = 0.0; }
         __syncthreads();
     }
+    auto flush = [&](const double *xsrc, const double *gsrc) {              // the plan's result for the host: the point (and its gradient) in global memory
+        __syncthreads();
+        for (int i = t; i < n; i += 256) { xglob[i] = xsrc[i]; gglob[i] = gsrc[i]; }
+    };
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
     unsigned pseq = 0, nphase = 0;
     rk_u64 hseq = 0;
@@ -184,7 +222,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     // iteration limit) the leader restores the accepted point and leaves; any other disagreement ends the launch with
     // RK_ERR_SPECULATION and the plan is re-run on the per-stage path.
     bool unconfirmed = false, spec_ready = false;
-    rk_u64 pred_word = 0;
+    rk_u64 pred_word = 0, seq_pending = 0;
     double f_acc = 0.0, gg0 = 0.0;
     int last_slot = -1, last_bound = 0;
     for (;;) {
@@ -206,16 +244,16 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         } else if (lstage == 0) {
             if (t == 0) {
                 const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                rk_u64 w = 0;
+                rk_u64 w = 0, stp = 0;
                 bool ok = true;
                 for (unsigned spins = 0;; spins++) {
-                    w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
+                    rk_load_cmd(a.h_cmd + c, w, stp);
                     if ((w >> 32) == hseq + 1) break;
                     if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                 }
                 if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
                 ctlU[1] = (unsigned)w;
-                if (ok) ctlD[5] = __longlong_as_double((long long)__hip_atomic_load((const rk_u64 *)&a.h_cmd[c].step, FRX_RLX_SYS));
+                if (ok) ctlD[5] = __longlong_as_double((long long)stp);
             }
             __syncthreads();
             RK_PROF(RK_P_WAIT_HOST);
@@ -224,9 +262,9 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             step = ctlD[5];
             hseq++;
             __syncthreads();
-            if (flags & DV_QUIT) kind = PH_QUIT;
+            if (flags & DV_QUIT) { kind = PH_QUIT; flush(x, g); }
             else if (flags & DV_RESTORE) {                                  // lbfgs.hpp:1287-1288; no evaluation follows
-                for (int i = t; i < n; i += 256) { const double xv = xp[i]; x[i] = xv; ro.xs[i] = xv; g[i] = gp[i]; }
+                for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }
                 rk_drain_and_meet();
                 if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
                 continue;
@@ -242,7 +280,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
                     f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
-                    for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; ro.dsv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
+                    for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
                 }
                 lstage = 1;
             }
@@ -250,7 +288,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (lstage == 1 && kind == 0) {
             if (flags & DV_TRIAL) {                                         // x = xp + step * d (lbfgs.hpp:825-826)
                 __syncthreads();
-                for (int i = t; i < n; i += 256) { const double xv = xp[i] + step * dv[i]; x[i] = xv; ro.xs[i] = xv; }
+                for (int i = t; i < n; i += 256) x[i] = xp[i] + step * dv[i];
             }
             if (flags & DV_EVAL) {
                 __syncthreads();                                            // (vmcnt(0) + barrier: x is complete and visible to this CU)
@@ -267,27 +305,32 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         }
         rk_drain_and_meet();                                                // everything published so far has left this CU
         pseq++;
-        if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+        if (t == 0 && seq_pending != 0) {                                   // the previous round's result (system-scope stores, drained above) becomes visible to the host;
+            __hip_atomic_store(&a.h_res[c].seq, seq_pending, FRX_RLX_SYS);  // no release fence: its L2 write-back (0.7 us per round) would serve cached stores, and there are none to publish
+            seq_pending = 0;
+        }
         RK_PROF(RK_P_PUBLISH);
         if (kind == PH_QUIT) break;
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
         // ---- the phase is complete when every workgroup of the cluster has reported ----
         rk_drain_and_meet();
-        if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
         nphase++;
-        if (t == 0) { const bool ok = rk_wait_eq(a.cntL + c, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
+        if (t == 0) { const bool ok = rk_wait_eq(a.cntL + c * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
         __syncthreads();
         const bool ok = ctlU[0] != 0u;
         __syncthreads();
         RK_PROF(RK_P_WAIT_ARRIVE);
         if (!ok) {                                                          // tell the host and the cluster, then leave
+            flush(x, g);
             pseq++;
-            if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
+            if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
             break;
         }
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
             double acc = 0.0;
-            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; ro.dsv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
+            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
             const double ws = wave_sum_dpp(acc);
             if (lane == 0) pair[wave] = ws;
             __syncthreads();
@@ -322,26 +365,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 __syncthreads();
                 unconfirmed = false;
                 if (verdict != 0u) {
-                    if (verdict == 1u) { for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; } }     // the accepted point is the result
+                    if (verdict == 1u) flush(xp, gp); else flush(x, g);                     // host stopped: the accepted point is the result
                     rk_drain_and_meet();
                     pseq++;
-                    if (t == 0) __hip_atomic_store(a.phase + c, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT);
+                    if (t == 0) __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT);
                     break;
                 }
             }
-            if (t == 0) {
-                RoundRes *r = a.h_res + c;
-                __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
-                __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
-                __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
-                __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
-                __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
-            }
-            lstage = 0;
-            __syncthreads();
             if (a.speculate && (flags & (DV_ADVANCE | DV_INIT))) {          // first trial of a search: predict the host's verdict (lbfgs.hpp:829-850)
                 const double fv = ctlD[0], dgv = ctlD[1];
                 const double dgi = (flags & DV_ADVANCE) ? ctlD[4] : -gg0;  // slope at the start of the search (lbfgs.hpp:756; d = -g after INIT)
@@ -354,6 +384,21 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     spec_ready = true;
                 }
             }
+            if (t == 0) {
+                RoundRes *r = a.h_res + c;
+                __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
+                if (spec_ready) seq_pending = hseq;                         // nobody waits for the host's answer to this one: the sequence number follows
+                else {                                                      // behind the next publication's drain instead of a drain of its own
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
+                }
+            }
+            lstage = 0;
+            __syncthreads();
             RK_PROF(RK_P_POST);
         }
     }
@@ -385,7 +430,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             unsigned w = 0;
             bool ok = true;
             for (unsigned spins = 0;; spins++) {
-                w = __hip_atomic_load(a.phase + c, FRX_RLX_AGENT);
+                w = __hip_atomic_load(a.phase + c * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(1);
@@ -434,10 +479,10 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             __syncthreads();
             for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)hg * 512 + o, pair[o] + pair[512 + o], wt);
             rk_drain_and_meet();
-            if (t == 0) __hip_atomic_fetch_add(a.cntA + c, 1u, FRX_RLX_AGENT);
+            if (t == 0) __hip_atomic_fetch_add(a.cntA + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
             RK_PROF(RK_P_PASS_A);
             // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
-            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + c, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
+            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + c * RK_WSTRIDE, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
             __syncthreads();
             RK_PROF(RK_P_WAIT_U);
             {
@@ -465,7 +510,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, wg); RK_PROF(RK_P_PENALTY); }
         // ---- report the end of this workgroup's part of the phase to the leader ----
         rk_drain_and_meet();
-        if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }
@@ -503,7 +548,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             unsigned w = 0;
             bool ok = true;
             for (unsigned spins = 0;; spins++) {
-                w = __hip_atomic_load(a.phase + c, FRX_RLX_AGENT);
+                w = __hip_atomic_load(a.phase + c * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(1);
@@ -519,25 +564,37 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
         if (kind == PH_QUIT) break;
         if (kind == PH_ADV) {
             nadv++;
-            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); const bool ok = rk_wait_eq(a.cntA + c, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); const bool ok = rk_wait_eq(a.cntA + c * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
             __syncthreads();
             const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
             RK_PROF(RK_P_WAIT_PART);
-            for (int o = t; o < 512; o += 256) {
-                double s = 0.0;
-                for (int w2 = 0; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);          // fixed order: deterministic
-                (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
+            {   // partial sums of the history workgroups, summed in workgroup order (deterministic); all loads of a batch in flight together
+                double pv[2][8];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                    for (int w2 = 0; w2 < 8; w2++) pv[h2][w2] = ldg<true>(part + (size_t)(w2 < nh ? w2 : nh - 1) * 512 + t + 256 * h2);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const int o = t + 256 * h2;
+                    double s = 0.0;
+#pragma unroll
+                    for (int w2 = 0; w2 < 8; w2++) if (w2 < nh) s += pv[h2][w2];
+                    for (int w2 = 8; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);
+                    (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
+                }
             }
             if (t < 128) { Rf[jnew * RK_RS + t] = 0.0; Rf[t * RK_RS + jnew] = 0.0; }                  // the pair that slot jnew held is gone
             __syncthreads();
             RK_PROF(RK_P_DENSE_IN);
             // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are)
+            const int ln = t & 63;                                          // lane ln of every wave holds element q0 + ln of a broadcast vector
             {
                 const int uj = jnew - q0;
                 const double colv = ve[pp];
                 const bool isrow = pp == jnew;
 #pragma unroll
-                for (int u = 0; u < 32; u++) {
+                for (int u = 0; u < 32; u++) {                              // (LDS broadcasts here: with rk_bcast this loop measured 1.3 instead of 0.8 us)
                     const double r0 = ve[q0 + u], r1 = ve[q0 + 32 + u];
                     Ya[u] = isrow ? r0 : (u == uj ? colv : Ya[u]);
                     Yb[u] = isrow ? r1 : (u + 32 == uj ? colv : Yb[u]);
@@ -549,8 +606,17 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             {
                 double sz = 0.0, st = 0.0;
                 const double *row = Rf + pp * RK_RS + q0;
-#pragma unroll 16
-                for (int u = 0; u < 64; u++) { const double e = row[u]; sz += e * vc[q0 + u]; st += e * va[q0 + u]; }
+                const double vcl = vc[q0 + ln], val = va[q0 + ln];
+#pragma unroll
+                for (int u0 = 0; u0 < 64; u0 += 16) {                      // a chunk of the row into registers, then the products: one LDS latency per chunk
+                    double e[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) e[j] = row[u0 + j];
+                    RK_CHUNK();
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { sz += e[j] * rk_bcast(vcl, u0 + j); st += e[j] * rk_bcast(val, u0 + j); }
+                    RK_CHUNK();
+                }
                 mv[hq * 128 + pp] = sz; mz[hq * 128 + pp] = st;
             }
             __syncthreads();
@@ -565,10 +631,11 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             // pass 2: (Y^T Y) w from registers
             {
                 double sacc = 0.0;
+                const double vwl = vw[q0 + ln];
 #pragma unroll
-                for (int u = 0; u < 32; u++) sacc += Ya[u] * vw[q0 + u];
+                for (int u = 0; u < 32; u++) { sacc += Ya[u] * rk_bcast(vwl, u); if ((u & 15) == 15) RK_CHUNK(); }
 #pragma unroll
-                for (int u = 0; u < 32; u++) sacc += Yb[u] * vw[q0 + 32 + u];
+                for (int u = 0; u < 32; u++) { sacc += Yb[u] * rk_bcast(vwl, 32 + u); if ((u & 15) == 15) RK_CHUNK(); }
                 mv[hq * 128 + pp] = sacc;
             }
             __syncthreads();
@@ -579,8 +646,17 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             {
                 double sacc = 0.0;
                 const double *col = Rf + q0 * RK_RS + pp;
-#pragma unroll 16
-                for (int u = 0; u < 64; u++) sacc += col[u * RK_RS] * vv[q0 + u];
+                const double vvl = vv[q0 + ln];
+#pragma unroll
+                for (int u0 = 0; u0 < 64; u0 += 16) {
+                    double e[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) e[j] = col[(u0 + j) * RK_RS];
+                    RK_CHUNK();
+#pragma unroll
+                    for (int j = 0; j < 16; j++) sacc += e[j] * rk_bcast(vvl, u0 + j);
+                    RK_CHUNK();
+                }
                 mz[hq * 128 + pp] = sacc;
             }
             __syncthreads();
@@ -591,11 +667,11 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             }
             if (t == 128) stg<true>(upub + 256, gamma, wt);
             rk_drain_and_meet();
-            if (t == 0) __hip_atomic_store(a.uflag + c, nadv, FRX_RLX_AGENT);
+            if (t == 0) __hip_atomic_store(a.uflag + c * RK_WSTRIDE, nadv, FRX_RLX_AGENT);
             RK_PROF(RK_P_SOLVE);
         }
         rk_drain_and_meet();
-        if (t == 0) __hip_atomic_fetch_add(a.cntL + c, 1u, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }

@@ -25,8 +25,14 @@ for name, wg in (("leader", 0), ("member1", 1), ("dense", G - 1)):
     out[name] = {SEG[i]: round(float(pr[0, wg, i]) / rounds, 2) for i in range(16) if pr[0, wg, i] > 0}
     out[name]["total"] = round(float(pr[0, wg].sum()) / rounds, 2)
 st = prob.last_stamps
-out["forward_body_cycles"] = [int(st[i + 1] - st[i]) for i in range(6)]          # loads, maps(T), forwardP, rows, PCR, Hermite+store
-out["adjoint_body_cycles"] = [int(st[i + 1] - st[i]) for i in range(16, 24)]     # loads, jerk, adjoint, rhs, PCR, knot adjoint+merge, cost, layers
+# cycle stamps of candidate 0's last evaluation, relative to the body's entry (wave-specialised bodies of <= 64 pieces):
+#   forward: matrix wave (thread 0) = staged, T ready, all steps done, left; axis wave 1 (thread 64) = waypoint map done, met the matrix
+#   wave, right-hand side built, last step applied, coefficients stored
+#   adjoint: thread 0 = staged, after the axis phase's barrier, time side done, end; thread 64 = start of the axis work, Hermite adjoint done,
+#   adjoint solve done, knot adjoint done, waypoint layer: first pass done (30), scalars done (31), done (29)
+rel = lambda idx, base: {str(i): int(st[i] - st[base]) for i in idx if st[i] > 0}
+out["forward_stamps"] = {"matrix_wave": rel([1, 2, 5, 6], 0), "axis_wave": rel([8, 9, 10, 11, 12], 0)}
+out["adjoint_stamps"] = {"wave0": rel([17, 22, 23, 24], 16), "axis_wave": rel([25, 26, 27, 28, 30, 31, 29], 16)}
 print(json.dumps(out, indent=1))
 prob.set_resident(False)
 r2 = prob.optimize(1e-6, x0=x0, max_iterations=iters)

@@ -48,12 +48,19 @@ def _share_check(frx, sc, ob, cands, kappa, label):
     # heavy-tailed quantity needs more than two samples
     variants = [(False, 0), (True, 0), (False, 11), (False, 12)]
     cpu = _cpu_plans(ob, sc, cands, kappa, tol, variants)
-    spread, dev, bad_status, n_fail = [], [], [], 0
+    spread, dev, bad_status, infeasible_like, n_fail = [], [], [], [], 0
     for b, plans in enumerate(cpu):
         sts = [p["status"] for p in plans]
         sa = sts[0]
         n_fail += sa < 0
         ok = r["status"][b] == sa or (len(set(sts)) > 1 and r["status"][b] in sts)   # path-sensitive candidates may take any CPU verdict
+        if not ok and max(sts) < 0:
+            # An INFEASIBLE scenario (every CPU variant fails): the run is chaotic from the first iterations (scenario 91 of the Monte-Carlo
+            # share: 16 of 16 CPU variants end in -1005 after 287 ... 15792 iterations at objectives 2e7 ... 6e13) and stalls somewhere on a
+            # penalty plateau; whether the stall is labelled as a failed line search or - one tiny step later - as a met stop criterion
+            # depends on the last bits.  What has to be reproduced is the verdict "no plan": a penalty-dominated objective.
+            infeasible_like.append((b, int(r["status"][b]), float(r["objective"][b]), sts))
+            ok = True
         if not ok:
             bad_status.append((b, int(r["status"][b]), sts))
         if min(sts) >= 0 and r["status"][b] >= 0:
@@ -61,7 +68,12 @@ def _share_check(frx, sc, ob, cands, kappa, label):
             spread.append((objs.max() - objs.min()) / abs(objs[0]))
             dev.append(np.abs(r["objective"][b] - objs).min() / abs(objs[0]))
     spread, dev = np.array(spread), np.array(dev)
+    feasible_obj = np.median([min(p["objective"] for p in plans) for plans in cpu if min(q["status"] for q in plans) >= 0])
+    for b, st, obj, sts in infeasible_like:                                 # "succeeded" where the reference fails: only with a penalty-dominated objective
+        if not (obj > 100.0 * feasible_obj):
+            bad_status.append((b, st, sts))
     summary = {"config": label, "candidates": len(cands), "failed_on_cpu": int(n_fail), "status_mismatches": bad_status,
+               "stalled_with_other_label": [(b, st, obj) for b, st, obj, _ in infeasible_like],
                "cpu_vs_cpu_objective_spread": {"median": float(np.median(spread)), "p95": float(np.percentile(spread, 95)), "max": float(spread.max())},
                "device_vs_cpu_objective": {"median": float(np.median(dev)), "p95": float(np.percentile(dev, 95)), "max": float(dev.max())},
                "plan_ms": r["ms_total"], "rounds": r["rounds"]}
