@@ -1041,7 +1041,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
         if ((e = p->d_pubsyg.alloc((size_t)B * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)B * G * 512)) != hipSuccess ||
             (e = p->d_upub.alloc((size_t)B * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)B * NXP)) != hipSuccess ||
-            (e = p->d_rwords.alloc((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)2 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
+            (e = p->d_rwords.alloc((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
@@ -1059,7 +1059,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
     HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G), p->stream));
-    std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 2 * B);
+    std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
@@ -1085,12 +1085,14 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     std::vector<char> waiting(B, 0), quit_sent(B, 0);
     std::vector<long> ncmd(B, 0);
     volatile unsigned long long *hc = p->h_rcmd.p, *hr = p->h_rres.p;
+    { const char *cs = std::getenv("FRX_RESIDENT_CMD_STRIDE"); rl.cmd_stride = cs && std::atoi(cs) == 1 ? 1 : 4; }   // 4: one cache line per candidate
+    const size_t cs2 = 2 * (size_t)rl.cmd_stride;
     auto post = [&](int b, int flags, int slot, int bound, double step) {
-        std::memcpy((void *)(hc + 2 * b + 1), &step, sizeof(double));
+        std::memcpy((void *)(hc + cs2 * b + 1), &step, sizeof(double));
         std::atomic_thread_fence(std::memory_order_release);
         ++seq[b];
         if (step == 1.0 && !(flags & 128)) flags |= 64;                                // DV_STEP_IS_ONE: lets the leader confirm a predicted command from this word alone
-        hc[2 * b] = (seq[b] << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
+        hc[cs2 * b] = (seq[b] << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
         ncmd[b]++;
     };
     const bool tracing = std::getenv("FRX_TRACE") != nullptr;

@@ -89,6 +89,7 @@ struct RoundLaunch {
     int B, G, m, E, NXP;
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;
+    int cmd_stride = 4;                                            // h_cmd: candidate b's 16-byte command at 16 * cmd_stride * b
 };
 enum { ROUND_E = 56, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)

@@ -254,7 +254,7 @@ struct LdsView {
 
 // The body works on the pieces [gp0, gp0 + npieces) with one WAVE and `sm` = that wave's private LDS; every wave of the workgroup
 // has to call it (it contains workgroup barriers), idle ones with npieces = 0.
-template <bool SH>
+template <bool SH, bool LAT = false>
 __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double *__restrict__ T, const double *__restrict__ C,
                                              double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, bool wt = true) {
     const int hstride = (Kmax + 1) * 4;
@@ -311,9 +311,8 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
             const double s1 = step * j;                           // sample abscissa as cc.cu:152
             const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
             double adj[12], Ps, gTa;
-            penalty_sample(c, s1, omg * step, dp.pc, hb, K, adj, Ps, gTa);
-            c.fence();
-            FRX_PHASE();
+            penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, adj, Ps, gTa);
+            if (!LAT) { c.fence(); FRX_PHASE(); }
             // the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates
             double o[20];
             o[0] = omg * step * Ps; o[1] = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
@@ -352,13 +351,13 @@ __global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *
     const int gp0 = blockIdx.x * ppw;
     penalty_body<false>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
 }
-// The same kernel under a 128-VGPR budget (4 waves per SIMD instead of 3; the compiler spills 30 VGPRs = 124 bytes of scratch per lane to
-// get there).  Selected with FRX_PENALTY_WAVES=4 for measurement; DESIGN.md 6 has the numbers and the default.
-__global__ __launch_bounds__(64, 4) void k_penalty_occ4(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
-                                                        double *__restrict__ out20, int lpp, int ppw, int Kmax) {
+// The latency form of the same kernel (penalty_sample<LAT>): for grids that cannot fill the chip (fewer workgroups than twice the SIMDs),
+// where the launch is one wave's latency long and registers are free.
+__global__ __launch_bounds__(64, 1) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                       double *__restrict__ out20, int lpp, int ppw, int Kmax) {
     extern __shared__ double sm[];
     const int gp0 = blockIdx.x * ppw;
-    penalty_body<false>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
+    penalty_body<false, true>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

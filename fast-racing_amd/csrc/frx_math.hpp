@@ -119,7 +119,9 @@ struct PtrView {
 //   adj   = out: a0,a1,a2,a3 (12 doubles), already weighted by ws
 //   Psum  = out: sum of chi*viol^3 (not weighted)
 //   gTalpha = out: a0.v + a1.a + a2.j + a3.s  (to be multiplied by alpha = j/kappa)
-template <class CV, class HV>
+//   LAT   = latency form: no phase boundaries and no forgetting - the scheduler may interleave the corridor loop with the limits (which
+//           do not depend on it) at the price of registers; for launches that cannot fill the chip anyway (one wave's latency IS the launch)
+template <bool LAT, class CV, class HV>
 FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, HV hb, int K, double *adj, double &Psum, double &gTalpha) {
     // ---- phase A: position and attitude only (CPU.hpp:260-279); everything else is evaluated after the loop ----
     double pl[3], zB[3], yB[3], xB[3], invF, invM;
@@ -135,8 +137,7 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
         yB[0] = 0.0; yB[1] = zB[2] * invM; yB[2] = -zB[1] * invM;
         cross3(yB, zB, xB);
     }
-    c.fence();
-    FRX_PHASE();
+    if (!LAT) { c.fence(); FRX_PHASE(); }
 
     double a0[3] = {0, 0, 0};
     double U0[3] = {0, 0, 0}, U1[3] = {0, 0, 0}, U2[3] = {0, 0, 0};
@@ -176,13 +177,13 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
         }
         P += pc.chi[0] * Pcorr;
     }
-    FRX_PHASE();
+    if (!LAT) FRX_PHASE();
 
     // ---- phase B: limits (CPU.hpp:281-304, 347-398) and reverse passes, one derivative at a time so that
     //      vel/acc/jer/sna are never live together; gTalpha = a0.v + a1.a + a2.j + a3.s is accumulated on the way ----
     double a2[3] = {0, 0, 0};
     if (needReverse) frame_reverse(U0, U1, U2, zB, yB, invF, invM, a2);      // corridor part of d pen / d acc
-    FRX_PHASE();
+    if (!LAT) FRX_PHASE();
     double gT;
     {   // velocity limit (CPU.hpp:347-359)
         double vel[3];
@@ -198,8 +199,7 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
 #pragma unroll
         for (int d = 0; d < 3; d++) adj[3 + d] = wV * vel[d];
     }
-    c.fence();
-    FRX_PHASE();
+    if (!LAT) { c.fence(); FRX_PHASE(); }
     double h[3], wH = 0.0;                                      // weight on dSqrMagThr = 2h
     {   // thrust limits (CPU.hpp:361-385; both use chi[2])
         double acc[3];
@@ -219,8 +219,7 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
             P += pc.chi[2] * (v2 * violaThrh);
         }
     }
-    c.fence();
-    FRX_PHASE();
+    if (!LAT) { c.fence(); FRX_PHASE(); }
     double a3[3] = {0, 0, 0};
     {   // body-rate limit (CPU.hpp:285-299, 387-398)
         double jer[3];
@@ -251,8 +250,7 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
         for (int d = 0; d < 3; d++) a2[d] += 2.0 * wH * h[d];
         gT += dot3(a2, jer);
     }
-    c.fence();
-    FRX_PHASE();
+    if (!LAT) { c.fence(); FRX_PHASE(); }
     {
         double sna[3];
         poly_eval<4>(c, s1, sna);
@@ -270,7 +268,7 @@ FRX_HD void penalty_sample(const double *c, const double *, double s1, double ws
         const double *org, *hs;
         FRX_HD double operator[](int i) const { return i < 4 ? org[i < 3 ? i : 0] : hs[i - 4]; }
     };
-    penalty_sample(PtrView{c}, s1, ws, pc, Blk{org, hs}, K, adj, Psum, gTalpha);
+    penalty_sample<false>(PtrView{c}, s1, ws, pc, Blk{org, hs}, K, adj, Psum, gTalpha);
 }
 
 // C2 / exponential time diffeomorphism, forward and derivative (CPU.hpp:639-641, 826-839)

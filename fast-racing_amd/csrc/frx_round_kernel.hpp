@@ -52,7 +52,7 @@ enum { DV_QUIT = 128, DV_STEP_IS_ONE = 64 };   // extra command flags of the res
                                                // leader confirm a predicted command from the command WORD alone (no second read over PCIe)
 
 // host -> device: word = seq << 32 | bound << 20 | slot << 8 | flags (written last); step first.  device -> host: seq written last.
-struct RoundCmd { rk_u64 word; double step; };
+struct RoundCmd { rk_u64 word; double step; };                          // candidate c's command is h_cmd[c * cmd_stride] (cmd_stride 4: one cache line per candidate)
 struct RoundRes { double f, dg, xx, gg, dginit, pad[2]; rk_u64 seq; };
 static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 
@@ -100,6 +100,8 @@ struct RoundArgs {
     rk_u64 census_ticks;                     // bound of the start-up census (all workgroups resident)
     double ls_ftol, ls_gtol, ls_min_step, ls_max_step;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
     int ls_max_linesearch, speculate;
+    int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
+    int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
     int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
@@ -129,6 +131,10 @@ __device__ __forceinline__ void rk_load_cmd(const RoundCmd *p, rk_u64 &word, rk_
     word = (rk_u64)r.x | ((rk_u64)r.y << 32); step = (rk_u64)r.z | ((rk_u64)r.w << 32);
 }
 
+// pause between two polls of a word another workgroup will write: a.poll_sleep selects the length (s_sleep takes an immediate)
+#define RK_PAUSE(a) do { switch ((a).poll_sleep) { case 0: __builtin_amdgcn_s_sleep(1); break; case 1: __builtin_amdgcn_s_sleep(2); break; \
+                                                 case 2: __builtin_amdgcn_s_sleep(4); break; default: __builtin_amdgcn_s_sleep(8); break; } } while (0)
+
 // ---- bounded waits (ONE lane) ----
 __device__ __forceinline__ bool rk_expired(const RoundArgs &a, rk_u64 deadline) {
     return __hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u || wall_clock64() > deadline;
@@ -138,7 +144,7 @@ __device__ __forceinline__ bool rk_wait_eq(const unsigned *w, unsigned want, con
     for (unsigned spins = 0;; spins++) {
         if (__hip_atomic_load(w, FRX_RLX_AGENT) == want) return true;
         if ((spins & 31u) == 31u && rk_expired(a, dl)) return false;
-        __builtin_amdgcn_s_sleep(1);
+        RK_PAUSE(a);
     }
 }
 __device__ __forceinline__ void rk_fail(const RoundArgs &a, unsigned code) {
@@ -167,7 +173,7 @@ __device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const Round
     for (int base = 0; base < ntasks; base += per_pass) {
         const int task = base + pw * 4 + v.wave;
         const int np = task < ntasks ? min(a.ppw, v.N - task * a.ppw) : 0;
-        penalty_body<true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, v.p0 + task * a.ppw, np, ev + (size_t)v.wave * a.pen_lds, v.lane, v.wt);
+        penalty_body<true, true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, v.p0 + task * a.ppw, np, ev + (size_t)v.wave * a.pen_lds, v.lane, v.wt);   // latency form: a wave has its SIMD to itself
         __syncthreads();
     }
 }
@@ -247,7 +253,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 rk_u64 w = 0, stp = 0;
                 bool ok = true;
                 for (unsigned spins = 0;; spins++) {
-                    rk_load_cmd(a.h_cmd + c, w, stp);
+                    rk_load_cmd(a.h_cmd + c * a.cmd_stride, w, stp);
                     if ((w >> 32) == hseq + 1) break;
                     if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                 }
@@ -340,7 +346,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         }
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
             rk_u64 early_w = 0;                                             // the host's command for a predicted round: read it while the adjoint runs
-            if (unconfirmed && t == 0) early_w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
+            if (unconfirmed && t == 0) early_w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             rk_drain_and_meet();
@@ -351,7 +357,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     rk_u64 w = early_w;
                     bool ok = true;
                     for (unsigned spins = 0; (w >> 32) != hseq; spins++) {
-                        w = __hip_atomic_load(&a.h_cmd[c].word, FRX_RLX_SYS);
+                        w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
                         if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                     }
                     unsigned verdict = 0u;                                   // 0 confirmed, 1 host stopped (QUIT), 2 anything else
@@ -433,7 +439,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
                 w = __hip_atomic_load(a.phase + c * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(1);
+                RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
             ctlU[0] = w & 15u;
@@ -551,7 +557,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                 w = __hip_atomic_load(a.phase + c * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(1);
+                RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
             ctlU[0] = w & 15u;
