@@ -180,7 +180,7 @@ def main():
     adj_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + 160 * npc + (8 * steps + 4) * 8 * npc + 8 * nx + 8))
     stage_bytes = {"forward": fwd_bytes, "penalty": alg_bytes, "adjoint": adj_bytes}
     dominant = max(stage_us, key=stage_us.get)
-    dom_kernel = {"forward": "frx::k_forward_knot", "penalty": "frx::k_penalty", "adjoint": "frx::k_backward_knot"}[dominant]
+    dom_kernel = {"forward": "frx::k_forward_knot", "penalty": "frx::k_penalty_lat", "adjoint": "frx::k_backward_knot"}[dominant]
     dom_achieved = stage_bytes[dominant] / (stage_us[dominant] * 1e-6) / 1e9
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
     fp64 = None
@@ -205,7 +205,7 @@ def main():
     valu = None
     valu_file = os.path.join(ROOT, "profiles", "r02_pmc_headline.json")
     if os.path.exists(valu_file) and args.config == "headline":
-        vj = json.load(open(valu_file)).get("valu_3_waves_per_simd", {})
+        vj = json.load(open(valu_file)).get("valu_latency_form_148_vgprs_default", {})
         cls = sorted(vj.items(), key=lambda kv: int(kv[0].split("_")[1]))          # launch classes by grid size: headline, large batch
         if cls:
             valu = {"source": "profiles/r02_pmc_headline.json", "headline_valu_busy": cls[0][1]["valu_busy_frac"],
@@ -311,7 +311,7 @@ def main():
                          "unit": "GB/s", "frac": dom_achieved / HBM_PEAK_GBS, "traffic": traffic if dominant == "penalty" else None,
                          "algorithmic_bytes_per_launch": stage_bytes[dominant], "avg_kernel_us": stage_us[dominant],
                          "stage_kernels_us": stage_us, "stage_algorithmic_bytes": stage_bytes,
-                         "penalty": {"kernel": "frx::k_penalty", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_kernel_us": pen_us, "traffic": traffic,
+                         "penalty": {"kernel": "frx::k_penalty_lat", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_kernel_us": pen_us, "traffic": traffic,
                                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
                                      "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6), "fp64": fp64, "large_batch": large, "valu": valu},
                          "hbm_bound_kernel": hbm_kernel, "states": states},

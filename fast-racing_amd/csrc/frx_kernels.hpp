@@ -822,7 +822,7 @@ __device__ __forceinline__ void pcr_waves2_wg(double *rowbuf, int nrow, int t, i
 // 11.1 k of the forward map's 19.4 k cycles.  Per step the wave also (i) takes the rows beyond the ends from an IDENTITY row (row 0,
 // knot 0 is not an unknown) instead of selecting 24 doubles lane by lane, (ii) uses the symmetry of the system, U_{k-s} = L_k^T and
 // L_{k+s} = U_k^T at every level (frx_minco.hpp: K is the Hessian of the jerk energy), instead of reading those blocks, and
-// (iii) inverts the 2x2 diagonal block with rcp_fast.
+// (iii) inverts the 2x2 diagonal block with rcp_fast.  (The symmetry goes all the way: U is not even part of a row's state.)
 // ---------------------------------------------------------------------------------------------
 typedef volatile __attribute__((address_space(3))) unsigned *lds_vuptr;
 __device__ __forceinline__ void lds_wait_ge(lds_vuptr w, unsigned want) {
@@ -839,25 +839,25 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
     const bool act = kk >= 1 && kk <= N - 1;
     int nst = 0;
     for (int s = 1; s < N - 1; s <<= 1) nst++;
-    double D[4], L[4], U[4], I[4];
+    // State of a row: D and L only.  U is never kept: at every level U_k = L_{k+s}^T (the system is symmetric), so the block a step needs
+    // is the transpose of the L it reads from the row above anyway, and the U recurrence (a 2x2 product, two LDS writes) disappears.
+    double D[4], L[4], I[4];
     {
         KnotRow me;
         knot_row_matrix(hL, hR, me);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { D[i] = me.D[i]; L[i] = kk == 1 ? 0.0 : me.L[i]; U[i] = kk == N - 1 ? 0.0 : me.U[i]; }   // fixed end knots: their coupling is on the right-hand side
+        for (int i = 0; i < 4; i++) { D[i] = me.D[i]; L[i] = kk == 1 ? 0.0 : me.L[i]; }   // fixed head knot: its coupling is on the right-hand side (the tail's too: no row N)
     }
     m2_inv_fast(D, I);
-    if (kk == 0) {                                                  // the identity row, in both buffers
+    if (kk == 0) {                                                  // the identity row (D^-1 = 1, L = 0) stands in for the rows beyond both ends, in both buffers
 #pragma unroll
         for (int buf = 0; buf < 2; buf++) {
             MR2(buf, 0, 0) = make_double2(1.0, 0.0); MR2(buf, 1, 0) = make_double2(0.0, 1.0);
-#pragma unroll
-            for (int f = 2; f < 6; f++) MR2(buf, f, 0) = make_double2(0.0, 0.0);
+            MR2(buf, 2, 0) = make_double2(0.0, 0.0); MR2(buf, 3, 0) = make_double2(0.0, 0.0);
         }
     } else if (act) {
         MR2(0, 0, kk) = make_double2(I[0], I[1]); MR2(0, 1, kk) = make_double2(I[2], I[3]);
         MR2(0, 2, kk) = make_double2(L[0], L[1]); MR2(0, 3, kk) = make_double2(L[2], L[3]);
-        MR2(0, 4, kk) = make_double2(U[0], U[1]); MR2(0, 5, kk) = make_double2(U[2], U[3]);
     }
     double2 *sp = save ? (double2 *)(save + (gk0 + kk) * sstride) : nullptr;     // null: the multipliers stay in LDS (resident caller)
     for (int it = 0; it < nst; it++) {
@@ -865,30 +865,27 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
         const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
         const int klo = inlo ? kk - s : 0, khi = inhi ? kk + s : 0;
         const double2 a0 = MR2(buf, 0, klo), a1 = MR2(buf, 1, klo), a2 = MR2(buf, 2, klo), a3 = MR2(buf, 3, klo);
-        const double2 b0 = MR2(buf, 0, khi), b1 = MR2(buf, 1, khi), b4 = MR2(buf, 4, khi), b5 = MR2(buf, 5, khi);
+        const double2 b0 = MR2(buf, 0, khi), b1 = MR2(buf, 1, khi), b2 = MR2(buf, 2, khi), b3 = MR2(buf, 3, khi);
         const double iLo[4] = {a0.x, a0.y, a1.x, a1.y}, lL[4] = {a2.x, a2.y, a3.x, a3.y};
-        const double iHi[4] = {b0.x, b0.y, b1.x, b1.y}, hU[4] = {b4.x, b4.y, b5.x, b5.y};
-        const double Lt[4] = {L[0], L[2], L[1], L[3]}, Ut[4] = {U[0], U[2], U[1], U[3]};   // = U of the row below / L of the row above
+        const double iHi[4] = {b0.x, b0.y, b1.x, b1.y}, hL[4] = {b2.x, b2.y, b3.x, b3.y};
+        const double U[4] = {hL[0], hL[2], hL[1], hL[3]};           // this row's U = (L of the row above)^T
+        const double Lt[4] = {L[0], L[2], L[1], L[3]};              // = U of the row below
         double al[4], be[4], tt[4];
         m2_mul(L, iLo, al);                                         // pcr_step_inv, matrix part
         m2_mul(U, iHi, be);
         m2_mul(al, Lt, tt);
 #pragma unroll
         for (int i = 0; i < 4; i++) D[i] = D[i] - tt[i];
-        m2_mul(be, Ut, tt);
+        m2_mul(be, hL, tt);
 #pragma unroll
         for (int i = 0; i < 4; i++) D[i] -= tt[i];
         m2_mul(al, lL, tt);
 #pragma unroll
         for (int i = 0; i < 4; i++) L[i] = -tt[i];
-        m2_mul(be, hU, tt);
-#pragma unroll
-        for (int i = 0; i < 4; i++) U[i] = -tt[i];
         m2_inv_fast(D, I);
         if (act) {
             MR2(buf ^ 1, 0, kk) = make_double2(I[0], I[1]); MR2(buf ^ 1, 1, kk) = make_double2(I[2], I[3]);
             MR2(buf ^ 1, 2, kk) = make_double2(L[0], L[1]); MR2(buf ^ 1, 3, kk) = make_double2(L[2], L[3]);
-            MR2(buf ^ 1, 4, kk) = make_double2(U[0], U[1]); MR2(buf ^ 1, 5, kk) = make_double2(U[2], U[3]);
 #pragma unroll
             for (int i = 0; i < 4; i++) { pw[kk * pws + it * 8 + i] = al[i]; pw[kk * pws + it * 8 + 4 + i] = be[i]; }
             if (sp) {

@@ -148,6 +148,9 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
     {
         const double e0 = pc.ell[0], e1 = pc.ell[1], e2 = pc.ell[2];
         double Pcorr = 0.0;
+#if defined(FRX_COUNT_BUILD)                                     // scripts/count_fp64.py: one copy of the loop body, so that static counts are per iteration
+#pragma unroll 1
+#endif
         for (int k = 0; k < K; k++) {
             const int r = 4 + 4 * k;
             const double n[3] = {hb[r], hb[r + 1], hb[r + 2]};

@@ -11,9 +11,10 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 src = os.path.join(ROOT, "fast-racing_amd", "csrc", "frx_device.hip")
 with tempfile.TemporaryDirectory() as td:
     out = os.path.join(td, "frx.s")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DFRX_COUNT_BUILD", "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)   # FRX_COUNT_BUILD: the half-space loop is not unrolled (frx_math.hpp)
     lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3frx9k_penaltyE"))
+sym = "_ZN3frx13k_penalty_latE" if (len(sys.argv) <= 2 or sys.argv[2] != "thr") else "_ZN3frx9k_penaltyE"   # default form of the kernel: latency form
+start = next(i for i, l in enumerate(lines) if l.startswith(sym))
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 body = lines[start:end]
 f64 = re.compile(r"^\s+(v_[a-z0-9_]*_f64)(?:_e32|_e64|_dpp|_sdwa)?\b")
@@ -38,7 +39,8 @@ sample = body[hdr1:tail1]
 n_all, f_all = flops(sample)
 n_hs, f_hs = flops(body[hs_lo:hs_hi])
 n_test, f_test = flops(body[hs_hdr:first_branch])
-res = {"kernel": "frx::k_penalty", "K": K,
+res = {"kernel": "frx::k_penalty_lat (default form)" if "lat" in sym else "frx::k_penalty (throughput form, FRX_PENALTY_FORM=thr)", "K": K,
+       "note": "static count of a build whose half-space loop is not unrolled; includes the 20 adds of the accumulate path that only runs with more than one sample per lane (kappa + 1 > 64)",
        "fp64_instructions": {"fixed": n_all - n_hs, "hs_test": n_test, "hs_violated_extra": n_hs - n_test},
        "flops": {"fixed": f_all - f_hs, "hs_test": f_test, "hs_violated_extra": f_hs - f_test}}
 res["flops_per_sample_no_violation"] = res["flops"]["fixed"] + K * f_test

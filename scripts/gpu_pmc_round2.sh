@@ -1,7 +1,8 @@
 # Round-2 counter passes of the penalty integrator (run in the SAME gpurun call as the bench line they accompany):
 #   HBM traffic per launch  FETCH_SIZE, WRITE_SIZE in separate --pmc runs; FETCH_SIZE doubled (gfx950 counts a 16-byte-per-lane coalesced
 #                           stream at half its bytes, MI355X_MICROARCH.md "HBM"; the kernel stages with 16-byte loads since round 2)
-#   VALU utilisation        SQ counters on the replicated 1024-candidate batch and on the headline batch
+#   VALU utilisation        SQ counters on the replicated 1024-candidate batch and on the headline batch, for both forms of the kernel
+#                           (latency form = default, throughput form = FRX_PENALTY_FORM=thr)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 CMD="python $R/scripts/kernel_sweep.py --batches 32,1024 --states it60 --reps 30"
@@ -9,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc2_$c -o p -- $CMD > /dev/null 2> $R/gpurun_out/pmc2_$c.err
 done
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc2_valu -o p -- $CMD > /dev/null 2> $R/gpurun_out/pmc2_valu.err
-FRX_PENALTY_WAVES=4 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc2_valu4 -o p -- $CMD > /dev/null 2> $R/gpurun_out/pmc2_valu4.err
+FRX_PENALTY_FORM=thr timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc2_valu4 -o p -- $CMD > /dev/null 2> $R/gpurun_out/pmc2_valu4.err
 cd $R
 python - <<'PY'
 import csv, json, collections
@@ -36,7 +37,7 @@ for name in ("pmc2_valu", "pmc2_valu4"):
         cyc = m["GRBM_GUI_ACTIVE"] / 8
         out["grid_%d" % grid] = {"kernel_cycles": cyc, "valu_busy_frac": 4.0 * m["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, "mean_waves_per_simd": 4.0 * m["SQ_WAVE_CYCLES"] / 1024 / cyc,
                                  "valu_insts_per_wave": m["SQ_INSTS_VALU"] / m["SQ_WAVES"], "wait_frac_of_wave_cycles": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]}
-    res["valu_3_waves_per_simd" if name == "pmc2_valu" else "valu_4_waves_per_simd_30_vgprs_spilled"] = out
+    res["valu_latency_form_148_vgprs_default" if name == "pmc2_valu" else "valu_throughput_form_126_vgprs"] = out
 json.dump(res, open("gpurun_out/r02_pmc_headline.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
