@@ -38,7 +38,9 @@ def iterates(o, n_iter_list=(0, 15, 60)):
 
 @pytest.mark.parametrize("solver", ["knot_pcr", "banded_lu"])
 @pytest.mark.parametrize("B,N,gates,kappa,obst", [(3, 32, 8, 8, False), (2, 64, 16, 16, True), (2, 8, 2, 48, True), (1, 12, 3, 70, False),
-                                                  (2, 2, 0, 8, False), (2, 1, 0, 8, False), (1, 100, 25, 8, False), (1, 65, 16, 8, False), (1, 128, 32, 8, False)])
+                                                  (2, 2, 0, 8, False), (2, 1, 0, 8, False), (1, 100, 25, 8, False), (1, 65, 16, 8, False), (1, 128, 32, 8, False),
+                                                  # few knots: 0 / 1 / 2 / 3 reduction steps of the matrix wave (its barrier sits behind step 0, 0, 1, 1), 63 knots at 64 pieces
+                                                  (2, 3, 0, 8, False), (2, 4, 0, 8, False), (1, 5, 0, 8, False), (1, 9, 1, 8, False), (1, 63, 15, 8, False)])
 def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst, solver):
     cands, prob, oracles = make(frx, sc, ob, B, N, gates, kappa, obstacles=obst)
     prob.set_solver(solver)
