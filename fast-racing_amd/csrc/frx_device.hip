@@ -82,7 +82,7 @@ int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void
 // previous point and previous gradient (rk_leader_loop)
 static int round_ct_doubles(const LaunchGeom &g) {
     const int xpad = (g.maxXb + 1) & ~1, vpad = (g.maxVb + g.knot_threads + 1) & ~1, pw = (g.pcr_steps * 8 + 5) * g.knot_threads;
-    return ((g.maxN * 19 + 1) & ~1) + 5 * xpad + vpad + ((pw + 1) & ~1);
+    return ((g.maxN * 19 + 1) & ~1) + 5 * xpad + vpad + ((pw + 1) & ~1) + 4 * g.knot_threads;
 }
 static int round_eval_doubles(const LaunchGeom &g) {
     const size_t pen = (size_t)g.ppw * 19 + (size_t)g.ppw * (g.Kmax + 1) * 4 + 64 * 21;              // doubles per wave (LaunchGeom::lds_pen)

@@ -58,11 +58,12 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
 // Operands that a RESIDENT caller (frx_round_kernel.hpp, leader workgroup) keeps in LDS from round to round, so that the evaluation
 // bodies neither stage them from global memory nor send the reduction multipliers through it: xs = the candidate's variables,
 // vs = its waypoint polytopes, dsv = the search direction, pw = [nrow][8 steps + 5] multipliers (only used by the wave-specialised
-// reduction, nrow == 64), gs = where the gradient goes.  vskew = 1: the polytope of waypoint w starts w doubles further on than in the
+// reduction, nrow == 64), gs = where the gradient goes, wq (optional, [nrow][4]) = per waypoint {|xi|^2, sum_a V_a xi_a^2} left by the forward map for the
+// adjoint of the same evaluation (its first pass over the vertices then is three multiplications).  vskew = 1: the polytope of waypoint w starts w doubles further on than in the
 // packed layout.  The blocks of consecutive waypoints are 3 nv doubles apart (36 for the 12-vertex overlaps of box corridors: a
 // multiple of 4 - the lanes of a wave, one waypoint per lane pair, then hit 8 of the 32 LDS double-banks, a four-way conflict on
 // every read of the waypoint map and of its adjoint, measured 2.7 k cycles for a 12-vertex pass); one double of skew makes the stride odd.  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
-struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g (no global store to drain behind the adjoint)
+struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g (no global store to drain behind the adjoint)
 
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
@@ -1021,6 +1022,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 }
                 nrm += dpp_mov<0xB1>(nrm); q0 += dpp_mov<0xB1>(q0); q1 += dpp_mov<0xB1>(q1); q2 += dpp_mov<0xB1>(q2);   // pair sums
                 if (wact && sub == 0) {
+                    if (ro && ro->wq) { double *wq = ro->wq + 4 * w; wq[0] = nrm; wq[1] = q0; wq[2] = q1; wq[3] = q2; }
                     const double sc = 2.0 / (1.0 + nrm), sc2 = sc * sc;
                     KN(KP, 0, w + 1) = sc2 * q0 + V[0]; KN(KP, 1, w + 1) = sc2 * q1 + V[1]; KN(KP, 2, w + 1) = sc2 * q2 + V[2];
                 }
@@ -1069,22 +1071,32 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 r0 = n0; r1 = n1;
             }
             FRX_STAMP_AX(11);
+            // everything of the Hermite stage that does not need the solution is computed while the matrix wave finishes: durations and their
+            // powers, the position part of the coefficients (hermite_coeffs with v = a = 0), the fixed end states
+            const int kp = kk < N ? kk : 0;
+            const double hK = Tf[kp], pK = KN(KP, ax, kp), pR = KN(KP, ax, kp + 1);
+            const double ih = rcp_fast(hK), ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih, dl = pR - pK;
+            const double c3p = 10.0 * dl * ih3, c4p = -15.0 * dl * ih4, c5p = 6.0 * dl * ih5;
+            const double vHead = KN(KV, ax, 0), aHead = KN(KA, ax, 0), vTail = KN(KV, ax, N), aTail = KN(KA, ax, N);
+            double *co = Cout + (size_t)(p0 + kp) * 18 + ax;
             lds_wait_ge(progress, (unsigned)(nst + 1));
             double vK, aK;                                                 // (v, a) of knot kk on this axis
             {
                 const double *Di = pwf + kc * pws + nsteps * 8;
                 vK = Di[0] * r0 + Di[1] * r1; aK = Di[2] * r0 + Di[3] * r1;
             }
-            if (kk == 0) { vK = KN(KV, ax, 0); aK = KN(KA, ax, 0); }
+            if (kk == 0) { vK = vHead; aK = aHead; }
             double vR = __shfl_down(vK, 1, 64), aR = __shfl_down(aK, 1, 64);
-            if (kk == N - 1) { vR = KN(KV, ax, N); aR = KN(KA, ax, N); }
-            // piece coefficients of this axis (quintic Hermite): piece kk between knots kk and kk + 1
+            if (kk == N - 1) { vR = vTail; aR = aTail; }
+            // piece coefficients of this axis (quintic Hermite, hermite_coeffs term by term): piece kk between knots kk and kk + 1
             if (kk < N) {
                 double cq[6];
-                hermite_coeffs(Tf[kk], KN(KP, ax, kk), vK, aK, KN(KP, ax, kk + 1), vR, aR, cq);
-                double *co = Cout + (size_t)(p0 + kk) * 18;
+                cq[0] = pK; cq[1] = vK; cq[2] = 0.5 * aK;
+                cq[3] = c3p - (4.0 * vR + 6.0 * vK) * ih2 - 0.5 * (3.0 * aK - aR) * ih;
+                cq[4] = c4p + (7.0 * vR + 8.0 * vK) * ih3 + 0.5 * (3.0 * aK - 2.0 * aR) * ih2;
+                cq[5] = c5p - 3.0 * (vR + vK) * ih4 - 0.5 * (aK - aR) * ih3;
 #pragma unroll
-                for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, cq[q], wt); if (ct_lds) ct_lds[kk * 19 + q * 3 + ax] = cq[q]; }
+                for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3, cq[q], wt); if (ct_lds) ct_lds[kk * 19 + q * 3 + ax] = cq[q]; }
             }
             FRX_STAMP_AX(12);
         }
@@ -1428,7 +1440,9 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             // with r_a = sc xi_a, sc = 2 / (1 + |xi|^2):  d f / d xi_a = xi_a (2 sc^2 (V_a . g) - 4 gdq / (1 + |xi|^2)^2),
             // gdq = 2 sc sum_a (V_a . g) xi_a^2  -  so |xi|^2 and the weighted sum come out of ONE pass over the vertices
             double s2 = 0.0;
-            if (wact)
+            const bool cached = ro && ro->wq;                           // the forward map of this evaluation left both sums in LDS (same workgroup, resident caller)
+            if (wact && cached) { const double *wq = ro->wq + 4 * w; qn = wq[0]; s2 = wq[1] * g0 + wq[2] * g1 + wq[3] * g2; }
+            if (wact && !cached)
                 for (int a0 = sub; a0 < nv1; a0 += 8) {                   // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
                     double xv[4], dgv[4];
 #pragma unroll
@@ -1438,7 +1452,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                         if (a0 + 2 * j < nv1) { const double x2 = xv[j] * xv[j]; qn += x2; s2 += dgv[j] * x2; }
                 }
             FRX_STAMP_AX(30);
-            qn += dpp_mov<0xB1>(qn); s2 += dpp_mov<0xB1>(s2);        // pair sums
+            if (!cached) { qn += dpp_mov<0xB1>(qn); s2 += dpp_mov<0xB1>(s2); }   // pair sums
             const double qp1 = qn + 1.0, iq = 1.0 / qp1, sc = 2.0 * iq;
             const double gdq = 2.0 * sc * s2, kq = 4.0 * gdq * (iq * iq), sc22 = 2.0 * sc * sc;
             FRX_STAMP_AX(31);

@@ -199,6 +199,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     // load / store through L2 and the adjoint's gradient stores had to be drained before the round could go on.
     ro.gs = ro.pw + (((a.nsteps * 8 + 5) * a.nrow + 1) & ~1);
     double *x = ro.xs, *g = ro.gs, *xp = ro.gs + xpad, *gp = xp + xpad, *dv = ro.dsv;
+    ro.wq = gp + xpad;                                                    // [nrow][4], forward map -> adjoint of the same evaluation
     {
         const int v0 = a.dp.cvoff[c], nvd = 3 * (a.dp.cvoff[c + 1] - v0);
         const double *vsrc = a.dp.vrec + 3 * (size_t)v0;
