@@ -991,6 +991,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         // ---- <= 64 pieces: wave 0 = matrix wave (pcr_matrix_wave64), waves 1-3 = one axis each ----
         const int wave = __builtin_amdgcn_readfirstlane(k >> 6), kk = k & 63;
         const int pws = nsteps * 8 + 5;
+        double *cstage = ct_lds ? ct_lds : rowbuf;                         // where the coefficients are collected (the matrix rows are dead by the time the axis waves write here)
         if (wave == 0) {
             // durations left and right of knot kk: the left one comes from the neighbouring lane (lane = piece = knot)
             const double hLs = __shfl_up(hMine, 1, 64);
@@ -1078,7 +1079,6 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             const double ih = rcp_fast(hK), ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih, dl = pR - pK;
             const double c3p = 10.0 * dl * ih3, c4p = -15.0 * dl * ih4, c5p = 6.0 * dl * ih5;
             const double vHead = KN(KV, ax, 0), aHead = KN(KA, ax, 0), vTail = KN(KV, ax, N), aTail = KN(KA, ax, N);
-            double *co = Cout + (size_t)(p0 + kp) * 18 + ax;
             lds_wait_ge(progress, (unsigned)(nst + 1));
             double vK, aK;                                                 // (v, a) of knot kk on this axis
             {
@@ -1095,10 +1095,21 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 cq[3] = c3p - (4.0 * vR + 6.0 * vK) * ih2 - 0.5 * (3.0 * aK - aR) * ih;
                 cq[4] = c4p + (7.0 * vR + 8.0 * vK) * ih3 + 0.5 * (3.0 * aK - 2.0 * aR) * ih2;
                 cq[5] = c5p - 3.0 * (vR + vK) * ih4 - 0.5 * (aK - aR) * ih3;
+                // to LDS only: 18 doubles per piece (stride 19), the caller's (C, T) copy when it keeps one, the dead row buffer otherwise
 #pragma unroll
-                for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3, cq[q], wt); if (ct_lds) ct_lds[kk * 19 + q * 3 + ax] = cq[q]; }
+                for (int q = 0; q < 6; q++) cstage[kk * 19 + q * 3 + ax] = cq[q];
             }
             FRX_STAMP_AX(12);
+        }
+        // C leaves the workgroup as ONE coalesced sweep of 16-byte stores by all four waves.  Stored straight from the axis lanes it was 1152
+        // scattered 8-byte write-through stores (lane stride 144 bytes), and draining them cost the resident kernel ~2 us per round.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int i = k; i < 9 * N; i += 256) {                              // 9 pairs of doubles per piece
+            const int pc = i / 9, q2 = 2 * (i - 9 * pc);
+            const double v0 = cstage[pc * 19 + q2], v1 = cstage[pc * 19 + q2 + 1];
+            double *dst = Cout + (size_t)(p0 + pc) * 18 + q2;
+            if (SH && wt) { stg<SH>(dst, v0, true); stg<SH>(dst + 1, v1, true); }
+            else *(double2 *)dst = make_double2(v0, v1);
         }
         FRX_STAMP(6);
         return;
