@@ -361,6 +361,11 @@ __global__ __launch_bounds__(64, 1) void k_penalty_lat(DevProblem dp, const doub
     penalty_body<false, true>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
 }
 
+// (A streaming form for large batches - 3072 one-wave workgroups walking over the wave-tasks with the next task's global reads in flight during
+// the current task's samples - was built and measured in round 2: correct, but SLOWER than one task per workgroup, 43.9 vs 40.2 us at 1024
+// candidates and 164 vs 145 us at 4096; the prefetched registers force the phased form of the sample, and load latency was not what the
+// launch was waiting for: DESIGN.md 3.2.)
+
 // ---------------------------------------------------------------------------------------------
 // k_backward: grid = B, block = 64.  Dynamic LDS: band[6N*13] | gd[6N*3] | cL[6N*3] | Tf[N] | gT[N] | gC[cN]
 // ---------------------------------------------------------------------------------------------

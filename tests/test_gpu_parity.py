@@ -416,3 +416,24 @@ def test_lost_round_is_reported_and_the_handle_stays_usable(frx, sc):
     r2 = q.optimize(1e-5)
     assert np.array_equal(r1["x"], r2["x"]) and np.array_equal(r1["evals"], r2["evals"]) and np.all(r1["status"] >= 0)
     p.close(); q.close()
+
+
+def test_penalty_of_a_large_batch_reproduces_the_small_batch(frx, sc):
+    """320 candidates = the 32 headline candidates ten times over (6827 wave-tasks, more than twice the chip's 3072 wave slots: the grid
+    runs in several waves of workgroups): every replica must reproduce the 32-candidate batch, which the tests above check against the
+    oracle.  (Written for the streaming form of the integrator, which was measured slower and removed; the property stays worth a test.)"""
+    B0, N, gates, kappa = sc.CONFIGS["headline"]
+    base = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B0)]
+    small = frx.Problem(base, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x = small.optimize(1e-6, max_iterations=40)["x"]                       # a state with active penalties
+    T, Cf = small.forward(x)
+    c0, gT0, gC0 = small.penalty(T, Cf)
+    small.close()
+    rep = 10
+    big = frx.Problem(base * rep, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    c1, gT1, gC1 = big.penalty(np.tile(T, rep), np.tile(Cf.reshape(-1), rep))
+    big.close()
+    for r in range(rep):
+        assert rel(c1[r * B0:(r + 1) * B0], c0) < 1e-13
+        assert rel(gT1[r * T.size:(r + 1) * T.size], gT0) < 1e-13
+        assert rel(gC1[r * gC0.shape[0]:(r + 1) * gC0.shape[0]], gC0) < 1e-13
