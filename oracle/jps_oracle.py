@@ -11,10 +11,12 @@ What is restated, with the reference lines it follows:
                                   graph_search.h:20-33 and the sift rules of the heap it uses (see boost_shim/)
   * the gate-to-gate splice       src/plan_manage/src/MinCoPlan_CPU.cpp:13-35
 
-Pinning: JPSPlanner and MapUtil include ROS, PCL and octomap headers and cannot be compiled here, so this part of the oracle is
-a restatement ("parity unpinned" for the post-processing).  The grid search underneath IS pinned: oracle/_ref/libref_jps.so is
-the reference's own graph_search.cpp compiled where it lies (recipe: oracle/Makefile, wrapper: ref_jps_wrap.cpp, heap:
-boost_shim/), `ref_grid_search` below calls it, and `astar` below is checked against it by tests/test_front_end.py.
+Pinning: oracle/_ref/libref_jps.so is the reference's own graph_search.cpp compiled where it lies (recipe: oracle/Makefile, wrapper:
+ref_jps_wrap.cpp, heap: boost_shim/); `ref_grid_search` below calls it, and `astar` below is checked against it by
+tests/test_front_end.py.  JPSPlanner and MapUtil include ROS, PCL and octomap headers; oracle/ros_shim/ holds empty stand-ins for the
+types those headers name, with which jps_planner.cpp and map_util.h compile UNMODIFIED into oracle/_ref/libref_jpsplanner.so
+(ref_jpsplanner_wrap.cpp; `RefPlanner` below).  The restatement in this file (Map, plan and the three path filters) is checked against
+that library bit for bit by tests/test_front_end.py, and so is the product.
 """
 import ctypes as C
 import math
@@ -309,3 +311,63 @@ def route(m: Map, start, goal, gates, eps=1.0, use_jps=False, search="auto"):
     if any(st):
         return [], st
     return out, st
+
+
+# ---- the reference's own JPSPlanner<3> / MapUtil<3>, compiled where they lie (oracle/_ref/libref_jpsplanner.so) ----
+_refp = None
+
+
+def ref_planner_lib():
+    global _refp
+    if _refp is None:
+        path = os.path.join(HERE, "_ref", "libref_jpsplanner.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        vp = C.c_void_p
+        R.ref_jp_create.argtypes = [vp, vp, vp, C.c_double]; R.ref_jp_create.restype = vp
+        R.ref_jp_destroy.argtypes = [vp]
+        R.ref_jp_mark.argtypes = [vp, vp, C.c_int, vp]
+        R.ref_jp_is_blocked.argtypes = [vp, vp, vp]; R.ref_jp_is_blocked.restype = C.c_int
+        R.ref_jp_float_to_int.argtypes = [vp, vp, vp]
+        R.ref_jp_plan.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int]; R.ref_jp_plan.restype = C.c_int
+        _refp = R
+    return _refp
+
+
+class RefPlanner:
+    """MapUtil<3>::setMap + JPSPlanner<3> of the reference itself."""
+
+    def __init__(self, origin, dim, res, cells):
+        self.R = ref_planner_lib()
+        self.dim = [int(d) for d in dim]
+        o = np.asarray(origin, np.float64); d = np.asarray(self.dim, np.int32)
+        c = np.ascontiguousarray(np.asarray(cells, np.int8).reshape(-1))
+        self.h = self.R.ref_jp_create(o.ctypes.data, d.ctypes.data, c.ctypes.data, float(res))
+
+    def close(self):
+        if self.h:
+            self.R.ref_jp_destroy(self.h); self.h = None
+
+    def mark_cloud(self, pts):
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.zeros(self.dim[0] * self.dim[1] * self.dim[2], np.int8)
+        self.R.ref_jp_mark(self.h, pts.ctypes.data, len(pts), out.ctypes.data)
+        return out
+
+    def is_blocked(self, a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return bool(self.R.ref_jp_is_blocked(self.h, a.ctypes.data, b.ctypes.data))
+
+    def float_to_int(self, p):
+        p = np.asarray(p, np.float64); out = np.zeros(3, np.int32)
+        self.R.ref_jp_float_to_int(self.h, p.ctypes.data, out.ctypes.data)
+        return out.tolist()
+
+    def plan(self, start, goal, eps=1.0, use_jps=False, cap=1 << 16):
+        s = np.asarray(start, np.float64); g = np.asarray(goal, np.float64)
+        raw = np.zeros((cap, 3)); path = np.zeros((cap, 3)); samp = np.zeros((cap, 3))
+        st, nr, np_, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        ok = self.R.ref_jp_plan(self.h, s.ctypes.data, g.ctypes.data, float(eps), int(use_jps), C.byref(st), raw.ctypes.data, C.byref(nr), path.ctypes.data,
+                                C.byref(np_), samp.ctypes.data, C.byref(ns), cap)
+        return {"ok": bool(ok), "status": st.value, "raw_path": raw[:nr.value].copy(), "path": path[:np_.value].copy(), "sample_path": samp[:ns.value].copy()}

@@ -1,7 +1,9 @@
 """the path-search front end (frx_grid_search / frx_jps_plan / frx_route_plan, csrc/frx_search.cpp).
 
 Checkers: oracle/_ref/libref_jps.so = the reference's own graph_search.cpp compiled where it lies (grid search, tables);
-oracle/jps_oracle.py = restatement of JPSPlanner<3>::plan's map queries and path post-processing, and of the A* search."""
+oracle/_ref/libref_jpsplanner.so = the reference's own JPSPlanner<3> and MapUtil<3> (jps_planner.cpp, map_util.h) compiled where they lie
+against empty ROS / PCL / octomap stand-ins; oracle/jps_oracle.py = restatement of the planner's map queries and path post-processing and
+of the A* search, itself checked against the compiled planner below."""
 import numpy as np
 import pytest
 
@@ -180,6 +182,66 @@ def test_planner_paths_equal_the_oracle_bit_for_bit(frx, search):
                     step = np.abs(np.diff(cs, axis=0))
                     assert step.max() <= 1 and step.sum(axis=1).min() >= 1
     assert n_ok >= 10
+
+
+needs_ref_planner = pytest.mark.skipif(jo.ref_planner_lib() is None, reason="oracle/_ref/libref_jpsplanner.so not built")
+
+
+@needs_ref_planner
+def test_planner_paths_equal_the_compiled_reference_planner(frx):
+    """The product AND the restatement against JPSPlanner<3>::plan itself (jps_planner.cpp:333-420 compiled where it lies): status, raw path,
+    simplified path and sample path, coordinate for coordinate, A* and jump-point search, maps with boxes and unknown cells."""
+    rng = np.random.default_rng(3)
+    n_ok = 0
+    for trial in range(24):
+        dim = [int(rng.integers(20, 44)), int(rng.integers(30, 70)), int(rng.integers(6, 14))]
+        vm, om = make_map(frx, rng, dim, [0.1, 0.25][trial % 2], int(rng.integers(5, 40)), unknown=trial % 3 == 0)
+        rp = jo.RefPlanner(om.origin, om.dim, om.res, om.cells)
+        a, b = free_point(rng, om), free_point(rng, om)
+        for use_jps in (False, True):
+            want = rp.plan(a, b, 1.0, use_jps)
+            got = vm.plan(a, b, 1.0, use_jps)
+            mine = jo.plan(om, a, b, 1.0, use_jps, "ref" if jo.ref_jps() is not None else "python") if (jo.ref_jps() is not None or not use_jps) else None
+            assert got["status"] == want["status"]
+            for k in ("raw_path", "path", "sample_path"):
+                assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), (trial, use_jps, k)
+                if mine is not None:
+                    assert np.array_equal(np.array(mine[k], dtype=np.float64).reshape(-1, 3), want[k]), (trial, use_jps, k, "restatement")
+            n_ok += want["status"] == 0
+        # start / goal verdicts: occupied start, goal outside
+        occ = np.argwhere(np.asarray(om.cells).reshape(dim[::-1]) == 100)
+        if len(occ):
+            z, y, x = occ[0]
+            bad = om.int_to_float([int(x), int(y), int(z)])
+            assert vm.plan(bad, b)["status"] == rp.plan(bad, b)["status"] == 1
+            assert vm.plan(a, bad)["status"] == rp.plan(a, bad)["status"] == 2
+        rp.close()
+    assert n_ok >= 20
+
+
+@needs_ref_planner
+def test_map_queries_equal_the_compiled_reference_map(frx):
+    """MapUtil<3>: setObs (cloud marking, points on cell faces included), floatToInt and isBlocked / rayTrace (map_util.h:108-136, 382-425) of the
+    reference itself against the product and the restatement."""
+    rng = np.random.default_rng(5)
+    vm = frx.VoxelMap.from_params(6.0, 9.0, 1.5, 0.1)
+    om = jo.Map(vm.origin, vm.dim, vm.res, np.zeros(vm.cells.size, np.int8))
+    rp = jo.RefPlanner(vm.origin, vm.dim, vm.res, np.zeros(vm.cells.size, np.int8))
+    pts = np.column_stack([rng.uniform(-3.4, 3.4, 3000), rng.uniform(-10.5, -0.5, 3000), rng.uniform(-0.2, 1.7, 3000)])
+    pts[:50, 0] = np.round(pts[:50, 0], 1)                                        # points exactly on cell faces
+    vm.mark_cloud(pts); om.mark_cloud(pts)
+    ref_cells = rp.mark_cloud(pts)
+    assert np.array_equal(np.asarray(vm.cells).reshape(-1), ref_cells) and np.array_equal(np.asarray(om.cells).reshape(-1), ref_cells)
+    n_blocked = 0
+    for _ in range(600):
+        a = [rng.uniform(-3.2, 3.2), rng.uniform(-10.2, -0.8), rng.uniform(-0.1, 1.6)]
+        b = [a[0] + rng.normal(0, 1.0), a[1] + rng.normal(0, 1.5), a[2] + rng.normal(0, 0.3)] if rng.random() < 0.9 else list(a)
+        want = rp.is_blocked(a, b)
+        assert vm.is_blocked(a, b) == want and om.is_blocked(a, b) == want
+        assert om.float_to_int(a) == rp.float_to_int(a)
+        n_blocked += want
+    assert 30 < n_blocked < 570
+    rp.close()
 
 
 def test_planner_status_codes(frx):
