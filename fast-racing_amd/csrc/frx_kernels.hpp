@@ -646,14 +646,15 @@ __device__ __forceinline__ void pcr_apply_wg(double *rbuf, int nrow, int k, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-specialised reduction for N - 1 <= 63 knots and 4 waves.  A PCR step of pcr_solve_wg is ~180 dependent FP64 instructions
-// issued by ONE wave while the other three wait at the barrier (measured ~1800 cycles per step: latency of dependent FP64
-// operations with nothing else to issue on that SIMD).  Here wave 0 reduces the MATRIX only (lane = knot) and publishes the step's
-// multipliers in LDS; waves 1-3 each carry ONE AXIS of the right-hand side (lane = knot) and apply step s while wave 0 already
-// works on step s+1.  The adjoint solve of k_backward_knot is the right-hand-side half alone.  Entry by entry the arithmetic is
-// that of pcr_step_inv / pcr_rhs_step.
-//   matrix rows : MR2(buf, f, k), f < 6  = (Dinv, L, U) as double2 pairs, [2][6][nrow] double2 at rowbuf
-//   rhs         : RS(buf, f, k),  f < 6  = first / second equation x axis, [2][6][nrow] doubles behind them
+// Wave-specialised reductions.  A PCR step of pcr_solve_wg is ~180 dependent FP64 instructions issued by ONE wave while the other three
+// wait at the barrier (measured ~1800 cycles per step: latency of dependent FP64 operations with nothing else to issue on that SIMD).
+// In the wave-specialised forms wave 0 reduces the MATRIX only (lane = knot) and publishes the step's multipliers in LDS; waves 1-3 each
+// carry ONE AXIS of the right-hand side (lane = knot).  Entry by entry the arithmetic is that of pcr_step_inv / pcr_rhs_step.
+//   <= 64 pieces  : forward = pcr_matrix_wave64 (free-running matrix wave, no barrier per step) + the axis code in forward_knot_body;
+//                   adjoint = backward_knot_wsp64 (multipliers re-used, neighbours by lane shifts); pcr_waves_wg = the adjoint solve alone
+//   65..128 pieces: pcr_waves2_wg (two knots per lane, barrier per step, right-hand sides through LDS)
+//   matrix rows : MR2(buf, f, k) = (Dinv, L[, U]) as double2 pairs, [2][6][nrow] double2 at rowbuf
+//   rhs         : RS(buf, f, k),  f < 6  = first / second equation x axis, [2][6][nrow] doubles behind them (pcr_waves2_wg, pcr_waves_wg)
 //   multipliers : pw[k * pws + step * 8 + i] (alpha 0-3, beta 4-7), final D^-1 at pw[k * pws + nsteps * 8 + i]
 // ---------------------------------------------------------------------------------------------
 #define MR2(buf, f, t) ((double2 *)rowbuf)[((buf) * 6 + (f)) * nrow + (t)]
