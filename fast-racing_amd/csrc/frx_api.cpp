@@ -1111,12 +1111,15 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), B));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     std::vector<double> t_host_thr(nsrv, 0.0);
+    std::vector<long> scans(nsrv, 0);
     auto serve = [&](int tid) {
         int mine = 0;
+        long nscan = 0;
         for (int b = tid; b < B; b += nsrv) mine += waiting[b] ? 1 : 0;
         auto t_last = clk::now();
         while (mine > 0 && abort_code.load(std::memory_order_relaxed) == 0) {
             bool progress = false;
+            nscan++;
             for (int b = tid; b < B; b += nsrv) {
                 if (!waiting[b]) continue;
                 const unsigned long long rs = hr[8 * b + 7];
@@ -1140,12 +1143,17 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
             else if (ms_since(t_last) > timeout_ms) abort_code.store(2);
             else __builtin_ia32_pause();
         }
+        scans[tid] = nscan;
     };
     {
         std::vector<std::thread> helpers;
         for (int tid = 1; tid < nsrv; tid++) helpers.emplace_back(serve, tid);
         serve(0);
         for (auto &h : helpers) h.join();
+    }
+    if (std::getenv("FRX_RESIDENT_HOST_STATS")) {                                     // diagnostic: how often a service thread looks at each of its mailboxes
+        const double wall_us = 1e3 * ms_since(t0);
+        for (int tid = 0; tid < nsrv; tid++) std::fprintf(stderr, "[frx] mailbox thread %d: %ld scans of %d mailboxes in %.0f us = %.3f us per scan, busy %.1f ms\n", tid, scans[tid], (B - tid + nsrv - 1) / nsrv, wall_us, wall_us / std::max(1L, scans[tid]), t_host_thr[tid]);
     }
     int rc = FRX_OK;
     double t_host = 0.0;
