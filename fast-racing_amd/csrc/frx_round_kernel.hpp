@@ -310,9 +310,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 continue;
             }
         }
+        if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
         pseq++;
         if (t == 0) __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+        if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
         if (t == 0 && seq_pending != 0) {                                   // the previous round's result (system-scope stores, drained above) becomes visible to the host;
             __hip_atomic_store(&a.h_res[c].seq, seq_pending, FRX_RLX_SYS);  // no release fence: its L2 write-back (0.7 us per round) would serve cached stores, and there are none to publish
             seq_pending = 0;

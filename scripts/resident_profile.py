@@ -31,7 +31,7 @@ st = prob.last_stamps
 #   adjoint: thread 0 = staged, after the axis phase's barrier, time side done, end; thread 64 = start of the axis work, Hermite adjoint done,
 #   adjoint solve done, knot adjoint done, waypoint layer: first pass done (30), scalars done (31), done (29)
 rel = lambda idx, base: {str(i): int(st[i] - st[base]) for i in idx if st[i] > 0}
-out["forward_stamps"] = {"matrix_wave": rel([1, 2, 5, 6], 0), "axis_wave": rel([8, 9, 10, 11, 12], 0)}
+out["forward_stamps"] = {"matrix_wave": rel([1, 2, 5, 6], 0), "axis_wave": rel([8, 9, 10, 11, 12], 0), "publication (leader thread 0: before its drain, drained, phase word stored)": rel([13, 14, 15], 0)}
 out["adjoint_stamps"] = {"wave0": rel([17, 22, 23, 24], 16), "axis_wave": rel([25, 26, 27, 28, 30, 31, 29], 16)}
 print(json.dumps(out, indent=1))
 prob.set_resident(False)
