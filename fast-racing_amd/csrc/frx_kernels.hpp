@@ -832,8 +832,10 @@ __device__ __forceinline__ void pcr_waves2_wg(double *rowbuf, int nrow, int t, i
 // (iii) inverts the 2x2 diagonal block with rcp_fast.  (The symmetry goes all the way: U is not even part of a row's state.)
 // ---------------------------------------------------------------------------------------------
 typedef volatile __attribute__((address_space(3))) unsigned *lds_vuptr;
+// (bounded like every other spin of the library: the matrix wave waits for nobody but the one barrier the axis waves reach without waiting, so the
+// bound - about a second - can only expire on a fault; the evaluation then finishes with whatever the multipliers hold instead of hanging the GPU)
 __device__ __forceinline__ void lds_wait_ge(lds_vuptr w, unsigned want) {
-    while (*w < want) __builtin_amdgcn_s_sleep(1);
+    for (unsigned spins = 0; *w < want && spins < (1u << 24); spins++) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
 // wave 0 of the workgroup; kk = lane = knot.  hL / hR: durations of the pieces left and right of the knot (1.0 on lanes without a knot).

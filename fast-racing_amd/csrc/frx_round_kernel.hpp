@@ -212,6 +212,28 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         for (int i = t; i < n; i += 256) { x[i] = xglob[i]; dv[i] = 0.0; g[i] = 0.0; xp[i] = 0.0; gp[i] = 0.0; }
         __syncthreads();
     }
+    // s = x - xp, y = g - gp of an accepted step (lbfgs.hpp:1354-1360) to the cluster, the point becomes the base: two elements per thread and
+    // trip (16-byte LDS accesses; 16-byte stores when the cluster shares an XCD and plain stores do)
+    auto publish_step = [&]() {
+        for (int i2 = 2 * t; i2 < a.NXP; i2 += 512) {
+            double2 s2 = make_double2(0.0, 0.0), y2 = s2, g2 = s2;
+            if (i2 + 1 < n) {
+                const double2 xv = *(const double2 *)(x + i2), gv = *(const double2 *)(g + i2), xq = *(const double2 *)(xp + i2), gq = *(const double2 *)(gp + i2);
+                s2 = make_double2(xv.x - xq.x, xv.y - xq.y); y2 = make_double2(gv.x - gq.x, gv.y - gq.y); g2 = gv;
+                *(double2 *)(xp + i2) = xv; *(double2 *)(gp + i2) = gv;
+            } else if (i2 < n) {
+                const double xv = x[i2], gv = g[i2];
+                s2.x = xv - xp[i2]; y2.x = gv - gp[i2]; g2.x = gv; xp[i2] = xv; gp[i2] = gv;
+            }
+            if (wt) {
+                stg<true>(pub + i2, s2.x, true); stg<true>(pub + i2 + 1, s2.y, true);
+                stg<true>(pub + a.NXP + i2, y2.x, true); stg<true>(pub + a.NXP + i2 + 1, y2.y, true);
+                stg<true>(pub + 2 * a.NXP + i2, g2.x, true); stg<true>(pub + 2 * a.NXP + i2 + 1, g2.y, true);
+            } else {
+                *(double2 *)(pub + i2) = s2; *(double2 *)(pub + a.NXP + i2) = y2; *(double2 *)(pub + 2 * a.NXP + i2) = g2;
+            }
+        }
+    };
     auto flush = [&](const double *xsrc, const double *gsrc) {              // the plan's result for the host: the point (and its gradient) in global memory
         __syncthreads();
         for (int i = t; i < n; i += 256) { xglob[i] = xsrc[i]; gglob[i] = gsrc[i]; }
@@ -241,11 +263,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             step = 1.0;
             f_acc = ctlD[0];
             last_slot = jnew; last_bound = bound;
-            for (int i = t; i < a.NXP; i += 256) {                          // same as the DV_ADVANCE branch below
-                double s = 0.0, y = 0.0, gv = 0.0;
-                if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
-                stg<true>(pub + i, s, wt); stg<true>(pub + a.NXP + i, y, wt); stg<true>(pub + 2 * a.NXP + i, gv, wt);
-            }
+            publish_step();                                                 // same as the DV_ADVANCE branch below
             if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }
             kind = PH_ADV; lstage = 1;
         } else if (lstage == 0) {
@@ -277,11 +295,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 continue;
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
                 f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
-                for (int i = t; i < a.NXP; i += 256) {
-                    double s = 0.0, y = 0.0, gv = 0.0;
-                    if (i < n) { const double xv = x[i]; gv = g[i]; s = xv - xp[i]; y = gv - gp[i]; xp[i] = xv; gp[i] = gv; }
-                    stg<true>(pub + i, s, wt); stg<true>(pub + a.NXP + i, y, wt); stg<true>(pub + 2 * a.NXP + i, gv, wt);
-                }
+                publish_step();
                 if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
                 kind = PH_ADV; lstage = 1;
             } else {
