@@ -3,10 +3,14 @@ CPU oracle on identical seeded inputs.  Tolerances (all relative, FP64):
   per-stage / per-evaluation quantities  1e-9   (re-association + FMA contraction only; measured ~1e-13)
   optimised coefficients                 1e-6   (BASELINE.json north_star), see test_lockstep_parity_along_the_whole_optimisation
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 PER_EVAL_TOL = 1e-9
 
@@ -437,3 +441,25 @@ def test_penalty_of_a_large_batch_reproduces_the_small_batch(frx, sc):
         assert rel(c1[r * B0:(r + 1) * B0], c0) < 1e-13
         assert rel(gT1[r * T.size:(r + 1) * T.size], gT0) < 1e-13
         assert rel(gC1[r * gC0.shape[0]:(r + 1) * gC0.shape[0]], gC0) < 1e-13
+
+
+def test_both_forms_of_the_penalty_integrator_agree(frx, sc):
+    """The latency form (default) and the throughput form (FRX_PENALTY_FORM=thr: phase boundaries, LDS re-reads, 126 VGPRs) are the same arithmetic;
+    the form is chosen once per process, so the other one runs in a child process."""
+    import subprocess, sys, tempfile
+    B, N, gates, kappa = 4, 24, 6, 16
+    cands = sc.make_batch(6, B, N, gates, obstacles=True)
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x = prob.optimize(1e-6, max_iterations=25)["x"]
+    T, Cf = prob.forward(x)
+    c0, gT0, gC0 = prob.penalty(T, Cf)
+    prob.close()
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), T=T, C=Cf)
+        code = (f"import sys, os, numpy as np; sys.path.insert(0, {ROOT!r}); import frx_import; import fast_racing_amd as frx; from fast_racing_amd import scenario as sc\n"
+                f"d = np.load(os.path.join({td!r}, 'in.npz')); p = frx.Problem(sc.make_batch(6, {B}, {N}, {gates}, obstacles=True), sc.ZHANGJIAJIE, qd_intervals={kappa})\n"
+                f"c, gT, gC = p.penalty(d['T'], d['C']); np.savez(os.path.join({td!r}, 'out.npz'), c=c, gT=gT, gC=gC)\n")
+        env = dict(os.environ, FRX_PENALTY_FORM="thr")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+        o = np.load(os.path.join(td, "out.npz"))
+        assert rel(o["c"], c0) < 1e-13 and rel(o["gT"], gT0) < 1e-13 and rel(o["gC"], gC0) < 1e-13
