@@ -137,7 +137,7 @@ __device__ __forceinline__ void rk_load_cmd(const RoundCmd *p, rk_u64 &word, rk_
 
 // ---- bounded waits (ONE lane) ----
 __device__ __forceinline__ bool rk_expired(const RoundArgs &a, rk_u64 deadline) {
-    return __hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u || wall_clock64() > deadline;
+    return __hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u || (rk_u64)wall_clock64() > deadline;
 }
 __device__ __forceinline__ bool rk_wait_eq(const unsigned *w, unsigned want, const RoundArgs &a) {
     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
