@@ -1247,6 +1247,7 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
                 std::vector<char> again(p->B, 0);
                 int n_again = 0;
                 for (int b = 0; b < p->B; b++) if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
+                if (n_again && std::getenv("FRX_RESIDENT_NO_RETRY")) { p->resident_retried = -n_again; n_again = 0; }   // diagnostic: report the resident kernel's own verdicts
                 if (n_again) {
                     const int used = p->resident_used;
                     const double t_res = p->stats[0];
