@@ -172,6 +172,7 @@ struct frx_problem {
     DevBuf<double> d_x, d_f, d_g, d_T, d_C, d_band, d_out20;
     DevBuf<long long> d_stamps;
     DevBuf<double> d_pcrw;
+    DevBuf<double> d_wq;                                    // [P][4]: per waypoint {|xi|^2, sum_a V_a xi_a^2}, forward map -> adjoint of the same evaluation
     // pinned staging
     PinBuf<double> h_x, h_f, h_g, h_T, h_C, h_out20;
     // device-vector L-BFGS state (allocated on first use)
@@ -511,6 +512,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     CR(p->d_x.alloc(p->NX)); CR(p->d_f.alloc(B)); CR(p->d_g.alloc(p->NX));
     CR(p->d_T.alloc(p->P)); CR(p->d_C.alloc((size_t)p->P * 18)); CR(p->d_band.alloc(p->boff[B])); CR(p->d_out20.alloc((size_t)p->P * 20));
     CR(p->d_pcrw.alloc((size_t)(p->geo.pcr_steps * 8 + 4) * p->P)); p->geo.pcrw = p->d_pcrw.p;
+    CR(p->d_wq.alloc((size_t)4 * p->P)); HIP_TRY(hipMemset(p->d_wq.p, 0, sizeof(double) * 4 * p->P));
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
 #undef CR
@@ -532,7 +534,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     d.piece_hbeg = p->d_piece_hbeg.p; d.piece_K = p->d_piece_K.p; d.piece_coarse = p->d_piece_coarse.p; d.piece_iv = p->d_piece_iv.p;
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
     d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
-    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.stamps = nullptr; d.cand_active = nullptr; d.piece_active = nullptr;
+    d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.wq_glob = p->d_wq.p; d.stamps = nullptr; d.cand_active = nullptr; d.piece_active = nullptr;
     *out = p;
     return FRX_OK;
 }

@@ -33,6 +33,8 @@ struct DevProblem {
     // DV_EVAL (finished, or restoring) are skipped by the objective kernels - the tail of a large batch runs at the cost of the
     // candidates still active
     const int *cand_active, *piece_active;
+    double *wq_glob;                          // [number of waypoints][4] scratch: {|xi|^2, sum_a V_a xi_a^2} per waypoint, written by the forward map and read by the
+                                              // adjoint of the same evaluation (stage kernels; the resident kernel keeps them in LDS, ResidentOps::wq)
     long long *stamps;                        // optional (null): s_memtime stamps of candidate 0's phases, [2][16] (frx_profile_phases)
 };
 

@@ -1032,6 +1032,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 nrm += dpp_mov<0xB1>(nrm); q0 += dpp_mov<0xB1>(q0); q1 += dpp_mov<0xB1>(q1); q2 += dpp_mov<0xB1>(q2);   // pair sums
                 if (wact && sub == 0) {
                     if (ro && ro->wq) { double *wq = ro->wq + 4 * w; wq[0] = nrm; wq[1] = q0; wq[2] = q1; wq[3] = q2; }
+                    else if (dp.wq_glob) { double2 *wq = (double2 *)(dp.wq_glob + 4 * (size_t)(p0 - b + w)); wq[0] = make_double2(nrm, q0); wq[1] = make_double2(q1, q2); }
                     const double sc = 2.0 / (1.0 + nrm), sc2 = sc * sc;
                     KN(KP, 0, w + 1) = sc2 * q0 + V[0]; KN(KP, 1, w + 1) = sc2 * q1 + V[1]; KN(KP, 2, w + 1) = sc2 * q2 + V[2];
                 }
@@ -1267,6 +1268,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     const int kp = piece ? kk : 0;                      // clamped piece index: loads are unconditional, results of lanes without a piece unused
     double h, o0 = 0.0, o1 = 0.0, c9[9], cq[6], cbq[6], r_tl[3] = {0, 0, 0};
     int r_wnv = 1, r_wvb = 0, r_wxb = 0;
+    double2 r_wq0 = make_double2(0.0, 0.0), r_wq1 = r_wq0;   // the forward map's sums of this pair's waypoint (stage kernels: through dp.wq_glob)
     {
         const double *ci = Cin + (size_t)(p0 + kp) * 18;
         const double *o = out20 + (size_t)(p0 + kp) * 20;
@@ -1280,7 +1282,11 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
 #pragma unroll
             for (int q = 0; q < 6; q++) { cbq[q] = ldg<SH>(o + 2 + q * 3 + ax); cq[q] = ct_lds ? ct_lds[kp * 19 + q * 3 + ax] : ldg<SH>(ci + q * 3 + ax); }
             r_tl[0] = dp.tailPVA[b * 9 + ax]; r_tl[1] = dp.tailPVA[b * 9 + 3 + ax]; r_tl[2] = dp.tailPVA[b * 9 + 6 + ax];
-            if ((t2 >> 1) < N - 1) { const int gw = p0 - b + (t2 >> 1); r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }   // pair t2 >> 1 = waypoint
+            if ((t2 >> 1) < N - 1) {                                // pair t2 >> 1 = waypoint
+                const int gw = p0 - b + (t2 >> 1);
+                r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw];
+                if (!ro && dp.wq_glob) { const double2 *wq = (const double2 *)(dp.wq_glob + 4 * (size_t)gw); r_wq0 = wq[0]; r_wq1 = wq[1]; }
+            }
         }
     }
     if (!ro) {
@@ -1459,8 +1465,10 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             // with r_a = sc xi_a, sc = 2 / (1 + |xi|^2):  d f / d xi_a = xi_a (2 sc^2 (V_a . g) - 4 gdq / (1 + |xi|^2)^2),
             // gdq = 2 sc sum_a (V_a . g) xi_a^2  -  so |xi|^2 and the weighted sum come out of ONE pass over the vertices
             double s2 = 0.0;
-            const bool cached = ro && ro->wq;                           // the forward map of this evaluation left both sums in LDS (same workgroup, resident caller)
-            if (wact && cached) { const double *wq = ro->wq + 4 * w; qn = wq[0]; s2 = wq[1] * g0 + wq[2] * g1 + wq[3] * g2; }
+            // the forward map of this evaluation left both sums behind: in LDS (same workgroup, resident caller) or in dp.wq_glob (stage kernels; first pass only)
+            const bool cached_lds = ro && ro->wq, cached = cached_lds || (!ro && dp.wq_glob && w0 == 0);
+            if (wact && cached_lds) { const double *wq = ro->wq + 4 * w; qn = wq[0]; s2 = wq[1] * g0 + wq[2] * g1 + wq[3] * g2; }
+            else if (wact && cached) { qn = r_wq0.x; s2 = r_wq0.y * g0 + r_wq1.x * g1 + r_wq1.y * g2; }
             if (wact && !cached)
                 for (int a0 = sub; a0 < nv1; a0 += 8) {                   // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
                     double xv[4], dgv[4];
