@@ -309,6 +309,8 @@ def main():
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "selected_by": "longest of the three stage kernels (HIP events)", "achieved": dom_achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom_achieved / HBM_PEAK_GBS, "traffic": traffic if dominant == "penalty" else None,
+                         "traffic_note": None if dominant == "penalty" else "PMC traffic is calibrated for the penalty integrator only (16-byte streaming loads: roofline.penalty.traffic); "
+                                         "raw, uncorrected FETCH_SIZE / WRITE_SIZE of the knot kernels: knot_kernels_raw_uncalibrated in profiles/r02_pmc_headline.json",
                          "algorithmic_bytes_per_launch": stage_bytes[dominant], "avg_kernel_us": stage_us[dominant],
                          "stage_kernels_us": stage_us, "stage_algorithmic_bytes": stage_bytes,
                          "penalty": {"kernel": "frx::k_penalty_lat", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_kernel_us": pen_us, "traffic": traffic,

@@ -5,7 +5,7 @@
 #                           (latency form = default, throughput form = FRX_PENALTY_FORM=thr)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CMD="python $R/scripts/kernel_sweep.py --batches 32,1024 --states it60 --reps 30"
+CMD="python $R/scripts/kernel_sweep.py --batches 32,1024 --states it60 --reps 30 --full"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc2_$c -o p -- $CMD > /dev/null 2> $R/gpurun_out/pmc2_$c.err
 done
@@ -15,7 +15,7 @@ cd $R
 python - <<'PY'
 import csv, json, collections
 def rows(d): return [r for r in csv.DictReader(open(f"gpurun_out/{d}/p_counter_collection.csv")) if "k_penalty" in r["Kernel_Name"]]
-res = {"command": "python scripts/kernel_sweep.py --batches 32,1024 --states it60 --reps 30 (headline batch and the same batch replicated 32x = 1024 candidates)", "kernel": "frx::k_penalty"}
+res = {"command": "python scripts/kernel_sweep.py --batches 32,1024 --states it60 --reps 30 --full (headline batch and the same batch replicated 32x = 1024 candidates)", "kernel": "frx::k_penalty"}
 by = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     g = collections.defaultdict(list)
@@ -26,6 +26,18 @@ for grid, m in sorted(by.items()):
     fb, wb = m["FETCH_SIZE_KB"] * 1024 * 2, m["WRITE_SIZE_KB"] * 1024
     traffic["grid_%d" % grid] = {"FETCH_SIZE_KB_raw": m["FETCH_SIZE_KB"], "WRITE_SIZE_KB": m["WRITE_SIZE_KB"], "fetch_bytes_x2": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb}
 res["traffic"] = traffic
+# the two knot kernels of the same runs (the sweep's --full leg): RAW counters, no correction - these kernels mix 8- and 16-byte loads, which the
+# guide's x2 rule for FETCH_SIZE is not calibrated for, so the figures are reported as they come and bench.py does not turn them into roofline.traffic
+def krows(d, name): return [r for r in csv.DictReader(open(f"gpurun_out/{d}/p_counter_collection.csv")) if name in r["Kernel_Name"]]
+raw = {}
+for kname in ("k_forward_knot", "k_backward_knot"):
+    per = collections.defaultdict(dict)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        g = collections.defaultdict(list)
+        for r in krows(f"pmc2_{c}", kname): g[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+        for grid, v in g.items(): per["grid_%d" % grid][c + "_KB_raw"] = sum(v) / len(v)
+    raw[kname] = dict(per)
+res["knot_kernels_raw_uncalibrated"] = raw
 smallest = min(by)
 res["traffic_bytes_per_launch"] = traffic["grid_%d" % smallest]["traffic_bytes_per_launch"]          # headline launch
 for name in ("pmc2_valu", "pmc2_valu4"):
