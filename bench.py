@@ -313,6 +313,7 @@ def main():
                                          "raw, uncorrected FETCH_SIZE / WRITE_SIZE of the knot kernels: knot_kernels_raw_uncalibrated in profiles/r02_pmc_headline.json",
                          "algorithmic_bytes_per_launch": stage_bytes[dominant], "avg_kernel_us": stage_us[dominant],
                          "stage_kernels_us": stage_us, "stage_algorithmic_bytes": stage_bytes,
+                         "stage_fracs": {k: stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS for k in stage_us},
                          "penalty": {"kernel": "frx::k_penalty_lat", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_kernel_us": pen_us, "traffic": traffic,
                                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
                                      "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6), "fp64": fp64, "large_batch": large, "valu": valu},
