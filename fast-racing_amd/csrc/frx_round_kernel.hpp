@@ -101,7 +101,7 @@ struct RoundArgs {
     double ls_ftol, ls_gtol, ls_min_step, ls_max_step;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
     int ls_max_linesearch, speculate;
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
-    int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters (FRX_RESIDENT_POLL)
+    int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
     int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
     double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
@@ -133,7 +133,7 @@ __device__ __forceinline__ void rk_load_cmd(const RoundCmd *p, rk_u64 &word, rk_
 
 // pause between two polls of a word another workgroup will write: a.poll_sleep selects the length (s_sleep takes an immediate)
 #define RK_PAUSE(a) do { switch ((a).poll_sleep) { case 0: __builtin_amdgcn_s_sleep(1); break; case 1: __builtin_amdgcn_s_sleep(2); break; \
-                                                 case 2: __builtin_amdgcn_s_sleep(4); break; default: __builtin_amdgcn_s_sleep(8); break; } } while (0)
+                                                 case 2: __builtin_amdgcn_s_sleep(4); break; case 3: __builtin_amdgcn_s_sleep(8); break; default: break; } } while (0)
 
 // ---- bounded waits (ONE lane) ----
 __device__ __forceinline__ bool rk_expired(const RoundArgs &a, rk_u64 deadline) {
