@@ -59,13 +59,18 @@ BATCH_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POI
 # every symbol include/frx.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params", "frx_lbfgs_gcopter_params",
-    "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_profile_phases", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
+    "frx_problem_create", "frx_problem_destroy", "frx_problem_set_solver", "frx_problem_set_lbfgs_mode", "frx_problem_totals", "frx_problem_layout", "frx_initial_guess",
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
-    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_dv_selftest", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
-    "frx_problem_set_resident", "frx_optimize_path", "frx_debug_trace", "frx_resident_profile",
-    "frx_eval_stage_times", "frx_dilate_batch", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
-    "frx_map_mark_cloud", "frx_map_is_blocked", "frx_grid_search", "frx_jps_tables", "frx_jps_plan", "frx_route_plan",
+    "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
+    "frx_problem_set_resident", "frx_optimize_path",
+    "frx_dilate_batch", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
+    "frx_map_mark_cloud", "frx_map_is_blocked", "frx_grid_search", "frx_jps_plan", "frx_route_plan",
+]
+# diagnostics, include/frx_debug.h: not part of the drop-in boundary
+DEBUG_SYMBOLS = [
+    "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
+    "frx_debug_resident_counts", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables",
 ]
 
 _lib = None
@@ -101,6 +106,10 @@ def lib():
         L.frx_optimize_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
         L.frx_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.frx_resident_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.frx_debug_direction_log.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.frx_debug_direction_log_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.frx_debug_set_resident_retry.argtypes = [C.c_void_p, C.c_int]
+        L.frx_debug_resident_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.frx_dilate_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
         L.frx_eval_stage_times.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
@@ -134,7 +143,7 @@ def lib():
         L.frx_jps_tables.argtypes = [_vp] * 6
         L.frx_jps_plan.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.frx_route_plan.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
-        for name in ABI_SYMBOLS:
+        for name in ABI_SYMBOLS + DEBUG_SYMBOLS:
             fn = getattr(L, name)
             if name not in ("frx_version", "frx_last_error", "frx_device_count", "frx_lbfgs_default_params",
                             "frx_lbfgs_gcopter_params", "frx_problem_destroy"):
@@ -440,6 +449,31 @@ class Problem:
             lib().frx_debug_trace(self.h, out.ctypes.data, n)
         return out
 
+    def direction_log(self, cap_steps: int, n_cands: int = 1):
+        """Record (s, y, g, d) of every accepted step of later resident plans (frx_debug_direction_log); 0 switches it off."""
+        _check(lib().frx_debug_direction_log(self.h, int(cap_steps), int(n_cands)))
+
+    def read_direction_log(self, cand: int = 0):
+        """dict(s, y, g, d: rows x nxp arrays; slot, bound: rows) of candidate `cand`'s accepted steps in the last resident plan."""
+        rows = C.c_int(); rd = C.c_int()
+        _check(lib().frx_debug_direction_log_read(self.h, cand, None, 0, C.byref(rows), C.byref(rd)))
+        out = np.zeros((rows.value, rd.value))
+        if rows.value:
+            _check(lib().frx_debug_direction_log_read(self.h, cand, out.ctypes.data, rows.value, C.byref(rows), C.byref(rd)))
+        nxp = (rd.value - 2) // 4
+        return dict(s=out[:, :nxp], y=out[:, nxp:2 * nxp], g=out[:, 2 * nxp:3 * nxp], d=out[:, 3 * nxp:4 * nxp],
+                    slot=out[:, 4 * nxp].astype(int), bound=out[:, 4 * nxp + 1].astype(int))
+
+    def set_resident_retry(self, enable: bool):
+        """Diagnostic: re-run candidates that fail on the resident kernel on the per-stage rounds (round-2 behaviour; default off)."""
+        _check(lib().frx_debug_set_resident_retry(self.h, 1 if enable else 0))
+
+    def resident_counts(self):
+        """(failed, retried) candidates of the last resident plan."""
+        a = C.c_int(); b = C.c_int()
+        _check(lib().frx_debug_resident_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def resident_profile(self):
         """[B][G][16] microseconds per segment of the last resident plan (needs FRX_RESIDENT_PROF in the environment)."""
         n = lib().frx_resident_profile(self.h, None, 0)
@@ -488,7 +522,8 @@ class Problem:
         _check(lib().frx_optimize_stats(self.h, stats))
         resident, dev_status = self.optimize_path()
         return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
-                    ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status)
+                    ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status,
+                    resident_failed=self.resident_counts()[0], resident_retried=self.resident_counts()[1])
 
     def stage_times(self, x, reps: int = 100):
         """Average microseconds of the forward, penalty and adjoint kernels at x (HIP events inside the library)."""

@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -20,6 +23,7 @@
 #include <vector>
 
 #include "../../include/frx.h"
+#include "../../include/frx_debug.h"
 #include "frx_device.hpp"
 #include "frx_internal.hpp"
 #include "frx_lbfgs.hpp"
@@ -35,6 +39,13 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
         if (e_ != hipSuccess)                                                                           \
             return fail(FRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
+
+// a pair of HIP events that is destroyed on every exit path
+struct HipEventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create() { hipError_t e = hipEventCreate(&e0); return e != hipSuccess ? e : hipEventCreate(&e1); }
+    ~HipEventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
 
 using clk = std::chrono::steady_clock;
 inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
@@ -52,23 +63,35 @@ public:
         if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
             for (int c = 0; c < CPU_SETSIZE; c++)
                 if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
-        // Workers are pinned only while this is the ONLY live pool of the process (several host threads driving separate handles
-        // would otherwise pin their pools onto the same cores and spin against each other), and the CALLER's thread is never
-        // pinned: its affinity is the caller's business.  FRX_PIN=0 disables pinning altogether; FRX_PIN_OFFSET / FRX_PIN_STRIDE
-        // choose which allowed CPUs the workers take.
+        // Every live pool of the process pins its workers onto its OWN range of the allowed CPUs: pool k (the lowest free index, taken at
+        // construction, returned at destruction) uses CPUs [k n, (k + 1) n) of the list - several host threads driving separate handles
+        // (frx_multi: one per device) neither share cores nor depend on which pool was created first.  A pool whose range does not fit
+        // the allowed set runs unpinned.  The CALLER's thread is never pinned: its affinity is the caller's business.  FRX_PIN=0 disables
+        // pinning altogether; FRX_PIN_OFFSET / FRX_PIN_STRIDE choose which allowed CPUs the ranges are cut from.
         const char *pe = std::getenv("FRX_PIN"), *po = std::getenv("FRX_PIN_OFFSET"), *ps = std::getenv("FRX_PIN_STRIDE");
         const int off = po ? std::atoi(po) : 0, stride = std::max(1, ps ? std::atoi(ps) : 1);
-        const bool alone = live_pools().fetch_add(1, std::memory_order_acq_rel) == 0;
-        const bool do_pin = alone && !(pe && pe[0] == '0') && n_ > 1 && (int)cpus.size() >= off + (n_ - 1) * stride + 1;
+        live_pools().fetch_add(1, std::memory_order_acq_rel);
+        {
+            std::lock_guard<std::mutex> g(slot_lock());
+            std::vector<char> &used = slots();
+            size_t k = 0;
+            while (k < used.size() && used[k]) k++;
+            if (k == used.size()) used.push_back(0);
+            used[k] = 1; slot_ = (int)k;
+        }
+        const long first = (long)off + (long)slot_ * n_ * stride, last = first + (long)(n_ - 1) * stride;
+        const bool do_pin = !(pe && pe[0] == '0') && n_ > 1 && last < (long)cpus.size();
         for (int t = 1; t < n_; t++) {
             workers_.emplace_back([this, t] { loop(t); });
-            if (do_pin) pin(workers_.back().native_handle(), cpus[off + t * stride]);
+            if (do_pin) pin(workers_.back().native_handle(), cpus[first + (long)t * stride]);
         }
     }
     ~SpinPool() {
         stop_.store(true, std::memory_order_release);
         for (auto &w : workers_) w.join();
         live_pools().fetch_sub(1, std::memory_order_acq_rel);
+        std::lock_guard<std::mutex> g(slot_lock());
+        if (slot_ >= 0 && slot_ < (int)slots().size()) slots()[slot_] = 0;
     }
     int size() const { return n_; }
     // fn(i) for i in [0, count): worker t takes i = t, t + n, t + 2n, ...
@@ -104,7 +127,9 @@ private:
             else cpu_relax();
         }
     }
-    int n_;
+    int n_, slot_ = -1;
+    static std::mutex &slot_lock() { static std::mutex m; return m; }
+    static std::vector<char> &slots() { static std::vector<char> v; return v; }
     std::vector<std::thread> workers_;
     std::function<void(int)> fn_;
     int count_ = 0;
@@ -187,13 +212,17 @@ struct frx_problem {
     DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags, d_pflags;
     // resident round kernel (frx_round_kernel.hpp): cluster exchange buffers and mapped mailboxes, allocated on first use
     DevBuf<double> d_pubsyg, d_part, d_upub, d_dpub, d_rdbg;
+    int dirlog_cap = 0, dirlog_cands = 0, dirlog_nxp = 0;   // direction log of the resident kernel (frx_debug_direction_log): records asked for / row geometry of the last plan
+    std::vector<double> dirlog;                             // [B] counts, then dirlog_cands x dirlog_cap records of 4 NXP + 2 doubles
     DevBuf<unsigned long long> d_rprof;                     // FRX_RESIDENT_PROF: [B][G][16] per-segment ticks of the last resident launch
     std::vector<unsigned long long> rprof;
     DevBuf<unsigned> d_rwords;
     PinBuf<unsigned long long> h_rcmd, h_rres;              // [B] x 2 words, [B] x 8 words
     int rk_B = 0, rk_G = 0, rk_NXP = 0;
     int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident)
+    int resident_retry = 0;                                 // 1 = re-run candidates that fail on the resident kernel on the per-stage rounds (diagnostic, frx_debug_set_resident_retry); the reference takes no second chance and neither does the default
     int resident_retried = 0;                               // candidates of the last plan re-run on the per-stage rounds after an L-BFGS error
+    int resident_failed = 0;                                // candidates of the last resident plan that ended with an L-BFGS error other than the iteration limit
     int resident_used = 0;                                  // diagnostics: 1 = the last frx_optimize ran on the resident kernel
     unsigned resident_status = 0;                           // device-side error code of the last resident launch (RK_ERR_*)
     std::vector<double> trace;                              // FRX_TRACE: per command of candidate 0 {flags, step, f, dg, dginit, xx, gg}
@@ -512,7 +541,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     CR(p->d_x.alloc(p->NX)); CR(p->d_f.alloc(B)); CR(p->d_g.alloc(p->NX));
     CR(p->d_T.alloc(p->P)); CR(p->d_C.alloc((size_t)p->P * 18)); CR(p->d_band.alloc(p->boff[B])); CR(p->d_out20.alloc((size_t)p->P * 20));
     CR(p->d_pcrw.alloc((size_t)(p->geo.pcr_steps * 8 + 4) * p->P)); p->geo.pcrw = p->d_pcrw.p;
-    CR(p->d_wq.alloc((size_t)4 * p->P)); HIP_TRY(hipMemset(p->d_wq.p, 0, sizeof(double) * 4 * p->P));
+    CR(p->d_wq.alloc((size_t)4 * p->P)); CR(hipMemset(p->d_wq.p, 0, sizeof(double) * 4 * p->P));
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
 #undef CR
@@ -617,7 +646,8 @@ int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4
     if (frx::launch_lbfgs_pre(dv, cmd.p, res.p, nullptr)) return fail(FRX_ERR_HIP, "k_lbfgs_pre launch (geometry not instantiated?)");
     HIP_TRY(hipDeviceSynchronize());
     xp = x; gp = g;
-    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HipEventPair evp; HIP_TRY(evp.create());
+    const hipEvent_t e0 = evp.e0, e1 = evp.e1;
     double worst = 0.0, us_sum = 0.0; int us_n = 0, end = 0;
     for (int k = 1; k <= iters; k++) {
         // the new accepted point: x moves by a random step that correlates with the gradient change, so y.s > 0 mostly
@@ -661,7 +691,6 @@ int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4
         }
         xp = x; gp = g; end = (end + 1) % m;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *max_rel_err = worst; *avg_us = us_n ? us_sum / us_n : 0.0;
     return FRX_OK;
 }
@@ -674,8 +703,8 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
     std::vector<double> f(p->B), g(p->NX);
     int rc = frx_objective_eval(p, x, f.data(), g.data());               // d_x, d_T, d_C, d_out20, pcrw all valid afterwards
     if (rc != FRX_OK) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HipEventPair evp; HIP_TRY(evp.create());
+    const hipEvent_t e0 = evp.e0, e1 = evp.e1;
     auto time_it = [&](int which, double &us) -> int {
         for (int w = 0; w < 3; w++) {                                    // warm
             hipError_t e = hipSuccess;
@@ -697,7 +726,6 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
         return FRX_OK;
     };
     for (int k = 0; k < 3; k++) if ((rc = time_it(k, out3_us[k])) != FRX_OK) break;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }
 
@@ -1013,9 +1041,22 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
 // optimize_device_vectors, but talks to each candidate's cluster through its own mailbox and never waits for the batch: a candidate's
 // next command is posted the moment its result arrives.  Returns FRX_OK, a negative frx_status, or 1 = not applicable / the device
 // gave up (resident_status says why): the caller then runs the one-launch-per-stage path from the untouched x.
+// A resident launch needs ALL of its workgroups on the chip at once (one per CU: ~154 KB of LDS each).  Two launches that share a
+// device - two shards of frx_multi on one GPU, two user threads - could each get a partially resident grid, and neither census would
+// ever complete.  Launches of this process are therefore serialised per device: the second plan waits for the first one's kernel to
+// leave (another PROCESS on the same device is caught by the census bound instead: 250 ms, then the per-stage path).
+static std::mutex &resident_device_lock(int device) {
+    static std::mutex table_lock;
+    static std::map<int, std::unique_ptr<std::mutex>> table;
+    std::lock_guard<std::mutex> g(table_lock);
+    std::unique_ptr<std::mutex> &m = table[device];
+    if (!m) m.reset(new std::mutex());
+    return *m;
+}
+
 static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals, double *objective) {
     const int B = p->B, m = pm.mem_size, E = frx::ROUND_E;
-    p->resident_used = 0; p->resident_status = 0;
+    p->resident_used = 0; p->resident_status = 0; p->resident_failed = 0;
     if (p->geo.solver != frx::SOLVER_KNOT_PCR || m < 1 || m > 128) return 1;
     // The compact representation inverts R = S^T Y (triangular part); with fewer variables than twice the history length the pairs
     // become linearly dependent and R^-1 loses its digits (n = 1: entries grow like 2^k), where the two-loop recursion of
@@ -1050,8 +1091,15 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         }
         p->rk_B = B; p->rk_G = G; p->rk_NXP = NXP;
     }
-    const bool want_dbg = std::getenv("FRX_RESIDENT_DBG") != nullptr;
-    if (want_dbg && (!p->d_rdbg.p || p->d_rdbg.n < (size_t)B * NXP) && p->d_rdbg.alloc((size_t)B * NXP) != hipSuccess) return 1;
+    // direction log (frx_debug.h): [B] record counts, then dirlog_cands x dirlog_cap records {s, y, g, d, slot, pair count}
+    const int log_cands = std::min(p->dirlog_cands, B);
+    const bool want_dbg = p->dirlog_cap > 0 && log_cands > 0;
+    const size_t log_rec = 4 * (size_t)NXP + 2, log_doubles = want_dbg ? (size_t)B + (size_t)log_cands * p->dirlog_cap * log_rec : 0;
+    p->dirlog.clear(); p->dirlog_nxp = NXP;
+    if (want_dbg) {
+        if ((!p->d_rdbg.p || p->d_rdbg.n < log_doubles) && p->d_rdbg.alloc(log_doubles) != hipSuccess) return fail(FRX_ERR_ALLOC, "direction log does not fit the device");
+        HIP_TRY(hipMemsetAsync(p->d_rdbg.p, 0, sizeof(double) * log_doubles, p->stream));
+    }
     const bool want_prof = std::getenv("FRX_RESIDENT_PROF") != nullptr;
     if (want_prof) {
         if ((!p->d_rprof.p || p->d_rprof.n < (size_t)B * G * 16) && p->d_rprof.alloc((size_t)B * G * 16) != hipSuccess) return 1;
@@ -1067,7 +1115,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
     frx::RoundLaunch rl;
     rl.x = p->d_x.p; rl.g = p->d_g.p; rl.xp = p->d_xp.p; rl.gp = p->d_gp.p; rl.d = p->d_dir.p; rl.f = p->d_f.p; rl.T = p->d_T.p; rl.C = p->d_C.p; rl.out20 = p->d_out20.p;
-    rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr;
+    rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr; rl.dbg_cap = want_dbg ? p->dirlog_cap : 0; rl.dbg_cands = want_dbg ? log_cands : 0;
     rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
@@ -1100,6 +1148,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     const bool tracing = std::getenv("FRX_TRACE") != nullptr;
     p->trace.clear();
     for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, &cmd[b]);
+    std::unique_lock<std::mutex> device_slot(resident_device_lock(p->device));        // one resident grid per device at a time (see above)
     const auto t0 = clk::now();
     HIP_TRY((hipError_t)frx::launch_round(p->dp, p->geo, rl, p->stream));
     for (int b = 0; b < B; b++) {
@@ -1143,7 +1192,16 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
             }
             if (progress) t_last = clk::now();
             else if (ms_since(t_last) > timeout_ms) abort_code.store(2);
-            else __builtin_ia32_pause();
+            else {
+                // a kernel that has LEFT while candidates still wait (start-up census failed: the grid did not fit next to another
+                // process's work; a device fault) will never answer: notice it from the stream instead of sitting out the whole timeout
+                if (tid == 0 && (nscan & 0x3FFF) == 0 && hipStreamQuery(p->stream) != hipErrorNotReady) {
+                    bool answered = true;
+                    for (int b = 0; b < B; b++) if (waiting[b] && hr[8 * b + 7] != seq[b]) answered = false;
+                    if (!answered) abort_code.store(1);
+                }
+                __builtin_ia32_pause();
+            }
         }
         scans[tid] = nscan;
     };
@@ -1173,9 +1231,14 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
             __builtin_ia32_pause();
         }
     }
+    device_slot.unlock();                                                             // the kernel has left the chip
     unsigned st[2] = {0, 0};
     HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * B, sizeof(st), hipMemcpyDeviceToHost));
     p->resident_status = st[1];
+    if (want_dbg) {
+        p->dirlog.resize(log_doubles);
+        HIP_TRY(hipMemcpy(p->dirlog.data(), p->d_rdbg.p, sizeof(double) * log_doubles, hipMemcpyDeviceToHost));
+    }
     if (rc < 0) return rc;
     if (rc != FRX_OK || st[1] != 0) return 1;
     long rounds = 0;
@@ -1189,6 +1252,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     for (int b = 0; b < B; b++) {
         status[b] = sv[b].status();
+        if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) p->resident_failed++;
         if (iters) iters[b] = sv[b].iterations();
         if (evals) evals[b] = sv[b].evaluations();
         if (objective) objective[b] = sv[b].value();
@@ -1243,14 +1307,17 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
             if (rc_dv < 0) return rc_dv;
             if (rc_dv != 0) std::copy(x_start.begin(), x_start.end(), x);
             else {
-                // Safety net: a candidate that ends with an L-BFGS error on the resident kernel is run again, from the same start, on
-                // the per-stage rounds (two-loop recursion; an iteration limit is not an error): a genuine failure (an infeasible corridor ends in LBFGSERR_MINIMUMSTEP on
-                // the CPU reference as well) fails again, a direction spoilt by an ill-conditioned R does not.
-                std::vector<char> again(p->B, 0);
-                int n_again = 0;
-                for (int b = 0; b < p->B; b++) if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
-                if (n_again && std::getenv("FRX_RESIDENT_NO_RETRY")) { p->resident_retried = -n_again; n_again = 0; }   // diagnostic: report the resident kernel's own verdicts
-                if (n_again) {
+                // A candidate that ends with an L-BFGS error on the resident kernel keeps that verdict, as it would in the reference
+                // (lbfgs_optimize returns the code, SE3GCOPTER::optimize ignores it, CPU.hpp:1249): on the Monte-Carlo and perturbation
+                // shares the resident kernel fails on no more candidates than the CPU oracle does (tests/test_gpu_configs.py).  Round 2
+                // re-ran such candidates on the per-stage rounds - a second chance the reference does not take, 2-3x the plan time for the
+                // batch that contains one; that re-run is now a diagnostic (frx_debug_set_resident_retry / FRX_RESIDENT_RETRY=1).
+                const char *rt_env = std::getenv("FRX_RESIDENT_RETRY");
+                const bool retry = rt_env ? rt_env[0] != '0' : p->resident_retry != 0;
+                if (retry && p->resident_failed > 0) {
+                    std::vector<char> again(p->B, 0);
+                    int n_again = 0;
+                    for (int b = 0; b < p->B; b++) if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
                     const int used = p->resident_used;
                     const double t_res = p->stats[0];
                     const int rc2 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);
@@ -1323,6 +1390,33 @@ int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_
     const int n = (int)p->rprof.size();
     if (out) std::memcpy(out, p->rprof.data(), sizeof(unsigned long long) * (size_t)std::min(n, std::max(cap_words, 0)));
     return n;
+}
+int frx_debug_direction_log(frx_problem *p, int cap_steps, int n_cands) {
+    if (!p || cap_steps < 0 || n_cands < 0) return fail(FRX_ERR_INVALID_ARG, "null handle or negative size");
+    p->dirlog_cap = cap_steps; p->dirlog_cands = cap_steps > 0 ? n_cands : 0;
+    p->dirlog.clear();
+    return FRX_OK;
+}
+int frx_debug_direction_log_read(const frx_problem *p, int cand, double *out, int cap_rows, int *rows, int *row_doubles) {
+    if (!p || cand < 0) return fail(FRX_ERR_INVALID_ARG, "null handle or negative candidate");
+    const size_t rec = 4 * (size_t)p->dirlog_nxp + 2;
+    int n = 0;
+    if (!p->dirlog.empty() && cand < std::min(p->dirlog_cands, p->B)) n = std::min((int)p->dirlog[cand], p->dirlog_cap);
+    if (rows) *rows = n;
+    if (row_doubles) *row_doubles = (int)rec;
+    if (out && n > 0) std::memcpy(out, p->dirlog.data() + p->B + (size_t)cand * p->dirlog_cap * rec, sizeof(double) * rec * (size_t)std::min(n, std::max(cap_rows, 0)));
+    return FRX_OK;
+}
+int frx_debug_set_resident_retry(frx_problem *p, int enable) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    p->resident_retry = enable ? 1 : 0;
+    return FRX_OK;
+}
+int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (failed) *failed = p->resident_failed;
+    if (retried) *retried = p->resident_retried;
+    return FRX_OK;
 }
 int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");

@@ -89,6 +89,7 @@ struct RoundLaunch {
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
     int B, G, m, E, NXP;
+    int dbg_cap = 0, dbg_cands = 0;                                 // direction log (dbg): [B] counts + dbg_cands x dbg_cap records of 4 NXP + 2 doubles
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;
     int cmd_stride = 4;                                            // h_cmd: candidate b's 16-byte command at 16 * cmd_stride * b

@@ -86,6 +86,15 @@ struct frx_multi {
 
 namespace {
 
+// The entry points below walk over the shards' devices with hipSetDevice; the caller's current device is its own business (bench.py mixes
+// torch and HIP in one process: a changed current device would send later allocations and launches to the wrong GPU) and is put back on
+// every exit path.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 void block_range(int total, int r, int world, int &lo, int &hi) {     // earlier shards take the remainder (fast-racing_amd/dist.py)
     const int base = total / world, rem = total % world;
     lo = r * base + std::min(r, rem);
@@ -103,6 +112,7 @@ int frx_multi_create(const frx_config *cfg, int n_devices, const int *devices, i
     *out = nullptr;
     const int ndev = frx_device_count();
     if (ndev <= 0) return frx::set_error(FRX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    DeviceGuard restore_device;
     int G = n_devices > 0 ? n_devices : ndev;
     G = std::min(G, B);                                                         // "only when it exceeds one device": never more shards than candidates
     frx_multi *m = new (std::nothrow) frx_multi();
@@ -167,6 +177,7 @@ int frx_multi_create(const frx_config *cfg, int n_devices, const int *devices, i
 
 void frx_multi_destroy(frx_multi *m) {
     if (!m) return;
+    DeviceGuard restore_device;
     for (size_t g = 0; g < m->comms.size(); g++) if (m->comms[g]) rccl().CommDestroy(m->comms[g]);
     for (Shard &s : m->sh) {
         (void)hipSetDevice(s.device);
@@ -197,6 +208,7 @@ int frx_multi_layout(const frx_multi *m, int *piece_off, int *x_off) {
 
 int frx_multi_initial_guess(frx_multi *m, double *x0) {
     if (!m || !x0) return frx::set_error(FRX_ERR_INVALID_ARG, "null argument");
+    DeviceGuard restore_device;
     for (Shard &s : m->sh) {
         const int rc = frx_initial_guess(s.h, x0 + m->x_off[s.lo]);
         if (rc != FRX_OK) return rc;
@@ -211,6 +223,7 @@ int frx_multi_optimize(frx_multi *m, const frx_lbfgs_params *params, double *x, 
                        int *status, int *iters, int *evals, int *winner_id, double *winner_objective, double *winner_C, double *winner_T,
                        int *winner_n) {
     if (!m || !params || !x || !status) return frx::set_error(FRX_ERR_INVALID_ARG, "null argument");
+    DeviceGuard restore_device;
     const int G = m->G;
     std::vector<double> Cbuf, Tbuf, obj;
     if (!C) { Cbuf.resize((size_t)m->p_off[m->B] * 18); C = Cbuf.data(); }
@@ -318,6 +331,7 @@ int frx_dilate_batch(int device, int n_seg, const double *p1, const double *p2, 
     if (n_seg < 1 || !p1 || !p2 || !bbox || n_obs < 0 || (n_obs && !obs) || cap_planes < 6 || !n_planes || !h_rec)
         return frx::set_error(FRX_ERR_INVALID_ARG, "frx_dilate_batch: null or out-of-range argument");
     if (frx_device_count() < 1) return frx::set_error(FRX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    DeviceGuard restore_device;
     if (hipSetDevice(device) != hipSuccess) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_dilate_batch: device ordinal out of range");
     const int pcap = 4096;                                                           // 4096 candidate points per cell: 96 KB of LDS + flags
     double *d_p1 = nullptr, *d_p2 = nullptr, *d_obs = nullptr, *d_h = nullptr, *d_C = nullptr, *d_d = nullptr; int *d_np = nullptr;

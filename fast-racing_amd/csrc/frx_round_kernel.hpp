@@ -104,7 +104,8 @@ struct RoundArgs {
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
     int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
-    double *dbg;                             // optional [B][NXP]: every new direction of the leader is also stored here (selftest)
+    double *dbg;                             // optional direction log (frx_debug.h, frx_debug_direction_log): [B] record counts, then per candidate c < dbg_cands
+    int dbg_cap, dbg_cands;                  // dbg_cap records of 4 NXP + 2 doubles: s, y, g (the pair and the gradient the direction was built from), d, slot, pair count
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
 };
 // profile segments (thread 0 of every workgroup accumulates the time since its previous checkpoint into one of these)
@@ -254,6 +255,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     rk_u64 pred_word = 0, seq_pending = 0;
     double f_acc = 0.0, gg0 = 0.0;
     int last_slot = -1, last_bound = 0;
+    unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
     for (;;) {
         int kind = 0;
         if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
@@ -355,7 +357,14 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         }
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
             double acc = 0.0;
-            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; if (a.dbg) a.dbg[(size_t)c * a.NXP + i] = di; }
+            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; }
+            if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what the cluster was given and what it returned
+                const size_t rec = 4 * (size_t)a.NXP + 2;
+                double *row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * rec;
+                for (int i = t; i < n; i += 256) { row[i] = ldg<true>(pub + i); row[a.NXP + i] = ldg<true>(pub + a.NXP + i); row[2 * a.NXP + i] = gp[i]; row[3 * a.NXP + i] = dv[i]; }
+                if (t == 0) { row[4 * a.NXP] = (double)last_slot; row[4 * a.NXP + 1] = (double)last_bound; a.dbg[c] = (double)(nadv_l + 1); }
+            }
+            nadv_l++;
             const double ws = wave_sum_dpp(acc);
             if (lane == 0) pair[wave] = ws;
             __syncthreads();
@@ -737,7 +746,12 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (!ok) rk_fail(a, RK_ERR_CENSUS);
+        if (!ok) {
+            // Tell the HOST, which can poll the mailboxes but not the status word: without this its service loop sat out the whole round
+            // timeout (5 s against the 250 ms census bound) and frx_optimize failed hard instead of taking the per-stage path.
+            rk_fail(a, RK_ERR_CENSUS);
+            if (v.wg == 0) __hip_atomic_store(&a.h_res[v.c].seq, ~(rk_u64)0, FRX_RLX_SYS);
+        }
         bool same = ok;
         for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + v.c * a.G + k, FRX_RLX_AGENT) == my_xcc;
         ctlU[0] = ok ? 1u : 0u;

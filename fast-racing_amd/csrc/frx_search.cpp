@@ -21,6 +21,7 @@
 // points of samplePath fall exactly on cell faces (0.05 m steps on a 0.1 m grid), so a fused multiply-add would move points
 // across faces.  The test suite's restatement evaluates the same expressions in IEEE double without fusing.
 #include "../../include/frx.h"
+#include "../../include/frx_debug.h"
 #include "frx_internal.hpp"
 
 #include <algorithm>

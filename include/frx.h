@@ -23,6 +23,7 @@
  *     asynchronous; the plain variants take host pointers and block.
  *   - the library never falls back to a CPU implementation: without a usable HIP device
  *     frx_problem_create() fails with FRX_ERR_NO_DEVICE.
+ *   - diagnostics (traces, in-kernel profiles, self-tests of single kernels) are NOT part of this boundary: include/frx_debug.h.
  */
 #ifndef FRX_H
 #define FRX_H
@@ -187,9 +188,6 @@ int frx_map_is_blocked(const double *a, const double *b, void *map);
  * expansions were spent; *cost = g of the goal.  FRX_ERR_CAPACITY when the path holds more than cap cells. */
 int frx_grid_search(const signed char *cmap, const int *dim, const int *start, const int *goal, double eps, int use_jps,
                     int max_expand, int cap, int *n_path, int *path_xyz, int *n_expanded, double *cost);
-/* The jump-point neighbour tables in the reference's storage order (JPS3DNeib ns[27][3][26], f1/f2[27][3][12]; JPS2DNeib
- * ns[9][2][8], f1/f2[9][2][2]; graph_search.h:72-127), generated from rules instead of spelled out; for the parity test. */
-int frx_jps_tables(int *ns3, int *f13, int *f23, int *ns2, int *f12, int *f22);
 /* JPSPlanner<3>::plan (jps_planner.cpp:333-420): cells of start and goal (must be free: *status = 1 / 2), grid search on the
  * occupied/not-occupied view of the map (unknown cells are traversable, updateMap :309-323), *status = -1 when there is no
  * path; then raw_path (cell centres, start first), path (removeCornerPts forwards and backwards, removeLinePts; :54-117) and
@@ -203,11 +201,6 @@ int frx_jps_plan(const frx_voxel_map *map, const double *start, const double *go
  * splices stale samples there). */
 int frx_route_plan(const frx_voxel_map *map, const double *start, const double *goal, int n_gates, const double *gates, double eps,
                    int use_jps, int n_threads, int cap, int *n_out, double *path_out, int *leg_status, int *leg_expanded);
-
-/* Diagnostic: k_lbfgs_pre (device two-loop recursion) against a host two-loop recursion on random histories, and its
- * duration.  geom4 = {doubles/thread, waves, look-ahead rows, pairs per reduction} or NULL for the library's choice. */
-int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err,
-                    double *avg_us);
 
 /* Asynchronous evaluation on host buffers (blocking and asynchronous variants): frx_objective_eval_async returns once
  * the work is enqueued on the handle's stream, frx_wait completes it and fills f and g (valid until then; one evaluation in flight per
@@ -242,14 +235,6 @@ int frx_problem_set_lbfgs_mode(frx_problem *p, int mode);
 #define FRX_SOLVER_KNOT_PCR 0
 #define FRX_SOLVER_BANDED_LU 1
 int frx_problem_set_solver(frx_problem *p, int solver);
-
-/* Diagnostic (bench): average microseconds of each stage kernel of an evaluation at x - {forward, penalty, adjoint} - over `reps`
- * back-to-back launches of one kernel at a time, HIP events on the handle's stream. */
-int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3_us);
-
-/* Diagnostic: runs one evaluation at x and returns shader-clock stamps taken at the phase boundaries of candidate 0's
- * k_forward_knot (out32[0..6]) and k_backward_knot (out32[16..24]). */
-int frx_profile_phases(frx_problem *p, const double *x, long long *out32);
 
 /* Totals: out6 = {B, total fine pieces, total coarse pieces, total free variables, max half-spaces per piece,
  * sum over fine pieces of their half-space count}. */
@@ -341,13 +326,6 @@ int frx_multi_optimize(frx_multi *m, const frx_lbfgs_params *params, double *x, 
                        int *winner_n);
 /* 1 when the last frx_multi_optimize exchanged the winner through RCCL, 0 for the in-process communicator. */
 int frx_multi_last_exchange(const frx_multi *m);
-
-/* Diagnostic (tests): with FRX_TRACE set in the environment, frx_optimize records for candidate 0 one row per evaluated command
- * {flags, step, f, g.d, gp.d_new, x.x, g.g}; returns the number of rows and copies up to cap_rows of them (7 doubles each). */
-int frx_debug_trace(const frx_problem *p, double *out, int cap_rows);
-/* Diagnostic: with FRX_RESIDENT_PROF set, the resident kernel runs its instrumented instantiation and leaves 16 counters of 100 MHz
- * ticks per workgroup ([B][G][16], segments RK_P_* of csrc/frx_round_kernel.hpp); returns the word count, copies up to cap_words. */
-int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_words);
 
 /*
  * Host-side solver on its own (used by the CPU tests and by integrators that bring their own

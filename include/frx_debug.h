@@ -1,0 +1,60 @@
+/*
+ * frx_debug.h — diagnostics of libfrx.so: traces, in-kernel profiles, self-tests of single kernels.
+ *
+ * NOT part of the drop-in boundary (include/frx.h is the reference's SE3GCOPTER / cuda_computer boundary plus its neighbours);
+ * nothing here is needed to plan a trajectory.  tests/, bench.py and scripts/ use these entries to look inside a plan.
+ * Same conventions as frx.h (int status, frx_last_error()).
+ */
+#ifndef FRX_DEBUG_H
+#define FRX_DEBUG_H
+
+#include "frx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic (tests): with FRX_TRACE set in the environment, frx_optimize records for candidate 0 one row per evaluated command
+ * {flags, step, f, g.d, gp.d_new, x.x, g.g}; returns the number of rows and copies up to cap_rows of them (7 doubles each). */
+int frx_debug_trace(const frx_problem *p, double *out, int cap_rows);
+/* Diagnostic: with FRX_RESIDENT_PROF set, the resident kernel runs its instrumented instantiation and leaves 16 counters of 100 MHz
+ * ticks per workgroup ([B][G][16], segments RK_P_* of csrc/frx_round_kernel.hpp); returns the word count, copies up to cap_words. */
+int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_words);
+
+/* Direction log of the resident round kernel (csrc/frx_round_kernel.hpp).  The kernel computes the L-BFGS direction in the compact
+ * (Byrd-Nocedal-Schnabel) form from a register-resident history; the reference computes it with the two-loop recursion
+ * (lbfgs.hpp:1381-1411).  frx_debug_direction_log(p, cap_steps, n_cands) makes every later resident plan on the handle record, for the
+ * first n_cands candidates and the first cap_steps accepted steps of each, the pair (s, y) the step added to the history, the gradient g
+ * the direction was built from and the direction d the cluster returned (cap_steps = 0 switches the log off).
+ * frx_debug_direction_log_read copies candidate `cand`'s records: row r = {s[nxp], y[nxp], g[nxp], d[nxp], slot, pair count}
+ * (*row_doubles = 4 nxp + 2 doubles, vectors zero-padded from n to nxp); *rows = records written (<= cap_steps); out may be NULL. */
+int frx_debug_direction_log(frx_problem *p, int cap_steps, int n_cands);
+int frx_debug_direction_log_read(const frx_problem *p, int cand, double *out, int cap_rows, int *rows, int *row_doubles);
+/* Round 2 re-ran, on the per-stage rounds, every candidate that ended with an L-BFGS error on the resident kernel; the default now keeps
+ * the resident kernel's verdict like the reference keeps lbfgs_optimize's.  enable = 1 restores the re-run on this handle (environment:
+ * FRX_RESIDENT_RETRY=0|1 overrides).  frx_debug_resident_counts: candidates of the last resident plan that ended with an L-BFGS error
+ * other than the iteration limit, and how many of them were re-run. */
+int frx_debug_set_resident_retry(frx_problem *p, int enable);
+int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried);
+
+/* Diagnostic (bench): average microseconds of each stage kernel of an evaluation at x - {forward, penalty, adjoint} - over `reps`
+ * back-to-back launches of one kernel at a time, HIP events on the handle's stream. */
+int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3_us);
+
+/* Diagnostic: runs one evaluation at x and returns shader-clock stamps taken at the phase boundaries of candidate 0's
+ * k_forward_knot (out32[0..6]) and k_backward_knot (out32[16..24]). */
+int frx_profile_phases(frx_problem *p, const double *x, long long *out32);
+
+/* Diagnostic: k_lbfgs_pre (device two-loop recursion) against a host two-loop recursion on random histories, and its
+ * duration.  geom4 = {doubles/thread, waves, look-ahead rows, pairs per reduction} or NULL for the library's choice. */
+int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4, unsigned seed, double *max_rel_err,
+                    double *avg_us);
+
+/* The jump-point neighbour tables in the reference's storage order (JPS3DNeib ns[27][3][26], f1/f2[27][3][12]; JPS2DNeib
+ * ns[9][2][8], f1/f2[9][2][2]; graph_search.h:72-127), generated from rules instead of spelled out; for the parity test. */
+int frx_jps_tables(int *ns3, int *f13, int *f23, int *ns2, int *f12, int *f22);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRX_DEBUG_H */

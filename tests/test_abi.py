@@ -10,8 +10,8 @@ import pytest
 from conftest import ROOT, has_gpu
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "frx.h")).read()
+def declared_symbols(header="frx.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(frx_[a-z_0-9]+)\s*\(", src)) - {"frx_batch_eval_fn"})
 
@@ -24,6 +24,12 @@ def test_every_declared_symbol_is_exported(frx):
         assert hasattr(L, s), f"{s} declared in include/frx.h but not exported by libfrx.so"
     assert sorted(frx.ABI_SYMBOLS) == syms
     assert frx.lib().frx_version() == 100
+    # the boundary header reads as the reference's SE3GCOPTER / cuda_computer interface plus its neighbours: diagnostics live in frx_debug.h
+    dbg = declared_symbols("frx_debug.h")
+    assert sorted(frx.DEBUG_SYMBOLS) == dbg and not set(dbg) & set(syms)
+    for s in dbg:
+        assert hasattr(L, s), f"{s} declared in include/frx_debug.h but not exported by libfrx.so"
+    assert not [s for s in syms if "debug" in s or "selftest" in s or "profile" in s]
 
 
 def test_config_struct_layout_matches_header(frx):

@@ -40,10 +40,27 @@ def _cpu_plans(ob, sc, cands, kappa, tol, variants):
     return [out[i * nv:(i + 1) * nv] for i in range(len(cands))]
 
 
+def _device_plans(frx, sc, cands, kappa, tol, batch=32):
+    """Plans of `cands` on the device in batches that fit the resident round kernel (32 headline-size candidates); the resident kernel's
+    OWN verdicts: nothing is re-run on another path (frx_debug_set_resident_retry stays off, and the environment must not switch it on)."""
+    assert os.environ.get("FRX_RESIDENT_RETRY", "0") == "0"
+    out = {"status": [], "objective": [], "ms_total": 0.0, "rounds": 0, "resident": [], "resident_failed": 0, "resident_retried": 0}
+    for lo in range(0, len(cands), batch):
+        prob = frx.Problem(cands[lo:lo + batch], sc.ZHANGJIAJIE, qd_intervals=kappa)
+        r = prob.optimize(tol)
+        assert r["device_status"] == 0
+        out["status"].append(r["status"]); out["objective"].append(r["objective"]); out["resident"].append(r["resident"])
+        out["ms_total"] += r["ms_total"]; out["rounds"] = max(out["rounds"], r["rounds"])
+        out["resident_failed"] += r["resident_failed"]; out["resident_retried"] += r["resident_retried"]
+        prob.close()
+    out["status"] = np.concatenate(out["status"]); out["objective"] = np.concatenate(out["objective"])
+    return out
+
+
 def _share_check(frx, sc, ob, cands, kappa, label):
     tol = sc.ZHANGJIAJIE["opt_rel_tol"]
-    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
-    r = prob.optimize(tol)
+    r = _device_plans(frx, sc, cands, kappa, tol)
+    assert min(r["resident"]) >= 3 and r["resident_retried"] == 0          # every batch ran on the resident round kernel, once
     # CPU, CPU' (the two abscissa forms: a 1e-16 perturbation) and two more CPU runs whose x0 is moved by a few ulp: the spread of a
     # heavy-tailed quantity needs more than two samples
     variants = [(False, 0), (True, 0), (False, 11), (False, 12)]
@@ -72,7 +89,10 @@ def _share_check(frx, sc, ob, cands, kappa, label):
     for b, st, obj, sts in infeasible_like:                                 # "succeeded" where the reference fails: only with a penalty-dominated objective
         if not (obj > 100.0 * feasible_obj):
             bad_status.append((b, st, sts))
-    summary = {"config": label, "candidates": len(cands), "failed_on_cpu": int(n_fail), "status_mismatches": bad_status,
+    n_fail_dev = int(np.sum((r["status"] < 0) & (r["status"] != -1004)))
+    n_fail_cpu_any = int(sum(1 for plans in cpu if min(p["status"] for p in plans) < 0))      # candidates on which at least one CPU variant fails
+    summary = {"config": label, "candidates": len(cands), "failed_on_cpu": int(n_fail), "failed_on_any_cpu_variant": n_fail_cpu_any,
+               "failed_on_resident_kernel": n_fail_dev, "resident_retried": r["resident_retried"], "status_mismatches": bad_status,
                "stalled_with_other_label": [(b, st, obj) for b, st, obj, _ in infeasible_like],
                "cpu_vs_cpu_objective_spread": {"median": float(np.median(spread)), "p95": float(np.percentile(spread, 95)), "max": float(spread.max())},
                "device_vs_cpu_objective": {"median": float(np.median(dev)), "p95": float(np.percentile(dev, 95)), "max": float(dev.max())},
@@ -80,11 +100,12 @@ def _share_check(frx, sc, ob, cands, kappa, label):
     print(json.dumps(summary))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"share_{label}.json"), "w"), indent=1)
-    prob.close()
     assert not bad_status, f"L-BFGS status differs from the CPU reference path for {bad_status}"
-    # every candidate inside the CPU-vs-CPU' envelope (x3: two CPU samples under-estimate the spread of a heavy-tailed quantity)
-    assert dev.max() <= max(3.0 * spread.max(), 5e-3), (dev.max(), spread.max())
-    assert np.median(dev) <= max(3.0 * np.median(spread), 1e-4)
+    # the resident kernel's own failures (no second chance): not more candidates than the CPU oracle loses on the same share
+    assert n_fail_dev == r["resident_failed"] and n_fail_dev <= max(int(n_fail), n_fail_cpu_any), summary
+    # every candidate inside the CPU-vs-CPU' envelope: the distance to the nearest of the four CPU plans against the spread among them
+    assert dev.max() <= 1.5 * spread.max(), (dev.max(), spread.max())
+    assert np.median(dev) <= np.median(spread), (np.median(dev), np.median(spread))
     return summary
 
 
@@ -97,8 +118,8 @@ def test_config3_share_of_one_gpu(frx, sc, ob):
 
 def test_config4_share_of_one_gpu(frx, sc, ob):
     """BASELINE.json configs[4]: Monte-Carlo sweep, independent scenarios; 128 of one GPU's 512 (ids 64..191, which include the
-    infeasible scenario 170): the reference's verdict (LBFGS status) reproduced for every scenario, objectives inside the
-    CPU-vs-CPU' envelope."""
+    infeasible scenario 170), run as four resident batches of 32: the reference's verdict (LBFGS status) reproduced for every scenario
+    by the resident kernel itself, objectives inside the CPU-vs-CPU' envelope."""
     B, N, gates, kappa = sc.CONFIGS["montecarlo4096"]
     cands = [sc.make_candidate(64 + b, N, gates) for b in range(128)]
     s = _share_check(frx, sc, ob, cands, kappa, "montecarlo4096_128")
@@ -132,6 +153,6 @@ def test_coefficient_spread_against_stopping_tolerance(frx, sc, ob, sid, N, gate
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", f"delta_curve_s{sid}_N{N}.json"), "w"), indent=1)
     prob.close()
     for row in rows:
-        assert row["device_status"] in row["cpu_status"] or row["device_status"] >= 0
+        assert row["device_status"] in row["cpu_status"], row
         assert row["device_vs_cpu_coeff"] <= max(2.0 * row["cpu_vs_cpu_coeff"], 1e-6), row
         assert row["device_vs_cpu_objective"] <= max(2.0 * row["cpu_vs_cpu_objective"], 1e-9), row

@@ -58,3 +58,36 @@ def test_a_failed_candidate_never_wins(frx, sc):
     r = mp.optimize(sc.ZHANGJIAJIE["opt_rel_tol"])
     assert r["status"][0] < 0 and r["status"][1] >= 0 and r["winner_id"] == 1
     mp.close()
+
+
+def test_config3_whole_eight_shards_on_one_device(frx, sc):
+    """BASELINE.json configs[3] WHOLE: 256 perturbed candidates block-partitioned into eight shards of 32 - the shape of an 8-GPU node -
+    with every shard on device 0 (the box has one GPU; the in-process communicator stands in for RCCL, which refuses a device twice).
+    The eight resident launches take turns on the device (one resident grid per device at a time, csrc/frx_api.cpp), so every shard's
+    plan is bit-identical to the same 32 candidates on a handle of their own, and the winner is the argmin over all 256."""
+    B, N, gates, kappa = sc.CONFIGS["perturbed256"]
+    assert B == 256
+    cands = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)]
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    mp = frx.MultiProblem(cands, sc.ZHANGJIAJIE, devices=[0] * 8, qd_intervals=kappa)
+    assert mp.n_shards == 8 and list(mp.shard_lo) == list(range(0, 257, 32)) and not mp.uses_rccl
+    x0 = mp.initial_guess()
+    r = mp.optimize(tol, x0=x0)
+    assert r["exchange"] == "host"
+    best = (np.inf, -1)
+    for g in range(8):
+        lo, hi = 32 * g, 32 * g + 32
+        p = frx.Problem(cands[lo:hi], sc.ZHANGJIAJIE, qd_intervals=kappa)
+        q = p.optimize(tol, x0=x0[mp.x_off[lo]:mp.x_off[hi]])
+        assert q["resident"] >= 3 and q["device_status"] == 0
+        assert np.array_equal(q["x"], r["x"][mp.x_off[lo]:mp.x_off[hi]]) and np.array_equal(q["objective"], r["objective"][lo:hi])
+        assert np.array_equal(q["status"], r["status"][lo:hi]) and np.array_equal(q["evals"], r["evals"][lo:hi])
+        f = np.where((q["status"] < 0) | ~np.isfinite(q["objective"]), np.inf, q["objective"])
+        if f.min() < best[0]:
+            best = (float(f.min()), lo + int(np.argmin(f)))
+        p.close()
+    assert (r["winner_objective"], r["winner_id"]) == best
+    sl = slice(mp.piece_off[best[1]], mp.piece_off[best[1] + 1])
+    assert np.array_equal(r["winner_C"], r["C"][6 * sl.start:6 * sl.stop]) and np.array_equal(r["winner_T"], r["T"][sl])
+    print("config[3] whole on one device: winner", best, "failed", int(np.sum(r["status"] < 0)))
+    mp.close()

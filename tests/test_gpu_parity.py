@@ -271,7 +271,7 @@ def test_ragged_batch_and_split_polytopes(frx, sc, ob):
                     assert rel(T[sl], Tr) < 1e-13 and rel(Cf[6 * sl.start:6 * sl.stop], Cr) < 1e-7
         prob.set_solver("knot_pcr")
         res = prob.optimize(1e-6, max_iterations=40)
-        assert np.all(res["status"] != 0) or True
+        assert np.all((res["status"] == -1004) | (res["status"] >= 0)), res["status"]     # 40 iterations: the limit (LBFGSERR_MAXIMUMITERATION) or an earlier stop
         for b, o in enumerate(oracles):                       # the reported value is the objective of the returned point
             f_ref, _ = o.objective(res["x"][prob.x_off[b]:prob.x_off[b + 1]])
             assert abs(f_ref - res["objective"][b]) <= 1e-9 * abs(f_ref)
