@@ -481,9 +481,20 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     ge.maxN = p->maxN; ge.maxCN = p->maxCN; ge.Kmax = p->Kmax;
     ge.lpp = std::min(spp, 64);
     ge.ppw = 64 / ge.lpp;
+    {   // stage kernel k_penalty: a workgroup of W waves owns floor(64 W / lpp) whole pieces; W in 1..4 for the best lane utilisation (the
+        // fewest waves among equals).  kappa = 16: 51/64 lanes with one wave, 255/256 with four; stock kappa = 48: 49/64 and 245/256.
+        // FRX_PENALTY_WAVES=1..4 overrides (measurements).
+        int best_w = 1; double best_u = 0.0;
+        for (int w = 1; w <= 4; w++) {
+            const double u = (double)((64 * w) / ge.lpp * ge.lpp) / (64.0 * w);
+            if (u > best_u + 1e-9) { best_u = u; best_w = w; }
+        }
+        if (const char *pw = std::getenv("FRX_PENALTY_WAVES")) { const int w = std::atoi(pw); if (w >= 1 && w <= 4) best_w = w; }
+        ge.pen_w = best_w; ge.ppg = (64 * best_w) / ge.lpp;
+    }
     ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
     ge.lds_bwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 6) + 2 * (size_t)p->maxN + p->maxCN);
-    ge.lds_pen = sizeof(double) * ((size_t)ge.ppw * 19 + (size_t)ge.ppw * (p->Kmax + 1) * 4 + 64 * 21);
+    ge.lds_pen = sizeof(double) * ((size_t)ge.ppg * 19 + (size_t)ge.ppg * (p->Kmax + 1) * 4 + (size_t)64 * ge.pen_w * 21);
     ge.solver = frx::SOLVER_KNOT_PCR;
     ge.knot_threads = 64 * ((p->maxN + 63) / 64);
     {
@@ -1109,6 +1120,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
     HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G), p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)B * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
     std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);

@@ -32,10 +32,10 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
     // default: the latency form (148 VGPRs, 3 waves per SIMD, phases interleaved by the scheduler) - measured faster at the headline batch
     // (4.97 vs 5.23 us) AND at 1024 candidates (39.8 vs 42.3 us) than the throughput form (126 VGPRs, 4 waves per SIMD); FRX_PENALTY_FORM=thr selects that one
     static const int forced = [] { const char *e = std::getenv("FRX_PENALTY_FORM"); return !e ? 0 : e[0] == 'l' ? 1 : 2; }();
-    const int nwg = (dp.P + g.ppw - 1) / g.ppw;
+    const int nwg = (dp.P + g.ppg - 1) / g.ppg;
     const bool lat = forced != 2;
-    if (lat) hipLaunchKernelGGL(k_penalty_lat, dim3(nwg), dim3(64), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppw, g.Kmax);
-    else hipLaunchKernelGGL(k_penalty, dim3(nwg), dim3(64), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppw, g.Kmax);
+    if (lat) hipLaunchKernelGGL(k_penalty_lat, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+    else hipLaunchKernelGGL(k_penalty, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
     return (int)hipGetLastError();
 }
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,

@@ -63,7 +63,7 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
 // packed layout.  The blocks of consecutive waypoints are 3 nv doubles apart (36 for the 12-vertex overlaps of box corridors: a
 // multiple of 4 - the lanes of a wave, one waypoint per lane pair, then hit 8 of the 32 LDS double-banks, a four-way conflict on
 // every read of the waypoint map and of its adjoint, measured 2.7 k cycles for a 12-vertex pass); one double of skew makes the stride odd.  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
-struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g (no global store to drain behind the adjoint)
+struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; double *gpub = nullptr; bool gwt = true; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g; gpub (optional, global): and to this array, for the other workgroups of the cluster (write-through unless gwt is false)
 
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
@@ -253,11 +253,16 @@ struct LdsView {
     __device__ __forceinline__ void fence() { asm volatile("" : "+v"(off)); }
 };
 
-// The body works on the pieces [gp0, gp0 + npieces) with one WAVE and `sm` = that wave's private LDS; every wave of the workgroup
-// has to call it (it contains workgroup barriers), idle ones with npieces = 0.
+// The body works on the pieces [gp0, gp0 + npieces) with a GROUP of nthr = 64 W threads (`lane` = index in the group) and `sm` = the
+// group's private LDS.  W = 1: one wave (the resident round kernel gives every wave of a workgroup its own pieces and LDS); W > 1: the
+// whole workgroup (the stage kernel).  Lane L owns sample L % lpp of piece L / lpp, so a group covers floor(64 W / lpp) whole pieces:
+// with kappa + 1 = 17 samples per piece one wave uses 51 of its 64 lanes (49 at the stock kappa = 48), four waves 255 of 256 (245) -
+// round 2 ran the stage kernel with W = 1 and left a fifth of every FP64 issue slot empty.  Every wave of the workgroup has to call it
+// (it contains workgroup barriers), idle ones with npieces = 0.
 template <bool SH, bool LAT = false>
 __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double *__restrict__ T, const double *__restrict__ C,
-                                             double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, bool wt = true) {
+                                             double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, bool wt = true,
+                                             int nthr = 64) {
     const int hstride = (Kmax + 1) * 4;
     double *cS = sm;
     double *tS = cS + ppw * 18;
@@ -276,26 +281,26 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
         double2 hv0 = make_double2(0.0, 0.0), hv1 = hv0, cv0 = hv0;
         double ca = 0.0, cb = 0.0, tv = 0.0;
         if (lane < nh2) hv0 = h2[lane];
-        if (lane + 64 < nh2) hv1 = h2[lane + 64];
+        if (lane + nthr < nh2) hv1 = h2[lane + nthr];
         if (SH) {                                                   // (C, T) come from another workgroup of the same launch: 8-byte L1-bypassing loads
             if (lane < nc) ca = ldg<SH>(csrc + lane);
-            if (lane + 64 < nc) cb = ldg<SH>(csrc + lane + 64);
+            if (lane + nthr < nc) cb = ldg<SH>(csrc + lane + nthr);
         } else if (lane < nc2) cv0 = ((const double2 *)csrc)[lane];
         if (lane < npieces) tv = ldg<SH>(T + gp0 + lane);
         if (lane < nh2) { hS[2 * lane] = hv0.x; hS[2 * lane + 1] = hv0.y; }
-        if (lane + 64 < nh2) { hS[2 * lane + 128] = hv1.x; hS[2 * lane + 129] = hv1.y; }
+        if (lane + nthr < nh2) { hS[2 * (lane + nthr)] = hv1.x; hS[2 * (lane + nthr) + 1] = hv1.y; }
         if (SH) {
             if (lane < nc) cS[lane] = ca;
-            if (lane + 64 < nc) cS[lane + 64] = cb;
-            for (int i = lane + 128; i < nc; i += 64) cS[i] = ldg<SH>(csrc + i);
+            if (lane + nthr < nc) cS[lane + nthr] = cb;
+            for (int i = lane + 2 * nthr; i < nc; i += nthr) cS[i] = ldg<SH>(csrc + i);
         } else {
             if (lane < nc2) { cS[2 * lane] = cv0.x; cS[2 * lane + 1] = cv0.y; }
             const double2 *c2p = (const double2 *)csrc;
-            for (int i = lane + 64; i < nc2; i += 64) { const double2 v = c2p[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }
+            for (int i = lane + nthr; i < nc2; i += nthr) { const double2 v = c2p[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }
         }
         if (lane < npieces) tS[lane] = tv;
 #pragma unroll 2
-        for (int i = lane + 128; i < nh2; i += 64) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }      // corridor blocks beyond 2 KB per wave
+        for (int i = lane + 2 * nthr; i < nh2; i += nthr) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }      // corridor blocks beyond two trips
     }
     __syncthreads();
 
@@ -337,7 +342,7 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     }
     __syncthreads();
     // fixed-order reduction over the samples of each piece: lane = (piece-in-wave, value)
-    for (int idx = lane; idx < npieces * 20; idx += 64) {
+    for (int idx = lane; idx < npieces * 20; idx += nthr) {
         const int p2 = idx / 20, v = idx - p2 * 20;
         const double *src = red + (p2 * lpp) * 21 + v;
         double s = 0.0;
@@ -346,19 +351,20 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
         stg<SH>(out20 + (size_t)gp0 * 20 + idx, s, wt);
     }
 }
-__global__ __launch_bounds__(64, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
-                                                   double *__restrict__ out20, int lpp, int ppw, int Kmax) {
+// Stage kernels: a workgroup of blockDim.x = 64 W threads owns ppg = floor(64 W / lpp) consecutive pieces (LaunchGeom::pen_w, ::ppg).
+__global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                    double *__restrict__ out20, int lpp, int ppg, int Kmax) {
     extern __shared__ double sm[];
-    const int gp0 = blockIdx.x * ppw;
-    penalty_body<false>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
+    const int gp0 = blockIdx.x * ppg;
+    penalty_body<false>(dp, T, C, out20, lpp, ppg, Kmax, gp0, min(ppg, dp.P - gp0), sm, threadIdx.x, true, blockDim.x);
 }
-// The latency form of the same kernel (penalty_sample<LAT>): for grids that cannot fill the chip (fewer workgroups than twice the SIMDs),
-// where the launch is one wave's latency long and registers are free.
-__global__ __launch_bounds__(64, 1) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
-                                                       double *__restrict__ out20, int lpp, int ppw, int Kmax) {
+// The latency form of the same kernel (penalty_sample<LAT>: no phase boundaries, 148 VGPRs) - the default: faster than the phased form at
+// every batch size measured.
+__global__ __launch_bounds__(256, 3) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                        double *__restrict__ out20, int lpp, int ppg, int Kmax) {
     extern __shared__ double sm[];
-    const int gp0 = blockIdx.x * ppw;
-    penalty_body<false, true>(dp, T, C, out20, lpp, ppw, Kmax, gp0, min(ppw, dp.P - gp0), sm, threadIdx.x);
+    const int gp0 = blockIdx.x * ppg;
+    penalty_body<false, true>(dp, T, C, out20, lpp, ppg, Kmax, gp0, min(ppg, dp.P - gp0), sm, threadIdx.x, true, blockDim.x);
 }
 
 // (A streaming form for large batches - 3072 one-wave workgroups walking over the wave-tasks with the next task's global reads in flight during
@@ -1256,8 +1262,9 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     double *vs = xs + maxXb;
     double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by the forward pass
     double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
-    double *gs = nullptr;
-    if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; pw = ro->pw; gs = ro->gs; }
+    double *gs = nullptr, *gpub = nullptr;
+    bool gwt = true;
+    if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; pw = ro->pw; gs = ro->gs; gpub = ro->gpub; gwt = ro->gwt; }
     const int pws = nsteps * 8 + 5;
     const bool tapped = tap.d != nullptr;
     const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
@@ -1424,6 +1431,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             if (kk < cN) {
                 const double gi = gCo[kk] * dT_dtau(xs[kk], dp.c2 != 0);
                 if (gs) gs[kk] = gi; else g[x0 + kk] = gi;
+                if (gpub) stg<SH>(gpub + kk, gi, gwt);
                 if (tapped) { t_dg += gi * dsv[kk]; t_xx += xs[kk] * xs[kk]; t_gg += gi * gi; }
             }
         } else {
@@ -1442,6 +1450,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                     const double de = dT_dtau(xs[i], dp.c2 != 0);
                     const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
                     if (gs) gs[i] = gi; else g[x0 + i] = gi;
+                    if (gpub) stg<SH>(gpub + i, gi, gwt);
                     if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
                 }
             }
@@ -1497,6 +1506,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                         if (a0 + 2 * j < nv1) {
                             const double gi = xv[j] * (sc22 * dgv[j] - kq);
                             if (gs) gs[xb - x0 + a0 + 2 * j] = gi; else g[xb + a0 + 2 * j] = gi;
+                            if (gpub) stg<SH>(gpub + (xb - x0 + a0 + 2 * j), gi, gwt);
                             t_dg += gi * dd[j]; t_xx += xv[j] * xv[j]; t_gg += gi * gi;
                         }
                 }
@@ -1745,6 +1755,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         for (int i = k; i < cN; i += nthr) {
             const double gi = gCo[i] * dT_dtau(xs[i], dp.c2 != 0);
             g[x0 + i] = gi; if (ro && ro->gs) ro->gs[i] = gi;
+            if (ro && ro->gpub) stg<SH>(ro->gpub + i, gi, ro->gwt);
             if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
         }
     } else if (k == 0) {
@@ -1761,6 +1772,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
             const double de = dT_dtau(xs[i], dp.c2 != 0);
             const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
             g[x0 + i] = gi; if (ro && ro->gs) ro->gs[i] = gi;
+            if (ro && ro->gpub) stg<SH>(ro->gpub + i, gi, ro->gwt);
             if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
         }
     }
@@ -1799,6 +1811,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
                 const double gdr = (V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2) * (sc * xi[a]) * 2.0;
                 const double gi = gdr * 2.0 / qp1 - xi[a] * 4.0 * gdq / qp1sq;
                 g[xb + a] = gi; if (ro && ro->gs) ro->gs[xb - x0 + a] = gi;
+                if (ro && ro->gpub) stg<SH>(ro->gpub + (xb - x0 + a), gi, ro->gwt);
                 if (tapped) { t_dg += gi * dsv[xb - x0 + a]; t_xx += xi[a] * xi[a]; t_gg += gi * gi; }
             }
     }

@@ -46,7 +46,7 @@ typedef volatile __attribute__((address_space(3))) unsigned *rk_ldsword;
 #define FRX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define FRX_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
-enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3 };
+enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3, PH_INIT = 4 };
 enum { RK_OK = 0, RK_ERR_CENSUS = 1, RK_ERR_HOST = 2, RK_ERR_PHASE = 3, RK_ERR_ARRIVE = 4, RK_ERR_DENSE = 5, RK_ERR_UFLAG = 6, RK_ERR_HOST_ABORT = 7, RK_ERR_SPECULATION = 8 };
 enum { DV_QUIT = 128, DV_STEP_IS_ONE = 64 };   // extra command flags of the resident kernel (frx_lbfgs.hpp: DV_* are < 32); the second one lets the
                                                // leader confirm a predicted command from the command WORD alone (no second read over PCIe)
@@ -58,7 +58,7 @@ static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 
 // LDS layout (doubles), shared by the kernel and the host-side size computation
 struct RoundLds {
-    int ctl, sC, yC, gC, pair, role, total;              // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
+    int ctl, sC, yC, gC, xpC, gpC, pair, role, total;    // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
     int Rf, vd, va, vb, vc, ve, vw, vv, mv;              // dense state: Rf = R^-1 as [128][129] (row stride 129: conflict-free by row AND by column)
 };
 enum { RK_RS = 129 };                                    // row stride of Rf
@@ -70,7 +70,7 @@ __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) 
     RoundLds L;
     int o = 0;
     L.ctl = o; o += 48;                                   // 16 unsigned | 8 doubles | 16 profile accumulators
-    L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT;
+    L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT; L.xpC = o; o += CHT; L.gpC = o; o += CHT;
     L.pair = o; o += 2 * 4 * 128;
     o = (o + 1) & ~1;
     L.role = o;
@@ -88,7 +88,7 @@ struct RoundArgs {
     DevProblem dp;
     int maxCN, maxXb, maxVb, nrow, nsteps, lpp, ppw, Kmax, pen_lds;   // geometry of the evaluation bodies (LaunchGeom); pen_lds in doubles per wave
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20, *pcrw;           // leader-private vectors + the evaluation's stage buffers
-    double *pubsyg;          // [B][3 NXP + 2] leader -> cluster: s, y, g of an accepted step, then (slot, pair count)
+    double *pubsyg;          // [B][3 NXP + 2] leader -> cluster: the point x and its gradient g (first 2 NXP doubles, zero beyond n), then (slot, pair count)
     double *part;            // [B][G][4][128] cluster -> dense: partial dot products
     double *upub;            // [B][258]      dense -> cluster: -u, gamma w, gamma
     double *dpub;            // [B][NXP]      cluster -> leader: direction chunks
@@ -201,6 +201,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     ro.gs = ro.pw + (((a.nsteps * 8 + 5) * a.nrow + 1) & ~1);
     double *x = ro.xs, *g = ro.gs, *xp = ro.gs + xpad, *gp = xp + xpad, *dv = ro.dsv;
     ro.wq = gp + xpad;                                                    // [nrow][4], forward map -> adjoint of the same evaluation
+    ro.gpub = pub + a.NXP; ro.gwt = wt;                                   // the adjoint also stores the gradient where the history workgroups read it
     {
         const int v0 = a.dp.cvoff[c], nvd = 3 * (a.dp.cvoff[c + 1] - v0);
         const double *vsrc = a.dp.vrec + 3 * (size_t)v0;
@@ -213,26 +214,19 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         for (int i = t; i < n; i += 256) { x[i] = xglob[i]; dv[i] = 0.0; g[i] = 0.0; xp[i] = 0.0; gp[i] = 0.0; }
         __syncthreads();
     }
-    // s = x - xp, y = g - gp of an accepted step (lbfgs.hpp:1354-1360) to the cluster, the point becomes the base: two elements per thread and
-    // trip (16-byte LDS accesses; 16-byte stores when the cluster shares an XCD and plain stores do)
-    auto publish_step = [&]() {
-        for (int i2 = 2 * t; i2 < a.NXP; i2 += 512) {
-            double2 s2 = make_double2(0.0, 0.0), y2 = s2, g2 = s2;
-            if (i2 + 1 < n) {
-                const double2 xv = *(const double2 *)(x + i2), gv = *(const double2 *)(g + i2), xq = *(const double2 *)(xp + i2), gq = *(const double2 *)(gp + i2);
-                s2 = make_double2(xv.x - xq.x, xv.y - xq.y); y2 = make_double2(gv.x - gq.x, gv.y - gq.y); g2 = gv;
-                *(double2 *)(xp + i2) = xv; *(double2 *)(gp + i2) = gv;
-            } else if (i2 < n) {
-                const double xv = x[i2], gv = g[i2];
-                s2.x = xv - xp[i2]; y2.x = gv - gp[i2]; g2.x = gv; xp[i2] = xv; gp[i2] = gv;
-            }
-            if (wt) {
-                stg<true>(pub + i2, s2.x, true); stg<true>(pub + i2 + 1, s2.y, true);
-                stg<true>(pub + a.NXP + i2, y2.x, true); stg<true>(pub + a.NXP + i2 + 1, y2.y, true);
-                stg<true>(pub + 2 * a.NXP + i2, g2.x, true); stg<true>(pub + 2 * a.NXP + i2 + 1, g2.y, true);
-            } else {
-                *(double2 *)(pub + i2) = s2; *(double2 *)(pub + a.NXP + i2) = y2; *(double2 *)(pub + 2 * a.NXP + i2) = g2;
-            }
+    // An accepted step (lbfgs.hpp:1354-1360: s = x - xp, y = g - gp, then the point becomes the base).  The cluster already HAS the point
+    // and its gradient: every trial point goes to the first NXP doubles of `pub` when it is formed and every gradient to the next NXP
+    // straight from the adjoint (ResidentOps::gpub), and each history workgroup keeps its chunk of the previous point and gradient in LDS,
+    // so it forms s and y itself - bit for bit the values the leader would have sent.  Round 2 published s, y and g here: 2016 stores and
+    // their drain (1.5-2 us) between the end of the adjoint and the phase word of every accepted step.
+    unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
+    auto accept_step = [&]() {
+        double *row = nullptr;                                              // direction log (tests): the pair and the gradient the direction is built from
+        if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * (4 * (size_t)a.NXP + 2);
+        for (int i = t; i < n; i += 256) {
+            const double xv = x[i], gv = g[i];
+            if (row) { row[i] = xv - xp[i]; row[a.NXP + i] = gv - gp[i]; row[2 * a.NXP + i] = gv; }
+            xp[i] = xv; gp[i] = gv;
         }
     };
     auto flush = [&](const double *xsrc, const double *gsrc) {              // the plan's result for the host: the point (and its gradient) in global memory
@@ -255,7 +249,6 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     rk_u64 pred_word = 0, seq_pending = 0;
     double f_acc = 0.0, gg0 = 0.0;
     int last_slot = -1, last_bound = 0;
-    unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
     for (;;) {
         int kind = 0;
         if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
@@ -265,8 +258,8 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             step = 1.0;
             f_acc = ctlD[0];
             last_slot = jnew; last_bound = bound;
-            publish_step();                                                 // same as the DV_ADVANCE branch below
-            if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }
+            accept_step();                                                  // same as the DV_ADVANCE branch below
+            if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
             kind = PH_ADV; lstage = 1;
         } else if (lstage == 0) {
             if (t == 0) {
@@ -297,13 +290,16 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 continue;
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
                 f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
-                publish_step();
-                if (t == 0) { stg<true>(pub + 3 * a.NXP, (double)jnew, wt); stg<true>(pub + 3 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
+                accept_step();
+                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
                 kind = PH_ADV; lstage = 1;
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
                     f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
-                    for (int i = t; i < n; i += 256) { const double gv = g[i]; dv[i] = -gv; xp[i] = x[i]; gp[i] = gv; }
+                    // the history workgroups take their chunks of the start point and its gradient as "previous point" (phase INIT, once
+                    // per plan): the gradient is in `pub` already (adjoint), the start point is not - it was never a trial point
+                    for (int i = t; i < n; i += 256) { const double gv = g[i], xv = x[i]; dv[i] = -gv; xp[i] = xv; gp[i] = gv; stg<true>(pub + i, xv, wt); }
+                    kind = PH_INIT;
                 }
                 lstage = 1;
             }
@@ -311,10 +307,10 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (lstage == 1 && kind == 0) {
             if (flags & DV_TRIAL) {                                         // x = xp + step * d (lbfgs.hpp:825-826)
                 __syncthreads();
-                for (int i = t; i < n; i += 256) x[i] = xp[i] + step * dv[i];
+                for (int i = t; i < n; i += 256) { const double xv = xp[i] + step * dv[i]; x[i] = xv; stg<true>(pub + i, xv, wt); }   // (drained with the forward map's stores before the CT phase word)
             }
             if (flags & DV_EVAL) {
-                __syncthreads();                                            // (vmcnt(0) + barrier: x is complete and visible to this CU)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // x is complete in LDS (no vmcnt: the trial point's stores to `pub` drain behind the forward map)
                 RK_PROF(RK_P_VECTORS);
                 forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt, &ro);
                 kind = PH_CT; lstage = 2;
@@ -333,8 +329,22 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         pseq++;
         if (t == 0) __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
         if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
-        if (t == 0 && seq_pending != 0) {                                   // the previous round's result (system-scope stores, drained above) becomes visible to the host;
-            __hip_atomic_store(&a.h_res[c].seq, seq_pending, FRX_RLX_SYS);  // no release fence: its L2 write-back (0.7 us per round) would serve cached stores, and there are none to publish
+        if (seq_pending != 0) {
+            // The result of the round whose acceptance the leader predicted goes to the host only NOW, behind the phase word of the step it
+            // started: posted right after the adjoint (round 2), its five stores to host memory sat in front of this publication's drain -
+            // ~1.5 us of PCIe write acknowledgements between the end of the adjoint and the cluster's start on the new direction, on three
+            // rounds out of four.  Thread 0 alone waits for them (the others meet it at the arrival barrier, behind which the whole
+            // direction phase lies anyway); no release fence: its L2 write-back would serve cached stores, and there are none to publish.
+            if (t == 0) {
+                RoundRes *r = a.h_res + c;
+                __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
+                __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&r->seq, seq_pending, FRX_RLX_SYS);
+            }
             seq_pending = 0;
         }
         RK_PROF(RK_P_PUBLISH);
@@ -358,10 +368,10 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
             double acc = 0.0;
             for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; }
-            if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what the cluster was given and what it returned
+            if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what came back for the pair logged by accept_step
                 const size_t rec = 4 * (size_t)a.NXP + 2;
                 double *row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * rec;
-                for (int i = t; i < n; i += 256) { row[i] = ldg<true>(pub + i); row[a.NXP + i] = ldg<true>(pub + a.NXP + i); row[2 * a.NXP + i] = gp[i]; row[3 * a.NXP + i] = dv[i]; }
+                for (int i = t; i < n; i += 256) row[3 * a.NXP + i] = dv[i];
                 if (t == 0) { row[4 * a.NXP] = (double)last_slot; row[4 * a.NXP + 1] = (double)last_bound; a.dbg[c] = (double)(nadv_l + 1); }
             }
             nadv_l++;
@@ -377,7 +387,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             if (unconfirmed && t == 0) early_w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
-            rk_drain_and_meet();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
@@ -418,18 +428,16 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     spec_ready = true;
                 }
             }
-            if (t == 0) {
+            if (spec_ready) seq_pending = hseq;                             // nobody waits for the host's answer to this one: posted behind the next phase word (above)
+            else if (t == 0) {
                 RoundRes *r = a.h_res + c;
                 __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->gg, (rk_u64)__double_as_longlong(ctlD[3]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->dginit, (rk_u64)__double_as_longlong(ctlD[4]), FRX_RLX_SYS);
-                if (spec_ready) seq_pending = hseq;                         // nobody waits for the host's answer to this one: the sequence number follows
-                else {                                                      // behind the next publication's drain instead of a drain of its own
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
-                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
             }
             lstage = 0;
             __syncthreads();
@@ -449,7 +457,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
     const bool wt = v.wt;
     const int hg = wg - 1;                                                  // history chunk of this workgroup (workgroups 1 .. G-2)
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
-    double *ctlD = sm + L.ctl + 8, *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *pair = sm + L.pair, *ev = sm + L.role + a.ct_doubles;
+    double *ctlD = sm + L.ctl + 8, *sC = sm + L.sC, *yC = sm + L.yC, *gC = sm + L.gC, *xpC = sm + L.xpC, *gpC = sm + L.gpC, *pair = sm + L.pair, *ev = sm + L.role + a.ct_doubles;
     double *pub = v.pub, *part = v.part, *upub = v.upub, *dpub = v.dpub;
     const int slot = t & 127, half = t >> 7;
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
@@ -478,16 +486,23 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
         __syncthreads();
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
+        if (kind == PH_INIT) {                                              // this workgroup's chunk of the start point and its gradient: the first pair's "previous point"
+            const int e0 = hg * CHT;
+            for (int i = t; i < CHT; i += 256) { xpC[i] = ldg<true>(pub + e0 + i); gpC[i] = ldg<true>(pub + a.NXP + e0 + i); }
+        }
 
         // ------------------------------------------------------------------------------------------------------------------
         // PHASE ADV: new pair into the history, 4 m dot products, dense step, linear combination
         // ------------------------------------------------------------------------------------------------------------------
         if (kind == PH_ADV) {
             nadv++;
-            // -- 1. this workgroup's chunk of s, y, g --
+            // -- 1. this workgroup's chunk of the accepted point and its gradient; s = x - xp, y = g - gp against the chunk kept from the previous step --
             const int e0 = hg * CHT;
-            for (int i = t; i < CHT; i += 256) { sC[i] = ldg<true>(pub + e0 + i); yC[i] = ldg<true>(pub + a.NXP + e0 + i); gC[i] = ldg<true>(pub + 2 * a.NXP + e0 + i); }
-            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 3 * a.NXP + 1); }
+            for (int i = t; i < CHT; i += 256) {
+                const double xv = ldg<true>(pub + e0 + i), gv = ldg<true>(pub + a.NXP + e0 + i);
+                sC[i] = xv - xpC[i]; yC[i] = gv - gpC[i]; gC[i] = gv; xpC[i] = xv; gpC[i] = gv;
+            }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 2 * a.NXP + 1); }
             __syncthreads();
             jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]); bound = __builtin_amdgcn_readfirstlane((int)ctlU[2]);   // wave-uniform by construction
             // -- 2. the new pair replaces slot jnew --
@@ -522,14 +537,27 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             {
                 const double coefS = ldg<true>(upub + slot), coefY = ldg<true>(upub + 128 + slot);
                 if (t == 0) ctlD[6] = ldg<true>(upub + 256);
-                double *wsum = pair;                                       // [4 waves][E]
+                // Element i of the chunk is a sum over the 128 SLOTS of this thread's products - a reduction ACROSS threads for each of the
+                // 2 E elements.  Round 2 did it with 14 packed four-value wave reductions per wave (~460 dependent DPP / crossbar
+                // instructions, ~1.6 us on a lone wave); now every thread drops its E products into an LDS square [256][E + 1] (the penalty
+                // scratch is idle in this phase; odd row stride: conflict-free both ways) and 4 E threads add up one column half each, in
+                // slot order - E stores, 64 loads and 64 additions per thread, fixed order.
+                double *xt = sm + L.role;                                  // [256][E + 1]
+                constexpr int XS = E + 1;
+                {
+                    double *mine = xt + t * XS;
 #pragma unroll
-                for (int e4 = 0; e4 < E; e4 += 4) {
-                    double v4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v4[k] = valid ? (coefS * Sreg[e4 + k] + coefY * Yreg[e4 + k]) : 0.0;
-                    const double q = wave_sum4_packed<false>(v4);          // lane k < 4 holds the sum of value k over the wave's 64 slots
-                    if (lane < 4) wsum[wave * E + e4 + lane] = q;
+                    for (int e = 0; e < E; e++) mine[e] = valid ? (coefS * Sreg[e] + coefY * Yreg[e]) : 0.0;
+                }
+                __syncthreads();
+                double *wsum = pair;                                       // [2 halves][2 parts][E]
+                if (t < 4 * E) {
+                    const int grp = t / E, e = t - grp * E;                // grp = half * 2 + part: slots [64 part, 64 part + 64) of that half
+                    const double *col = xt + (size_t)(grp * 64) * XS + e;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+                    for (int i = 0; i < 64; i += 4) { s0 += col[i * XS]; s1 += col[(i + 1) * XS]; s2 += col[(i + 2) * XS]; s3 += col[(i + 3) * XS]; }
+                    wsum[grp * E + e] = (s0 + s1) + (s2 + s3);
                 }
                 __syncthreads();
                 const double gamma = ctlD[6];
@@ -568,6 +596,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
     double *Rf = sm + L.Rf, *vd = sm + L.vd, *va = sm + L.va, *vb = sm + L.vb, *vc = sm + L.vc, *ve = sm + L.ve, *vw = sm + L.vw, *vv = sm + L.vv,
            *mv = sm + L.mv, *mz = sm + L.mv + 256;
     double *pub = v.pub, *part = v.part, *upub = v.upub;
+    double *ctlD = sm + L.ctl + 8;
     const int pp = t & 127, hq = t >> 7, q0 = 64 * hq;
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
     double Ya[32], Yb[32];                                                  // (Y^T Y)[pp][q0 .. q0 + 31], [q0 + 32 .. q0 + 63]: two arrays the compiler keeps in registers
@@ -598,7 +627,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
         if (kind == PH_QUIT) break;
         if (kind == PH_ADV) {
             nadv++;
-            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 3 * a.NXP); const bool ok = rk_wait_eq(a.cntA + c * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); const bool ok = rk_wait_eq(a.cntA + c * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
             __syncthreads();
             const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
             RK_PROF(RK_P_WAIT_PART);
@@ -621,20 +650,9 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             if (t < 128) { Rf[jnew * RK_RS + t] = 0.0; Rf[t * RK_RS + jnew] = 0.0; }                  // the pair that slot jnew held is gone
             __syncthreads();
             RK_PROF(RK_P_DENSE_IN);
-            // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are)
             const int ln = t & 63;                                          // lane ln of every wave holds element q0 + ln of a broadcast vector
-            {
-                const int uj = jnew - q0;
-                const double colv = ve[pp];
-                const bool isrow = pp == jnew;
-#pragma unroll
-                for (int u = 0; u < 32; u++) {                              // (LDS broadcasts here: with rk_bcast this loop measured 1.3 instead of 0.8 us)
-                    const double r0 = ve[q0 + u], r1 = ve[q0 + 32 + u];
-                    Ya[u] = isrow ? r0 : (u == uj ? colv : Ya[u]);
-                    Yb[u] = isrow ? r1 : (u + 32 == uj ? colv : Yb[u]);
-                }
-            }
-            RK_PROF(RK_P_VECTORS);                                          // (dense workgroup: Y^T Y update)
+            // (Y^T Y's registers take the new pair's row and column AFTER the result is published - 0.8 us off the critical path; until
+            // then row / column jnew of the registers still hold the dropped pair: pass 2 masks them and adds the new ones from `ve`)
             const double rho = vc[jnew], gamma = rho / ve[jnew], wl = va[jnew] / rho;      // y.s, y.s / y.y of the newest pair (lbfgs.hpp:1403)
             // pass 1: rows of the old R^-1, two right-hand sides at once: z = R22^-1 c, tt = R22^-1 a (row and column jnew are zero)
             {
@@ -662,10 +680,15 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                 vw[t] = wp;
             }
             __syncthreads();
-            // pass 2: (Y^T Y) w from registers
+            // pass 2: (Y^T Y) w.  The registers hold the matrix of the PREVIOUS step; the new pair's row and column are e = Y^T y_new (ve):
+            //   (YY w)[p] = sum_{q != jnew} YY_old[p][q] w[q] + e[p] w[jnew]   (p != jnew),      (YY w)[jnew] = e . w
             {
                 double sacc = 0.0;
-                const double vwl = vw[q0 + ln];
+                const double vwl = (q0 + ln == jnew) ? 0.0 : vw[q0 + ln];
+                if (t < 128) {                                              // e . w on waves 0 and 1, interleaved with the products below
+                    const double ws = wave_sum_dpp(ve[t] * vw[t]);
+                    if (ln == 0) ctlD[t >> 6] = ws;
+                }
 #pragma unroll
                 for (int u = 0; u < 32; u++) { sacc += Ya[u] * rk_bcast(vwl, u); if ((u & 15) == 15) RK_CHUNK(); }
 #pragma unroll
@@ -674,7 +697,10 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             }
             __syncthreads();
             RK_PROF(RK_P_FORWARD);                                          // (dense workgroup: column update + pass 2)
-            if (t < 128) vv[t] = vd[t] * vw[t] + gamma * (mv[t] + mv[128 + t]) - gamma * vb[t];
+            if (t < 128) {
+                const double yyw = t == jnew ? ctlD[0] + ctlD[1] : (mv[t] + mv[128 + t]) + ve[t] * vw[jnew];
+                vv[t] = vd[t] * vw[t] + gamma * yyw - gamma * vb[t];
+            }
             __syncthreads();
             // pass 3: columns of the new R^-1: u = R^-T v
             {
@@ -703,6 +729,18 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             rk_drain_and_meet();
             if (t == 0) __hip_atomic_store(a.uflag + c * RK_WSTRIDE, nadv, FRX_RLX_AGENT);
             RK_PROF(RK_P_SOLVE);
+            {   // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are) - behind the publication
+                const int uj = jnew - q0;
+                const double colv = ve[pp];
+                const bool isrow = pp == jnew;
+#pragma unroll
+                for (int u = 0; u < 32; u++) {                              // (LDS broadcasts here: with rk_bcast this loop measured 1.3 instead of 0.8 us)
+                    const double r0 = ve[q0 + u], r1 = ve[q0 + 32 + u];
+                    Ya[u] = isrow ? r0 : (u == uj ? colv : Ya[u]);
+                    Yb[u] = isrow ? r1 : (u + 32 == uj ? colv : Yb[u]);
+                }
+            }
+            RK_PROF(RK_P_VECTORS);                                          // (dense workgroup: Y^T Y update)
         }
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);

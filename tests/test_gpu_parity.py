@@ -271,7 +271,10 @@ def test_ragged_batch_and_split_polytopes(frx, sc, ob):
                     assert rel(T[sl], Tr) < 1e-13 and rel(Cf[6 * sl.start:6 * sl.stop], Cr) < 1e-7
         prob.set_solver("knot_pcr")
         res = prob.optimize(1e-6, max_iterations=40)
-        assert np.all((res["status"] == -1004) | (res["status"] >= 0)), res["status"]     # 40 iterations: the limit (LBFGSERR_MAXIMUMITERATION) or an earlier stop
+        # the reference's verdict after 40 iterations, candidate by candidate: the iteration limit (-1004) for most, LBFGSERR_MAXIMUMLINESEARCH
+        # (-1005) for the one-piece candidate, whose single variable is converged long before
+        cpu_status = [int(o.optimize(1e-6, max_iterations=40)["status"]) for o in oracles]
+        assert list(res["status"]) == cpu_status, (list(res["status"]), cpu_status)
         for b, o in enumerate(oracles):                       # the reported value is the objective of the returned point
             f_ref, _ = o.objective(res["x"][prob.x_off[b]:prob.x_off[b + 1]])
             assert abs(f_ref - res["objective"][b]) <= 1e-9 * abs(f_ref)
