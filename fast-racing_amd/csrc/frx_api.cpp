@@ -482,13 +482,18 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     ge.lpp = std::min(spp, 64);
     ge.ppw = 64 / ge.lpp;
     {   // stage kernel k_penalty: a workgroup of W waves owns floor(64 W / lpp) whole pieces; W in 1..4 for the best lane utilisation (the
-        // fewest waves among equals).  kappa = 16: 51/64 lanes with one wave, 255/256 with four; stock kappa = 48: 49/64 and 245/256.
-        // FRX_PENALTY_WAVES=1..4 overrides (measurements).
+        // fewest waves among equals) - kappa = 16: 51/64 lanes with one wave, 255/256 with four; stock kappa = 48: 49/64 and 245/256.
+        // Measured (profiles/r03_penalty_waves_per_workgroup.jsonl, kappa = 16): 1024 candidates 40.3 -> 35.9 us, 4096 candidates 153 -> 132 us
+        // (kappa = 48, 1024 candidates: 116 -> 95 us); but a launch that fits the chip's SIMDs in one go is ONE wave's latency, and there
+        // one-wave workgroups (no barrier, twice the CUs in use) win: 4.79 against 5.17 us at the headline batch.  FRX_PENALTY_WAVES=1..4 overrides.
         int best_w = 1; double best_u = 0.0;
         for (int w = 1; w <= 4; w++) {
             const double u = (double)((64 * w) / ge.lpp * ge.lpp) / (64.0 * w);
             if (u > best_u + 1e-9) { best_u = u; best_w = w; }
         }
+        int simds = 1024;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) simds = 4 * prop.multiProcessorCount; }
+        if ((p->P + ge.ppw - 1) / ge.ppw <= simds) best_w = 1;
         if (const char *pw = std::getenv("FRX_PENALTY_WAVES")) { const int w = std::atoi(pw); if (w >= 1 && w <= 4) best_w = w; }
         ge.pen_w = best_w; ge.ppg = (64 * best_w) / ge.lpp;
     }

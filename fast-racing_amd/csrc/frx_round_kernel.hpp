@@ -383,16 +383,15 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             RK_PROF(RK_P_GATHER);
         }
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
-            rk_u64 early_w = 0;                                             // the host's command for a predicted round: read it while the adjoint runs
-            if (unconfirmed && t == 0) early_w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
+            if (unconfirmed) tap.early_cmd = &a.h_cmd[c * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
                     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                    rk_u64 w = early_w;
+                    rk_u64 w = (rk_u64)__double_as_longlong(ctlD[7]);
                     bool ok = true;
                     for (unsigned spins = 0; (w >> 32) != hseq; spins++) {
                         w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
