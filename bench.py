@@ -12,8 +12,12 @@ owns its own batch of 32 candidates (different gate perturbations); the evaluati
 collective — the only exchange is the final winner selection, outside the timed region.
 
 The JSON line also carries:
-  roofline      for the dominant kernel k_penalty: algorithmic bytes (sum over pieces of 312 + 48 K_i,
-                SURVEY.md §8d) / its average duration measured with HIP events on the launch stream
+  roofline      the penalty integrator k_penalty (the kernel SURVEY.md §8d prices): algorithmic bytes (sum over pieces of
+                312 + 48 K_i) / its average duration, HIP events on the library's launch stream, measured in this run;
+                roofline.evaluation = the whole step against §8d's bytes of an evaluation (penalty bytes + 16 n + 24 sum nv per
+                candidate); the two knot kernels with their IMPLEMENTATION traffic (stage buffers, saved multipliers - not
+                algorithmic bytes).  Counter figures (HBM traffic, VALU busy) come from the committed counter passes of the same
+                gpurun call and are marked "from_profile": true
   cpu_baseline  the CPU oracle (faithful restatement of the reference CPU path) timed on the host cores
   plan_*        full SE(3) plan (frx_optimize from the reference's initial guess, stock OptRelTol)
 """
@@ -152,7 +156,7 @@ def main():
     samples_per_step = prob.samples()
 
     # the three stage kernels one at a time (HIP events on the library's launch stream, frx_eval_stage_times): the roofline object is
-    # reported for the one that takes longest, the penalty integrator keeps its own sub-object (it is the kernel SURVEY.md 8d prices)
+    # reported for the penalty integrator (the kernel SURVEY.md 8d prices); the two knot kernels get sub-objects with their implementation traffic
     stage_us = prob.stage_times(x_state, reps=max(args.steps, 100))
     # evaluation time along the optimisation (SURVEY.md 8d "kernel-only benchmark state"): the reference initial guess and the iterates
     # after 10 / 20 / 40 / 80 iterations; the headline `value` is taken at the 60-iteration state above
@@ -179,9 +183,9 @@ def main():
     fwd_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + (8 * steps + 4) * 8 * npc))
     adj_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + 160 * npc + (8 * steps + 4) * 8 * npc + 8 * nx + 8))
     stage_bytes = {"forward": fwd_bytes, "penalty": alg_bytes, "adjoint": adj_bytes}
-    dominant = max(stage_us, key=stage_us.get)
-    dom_kernel = {"forward": "frx::k_forward_knot", "penalty": "frx::k_penalty_lat", "adjoint": "frx::k_backward_knot"}[dominant]
-    dom_achieved = stage_bytes[dominant] / (stage_us[dominant] * 1e-6) / 1e9
+    pen_kernel = "frx::k_penalty" if os.environ.get("FRX_PENALTY_FORM", "l")[0] == "t" else "frx::k_penalty_lat"     # launch_penalty's choice (csrc/frx_device.hip)
+    # SURVEY.md 8d, "full objective evaluation": penalty bytes + x in and g out (16 n) + the waypoint polytopes (24 bytes per vertex) per candidate
+    eval_bytes = int(alg_bytes + np.sum(16 * nx + 24 * nvert))
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
     fp64 = None
     fc = os.path.join(ROOT, "profiles", "r02_fp64_count_k_penalty.json")
@@ -191,26 +195,23 @@ def main():
         fp64 = {"flops_per_sample": fl, "flops_per_sample_all_corridor_planes_violated": fj["flops_per_sample_all_violated"], "source": "profiles/r02_fp64_count_k_penalty.json",
                 "achieved_tflops": fl * samples_per_step / (pen_us * 1e-6) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                 "frac": fl * samples_per_step / (pen_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS}
-    # HBM traffic per launch of k_penalty from the committed PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # in separate runs, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): profiles/r01_pmc_headline.json
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_headline.json")
-    if not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_headline.json")
-    if os.path.exists(pmc_file) and args.config == "headline":
+    # Counter passes (rocprofv3 --pmc, one counter set per pass, scripts/r03/gpu_pmc.sh) of the gpurun call that produced the committed bench line:
+    # read from profiles/, never measured inside this process - hence "from_profile".  FETCH_SIZE / WRITE_SIZE are converted to bytes with the
+    # factors calibrated in the same call on a coalesced copy of known size (8-byte and 16-byte accesses per lane).
+    traffic, traffic_src, valu, knot_traffic, calib = None, None, None, {}, None
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_headline.json",)) if os.path.exists(f)), None)
+    if pmc_file and args.config == "headline":
         pj = json.load(open(pmc_file))
-        traffic, traffic_src = pj["traffic_bytes_per_launch"], os.path.relpath(pmc_file, ROOT)
-
-    # VALU utilisation of the same kernel from the committed counter pass (scripts/gpu_pmc_valu.sh): the path is FP64-issue
-    # bound, not HBM bound (SURVEY.md 8d asks for the FP64 VALU fraction next to the HBM one)
-    valu = None
-    valu_file = os.path.join(ROOT, "profiles", "r02_pmc_headline.json")
-    if os.path.exists(valu_file) and args.config == "headline":
-        vj = json.load(open(valu_file)).get("valu_latency_form_148_vgprs_default", {})
-        cls = sorted(vj.items(), key=lambda kv: int(kv[0].split("_")[1]))          # launch classes by grid size: headline, large batch
+        traffic, traffic_src, calib = pj["traffic_bytes_per_launch"], os.path.relpath(pmc_file, ROOT), {k: v["bytes_per_counted_byte"] for k, v in pj["calibration"].items()}
+        for kname, key in (("k_forward_knot", "forward"), ("k_backward_knot", "adjoint")):
+            grids = pj["kernels"].get(kname, {})
+            if grids:
+                small = sorted(grids, key=lambda k: int(k.split("_")[1]))[0]
+                knot_traffic[key] = grids[small].get("traffic_bytes_per_launch_range")
+        cls = sorted(pj.get("valu_k_penalty_lat", {}).items(), key=lambda kv: int(kv[0].split("_")[1]))          # launch classes by grid size: headline, large batch
         if cls:
-            valu = {"source": "profiles/r02_pmc_headline.json", "headline_valu_busy": cls[0][1]["valu_busy_frac"],
-                    "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"], "large_batch_waves_per_simd": cls[-1][1]["mean_waves_per_simd"],
-                    "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"]}
+            valu = {"from_profile": True, "source": traffic_src, "headline_valu_busy": cls[0][1]["valu_busy_frac"], "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"],
+                    "large_batch_waves_per_simd": cls[-1][1]["mean_waves_per_simd"], "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"]}
 
     # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
     # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
@@ -278,6 +279,7 @@ def main():
                 "plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
                 "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min()),
+                "plan_resident_failed": int(r["resident_failed"]), "plan_resident_retried": int(r["resident_retried"]),
                 "plan_path": ("resident round kernel, %d workgroups per candidate" % r["resident"]) if r["resident"] else "one launch per stage and round",
                 "plan_us_per_round": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
         if rank == 0:
@@ -307,16 +309,24 @@ def main():
                        "step": "one batched objective evaluation x->(f,grad): k_forward + k_penalty + k_backward, inputs resident in HBM",
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "selected_by": "longest of the three stage kernels (HIP events)", "achieved": dom_achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom_achieved / HBM_PEAK_GBS, "traffic": traffic if dominant == "penalty" else None,
-                         "traffic_note": None if dominant == "penalty" else "PMC traffic is calibrated for the penalty integrator only (16-byte streaming loads: roofline.penalty.traffic); "
-                                         "raw, uncorrected FETCH_SIZE / WRITE_SIZE of the knot kernels: knot_kernels_raw_uncalibrated in profiles/r02_pmc_headline.json",
-                         "algorithmic_bytes_per_launch": stage_bytes[dominant], "avg_kernel_us": stage_us[dominant],
-                         "stage_kernels_us": stage_us, "stage_algorithmic_bytes": stage_bytes,
-                         "stage_fracs": {k: stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS for k in stage_us},
-                         "penalty": {"kernel": "frx::k_penalty_lat", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_kernel_us": pen_us, "traffic": traffic,
-                                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6),
-                                     "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6), "fp64": fp64, "large_batch": large, "valu": valu},
+            "roofline": {"bound": "hbm", "kernel": pen_kernel, "selected_by": "the kernel SURVEY.md 8d prices: the penalty integrator (CPU.hpp:188-408 = cuda_computer::compute)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,
+                         "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_stage_times)",
+                         "traffic": traffic, "traffic_from_profile": traffic is not None, "traffic_source": traffic_src, "counter_calibration_bytes_per_counted_byte": calib,
+                         "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6), "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6),
+                         "fp64": fp64, "valu": valu, "large_batch": large,
+                         "evaluation": {"what": "one whole step x -> (f, grad): forward map + penalty integrator + adjoint (three launches)",
+                                        "algorithmic_bytes_per_step": eval_bytes, "definition": "SURVEY.md 8d: penalty bytes + 16 n + 24 sum(nv) per candidate",
+                                        "us_per_step": dt / args.steps * 1e6, "achieved": eval_bytes / (dt / args.steps) / 1e9, "unit": "GB/s",
+                                        "frac": eval_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "stage_kernels_us": stage_us,
+                         "knot_kernels": {k: {"kernel": {"forward": "frx::k_forward_knot", "adjoint": "frx::k_backward_knot"}[k], "avg_kernel_us": stage_us[k],
+                                              "implementation_traffic_bytes": stage_bytes[k],
+                                              "implementation_traffic_note": "x, waypoint polytopes, (T, C), out20, saved reduction multipliers, g: stage buffers between the three launches, NOT algorithmic bytes",
+                                              "implementation_traffic_frac_of_hbm_peak": stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                              "traffic_range": knot_traffic.get(k), "traffic_from_profile": knot_traffic.get(k) is not None,
+                                              "bound": "latency: one workgroup per candidate, a dependent FP64 chain (DESIGN.md 3.1, 3.3)"} for k in ("forward", "adjoint")},
                          "hbm_bound_kernel": hbm_kernel, "states": states},
             "cpu_baseline": cpu,
         }

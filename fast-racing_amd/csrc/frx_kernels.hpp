@@ -257,6 +257,56 @@ struct LdsView {
     __device__ __forceinline__ void fence() { asm volatile("" : "+v"(off)); }
 };
 
+// The samples of ONE lane (sample jl, jl + lpp, ... of the piece whose coefficients are at cS and corridor block at hS, duration Tp): their 20 partials
+// {cost, d/dT, d/dc[6][3]} accumulated into the lane's LDS slot `mine`.
+template <bool LAT>
+__device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const double *cS, const double *hS, double Tp, int jl, int lpp, double *mine) {
+    LdsView c(cS), hb(hS);
+    const int K = (int)hb[3];
+    const int kappa = dp.kappa;
+    const double step = Tp / kappa;                           // CPU.hpp:245
+    const double invK = dp.inv_kappa;
+    bool first = true;
+    for (int j = jl; j <= kappa; j += lpp) {
+        const double s1 = step * j;                           // sample abscissa as cc.cu:152
+        const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
+        double adj[12], Ps, gTa;
+        penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, adj, Ps, gTa);
+        if (!LAT) { c.fence(); FRX_PHASE(); }
+        // the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates
+        double o[20];
+        o[0] = omg * step * Ps; o[1] = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
+        const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+        const double b0[6] = {1.0, s1, s2, s3, s4, s5};
+        const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+        const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+        const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) o[2 + 3 * k + d] = b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
+        if (!first) {
+#pragma unroll
+            for (int i = 0; i < 20; i++) o[i] += mine[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 20; i++) mine[i] = o[i];
+        first = false;
+    }
+}
+// fixed-order reduction over the samples of each piece (lane slots red[lane * 21 ..]): thread = (piece of the group, value)
+template <bool SH>
+__device__ __forceinline__ void penalty_reduce(const double *red, int npieces, int lpp, double *__restrict__ out, int lane, int nthr, bool wt) {
+    for (int idx = lane; idx < npieces * 20; idx += nthr) {
+        const int p2 = idx / 20, v = idx - p2 * 20;
+        const double *src = red + (p2 * lpp) * 21 + v;
+        double s = 0.0;
+#pragma unroll 4
+        for (int l = 0; l < lpp; l++) s += src[l * 21];
+        stg<SH>(out + idx, s, wt);
+    }
+}
+
 // The body works on the pieces [gp0, gp0 + npieces) with a GROUP of nthr = 64 W threads (`lane` = index in the group) and `sm` = the
 // group's private LDS.  W = 1: one wave (the resident round kernel gives every wave of a workgroup its own pieces and LDS); W > 1: the
 // whole workgroup (the stage kernel).  Lane L owns sample L % lpp of piece L / lpp, so a group covers floor(64 W / lpp) whole pieces:
@@ -309,51 +359,9 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     __syncthreads();
 
     const bool active = pl < npieces && (pfl & DV_EVAL);
-    double *mine = red + lane * 21;
-    if (active) {
-        LdsView c(cS + pl * 18), hb(hS + (size_t)pl * hstride);
-        const int K = (int)hb[3];
-        const int kappa = dp.kappa;
-        const double step = tS[pl] / kappa;                      // CPU.hpp:245
-        const double invK = dp.inv_kappa;
-        bool first = true;
-        for (int j = jl; j <= kappa; j += lpp) {
-            const double s1 = step * j;                           // sample abscissa as cc.cu:152
-            const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
-            double adj[12], Ps, gTa;
-            penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, adj, Ps, gTa);
-            if (!LAT) { c.fence(); FRX_PHASE(); }
-            // the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates
-            double o[20];
-            o[0] = omg * step * Ps; o[1] = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
-            const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-            const double b0[6] = {1.0, s1, s2, s3, s4, s5};
-            const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
-            const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
-            const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-#pragma unroll
-                for (int d = 0; d < 3; d++) o[2 + 3 * k + d] = b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
-            if (!first) {
-#pragma unroll
-                for (int i = 0; i < 20; i++) o[i] += mine[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 20; i++) mine[i] = o[i];
-            first = false;
-        }
-    }
+    if (active) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, red + lane * 21);
     __syncthreads();
-    // fixed-order reduction over the samples of each piece: lane = (piece-in-wave, value)
-    for (int idx = lane; idx < npieces * 20; idx += nthr) {
-        const int p2 = idx / 20, v = idx - p2 * 20;
-        const double *src = red + (p2 * lpp) * 21 + v;
-        double s = 0.0;
-#pragma unroll 4
-        for (int l = 0; l < lpp; l++) s += src[l * 21];
-        stg<SH>(out20 + (size_t)gp0 * 20 + idx, s, wt);
-    }
+    penalty_reduce<SH>(red, npieces, lpp, out20 + (size_t)gp0 * 20, lane, nthr, wt);
 }
 // Stage kernels: a workgroup of blockDim.x = 64 W threads owns ppg = floor(64 W / lpp) consecutive pieces (LaunchGeom::pen_w, ::ppg).
 __global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
@@ -369,6 +377,51 @@ __global__ __launch_bounds__(256, 3) void k_penalty_lat(DevProblem dp, const dou
     extern __shared__ double sm[];
     const int gp0 = blockIdx.x * ppg;
     penalty_body<false, true>(dp, T, C, out20, lpp, ppg, Kmax, gp0, min(ppg, dp.P - gp0), sm, threadIdx.x, true, blockDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_penalty_stream: the same integrand for grids that fill the chip several times over (hundreds of candidates).  PERSISTENT workgroups
+// walk over the groups of pieces; the next group's coefficients, durations and corridor blocks travel global -> LDS with
+// global_load_lds_dwordx4 (no VGPRs, nothing for the sample's register allocation to give up) into the second of two buffers while the
+// current group's samples are evaluated, so a wave no longer spends the first third of every task waiting for its operands (round 2:
+// VALU busy 50 % at 2.15 resident waves per SIMD; the register-prefetching form of round 2 was slower because the prefetch forced the
+// phased sample).  Rules of the LDS-DMA path (CDNA guide): one `extern __shared__` array, no ordinary global load inside the loop
+// (hipcc would wait vmcnt(0) at its use and drain the DMA), raw s_barrier with lgkmcnt-only waits, one explicit vmcnt(0) where the
+// buffer is first read.  Arithmetic, lane mapping and reduction order are penalty_body's: bit-equal results.
+// Dynamic LDS (doubles): 2 x { cS[ppg 18] | tS[ppg, even] | hS[ppg hstride] } | red[nthr 21]
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *lds_vptr;
+typedef const __attribute__((address_space(1))) void *glb_cvptr;
+template <bool LAT>
+__global__ __launch_bounds__(256, 3) void k_penalty_stream(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                           double *__restrict__ out20, int lpp, int ppg, int Kmax, int ngroups) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int nthr = blockDim.x, lane = threadIdx.x, w64 = (lane >> 6) << 6;
+    const int hstride = (Kmax + 1) * 4;
+    const int cD = ppg * 18, tD = (ppg + 1) & ~1, hD = ppg * hstride, BUFD = cD + tD + hD;
+    double *red = sm + 2 * BUFD;
+    const int pl = lane / lpp, jl = lane - pl * lpp;
+    auto issue = [&](int grp, double *buf) {
+        const int gp0 = grp * ppg, np = min(ppg, dp.P - gp0);
+        const int nc = np * 9, nh = (np * hstride) >> 1, nt = 2 * np;          // 16-byte chunks of coefficients and corridor blocks, dwords of durations
+        const double *csrc = C + (size_t)gp0 * 18, *hsrc = dp.hblk + (size_t)gp0 * hstride;
+        const unsigned *tsrc = (const unsigned *)(T + gp0);
+        for (int q0 = 0; q0 < nc; q0 += nthr) if (q0 + lane < nc) __builtin_amdgcn_global_load_lds((glb_cvptr)(csrc + 2 * (q0 + lane)), (lds_vptr)(buf + 2 * (q0 + w64)), 16, 0, 0);
+        for (int q0 = 0; q0 < nh; q0 += nthr) if (q0 + lane < nh) __builtin_amdgcn_global_load_lds((glb_cvptr)(hsrc + 2 * (q0 + lane)), (lds_vptr)(buf + cD + tD + 2 * (q0 + w64)), 16, 0, 0);
+        for (int q0 = 0; q0 < nt; q0 += nthr) if (q0 + lane < nt) __builtin_amdgcn_global_load_lds((glb_cvptr)(tsrc + q0 + lane), (lds_vptr)((unsigned *)(buf + cD) + q0 + w64), 4, 0, 0);
+    };
+    int grp = blockIdx.x, cur = 0;
+    if (grp < ngroups) issue(grp, sm);
+    for (; grp < ngroups; grp += gridDim.x, cur ^= 1) {
+        double *buf = sm + cur * BUFD;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // this group's operands have landed (every wave's share); the previous group's reduction is over
+        const int nxt = grp + gridDim.x;
+        if (nxt < ngroups) issue(nxt, sm + (cur ^ 1) * BUFD);                         // into the buffer the previous group was read from
+        const int gp0 = grp * ppg, np = min(ppg, dp.P - gp0);
+        if (pl < np) penalty_lane_samples<LAT>(dp, buf + pl * 18, buf + cD + tD + (size_t)pl * hstride, buf[cD + pl], jl, lpp, red + lane * 21);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        penalty_reduce<false>(red, np, lpp, out20 + (size_t)gp0 * 20, lane, nthr, true);
+    }
 }
 
 // (A streaming form for large batches - 3072 one-wave workgroups walking over the wave-tasks with the next task's global reads in flight during

@@ -220,6 +220,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     // so it forms s and y itself - bit for bit the values the leader would have sent.  Round 2 published s, y and g here: 2016 stores and
     // their drain (1.5-2 us) between the end of the adjoint and the phase word of every accepted step.
     unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
+    bool trial_done = false, dg_pending = false;
     auto accept_step = [&]() {
         double *row = nullptr;                                              // direction log (tests): the pair and the gradient the direction is built from
         if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * (4 * (size_t)a.NXP + 2);
@@ -305,10 +306,11 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             }
         }
         if (lstage == 1 && kind == 0) {
-            if (flags & DV_TRIAL) {                                         // x = xp + step * d (lbfgs.hpp:825-826)
+            if ((flags & DV_TRIAL) && !trial_done) {                        // x = xp + step * d (lbfgs.hpp:825-826); after an ADVANCE the gather above has done it
                 __syncthreads();
                 for (int i = t; i < n; i += 256) { const double xv = xp[i] + step * dv[i]; x[i] = xv; stg<true>(pub + i, xv, wt); }   // (drained with the forward map's stores before the CT phase word)
             }
+            trial_done = false;
             if (flags & DV_EVAL) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // x is complete in LDS (no vmcnt: the trial point's stores to `pub` drain behind the forward map)
                 RK_PROF(RK_P_VECTORS);
@@ -366,8 +368,16 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             break;
         }
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
+            // ... and, in the same sweep, the first trial point of the new search x = xp + step d (lbfgs.hpp:825-826; every ADVANCE command
+            // carries TRIAL): the element a thread gathers is the element it moves, so no barrier lies between the two
             double acc = 0.0;
-            for (int i = t; i < n; i += 256) { const double di = ldg<true>(dpub + i); dv[i] = di; acc += gp[i] * di; }
+            const bool with_trial = (flags & DV_TRIAL) != 0;
+            for (int i = t; i < n; i += 256) {
+                const double di = ldg<true>(dpub + i);
+                dv[i] = di; acc += gp[i] * di;
+                if (with_trial) { const double xv = xp[i] + step * di; x[i] = xv; stg<true>(pub + i, xv, wt); }
+            }
+            trial_done = with_trial;
             if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what came back for the pair logged by accept_step
                 const size_t rec = 4 * (size_t)a.NXP + 2;
                 double *row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * rec;
@@ -376,13 +386,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             }
             nadv_l++;
             const double ws = wave_sum_dpp(acc);
-            if (lane == 0) pair[wave] = ws;
-            __syncthreads();
-            if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]);
-            __syncthreads();
+            if (lane == 0) pair[wave] = ws;                                 // summed by thread 0 in front of the adjoint: the barriers of the forward map lie in between
+            dg_pending = true;
             RK_PROF(RK_P_GATHER);
         }
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
+            if (dg_pending) { if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]); dg_pending = false; }   // gp . d of this round's ADVANCE (read behind the adjoint's barrier)
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
             if (unconfirmed) tap.early_cmd = &a.h_cmd[c * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
