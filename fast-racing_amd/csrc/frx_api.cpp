@@ -486,7 +486,6 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         // Measured (profiles/r03_penalty_waves_per_workgroup.jsonl, kappa = 16): 1024 candidates 40.3 -> 35.9 us, 4096 candidates 153 -> 132 us
         // (kappa = 48, 1024 candidates: 116 -> 95 us); but a launch that fits the chip's SIMDs in one go is ONE wave's latency, and there
         // one-wave workgroups (no barrier, twice the CUs in use) win: 4.79 against 5.17 us at the headline batch.  FRX_PENALTY_WAVES=1..4 overrides.
-        const size_t lds_cap_bytes = 160 * 1024;
         int best_w = 1; double best_u = 0.0;
         for (int w = 1; w <= 4; w++) {
             const double u = (double)((64 * w) / ge.lpp * ge.lpp) / (64.0 * w);
@@ -497,19 +496,6 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         if ((p->P + ge.ppw - 1) / ge.ppw <= simds) best_w = 1;
         if (const char *pw = std::getenv("FRX_PENALTY_WAVES")) { const int w = std::atoi(pw); if (w >= 1 && w <= 4) best_w = w; }
         ge.pen_w = best_w; ge.ppg = (64 * best_w) / ge.lpp;
-        // k_penalty_stream: persistent workgroups for grids that fill the SIMDs several times over.  FRX_PENALTY_STREAM=0|1 forces it off / on,
-        // FRX_PENALTY_STREAM_WAVES=1..4 the workgroup width (default: the stage kernel's choice among the utilisation-equal widths).
-        const int cus = simds / 4;
-        int sw = best_w == 1 && ge.lpp <= 32 ? 1 : best_w;
-        if (const char *e = std::getenv("FRX_PENALTY_STREAM_WAVES")) { const int w = std::atoi(e); if (w >= 1 && w <= 4) sw = w; }
-        const int sppg = (64 * sw) / ge.lpp;
-        const size_t bufd = (size_t)sppg * 18 + ((sppg + 1) & ~1) + (size_t)sppg * (p->Kmax + 1) * 4;
-        ge.lds_pens = sizeof(double) * (2 * bufd + (size_t)64 * sw * 21);
-        const int per_cu = std::max(1, std::min((int)(lds_cap_bytes / std::max<size_t>(ge.lds_pens, 1)), 12 / sw));   // 148 VGPRs: three waves per SIMD
-        ge.pen_sw = sw; ge.pen_sppg = sppg; ge.pen_sgrid = cus * per_cu;
-        const int waves1 = (p->P + ge.ppw - 1) / ge.ppw;
-        ge.pen_stream = ge.lds_pens <= lds_cap_bytes && waves1 > 4 * simds ? 1 : 0;
-        if (const char *e = std::getenv("FRX_PENALTY_STREAM")) ge.pen_stream = (e[0] != '0' && ge.lds_pens <= lds_cap_bytes) ? 1 : 0;
     }
     ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
     ge.lds_bwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 6) + 2 * (size_t)p->maxN + p->maxCN);

@@ -17,10 +17,6 @@ int launch_set_limits(const LaunchGeom &g) {
     if ((e = hipFuncSetAttribute((const void *)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_penalty, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_penalty_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
-    if (g.pen_stream) {
-        if ((e = hipFuncSetAttribute((const void *)k_penalty_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pens)) != hipSuccess) return (int)e;
-        if ((e = hipFuncSetAttribute((const void *)k_penalty_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pens)) != hipSuccess) return (int)e;
-    }
     if ((e = hipFuncSetAttribute((const void *)k_forward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_backward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
     return 0;
@@ -37,12 +33,6 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
     // (4.97 vs 5.23 us) AND at 1024 candidates (39.8 vs 42.3 us) than the throughput form (126 VGPRs, 4 waves per SIMD); FRX_PENALTY_FORM=thr selects that one
     static const int forced = [] { const char *e = std::getenv("FRX_PENALTY_FORM"); return !e ? 0 : e[0] == 'l' ? 1 : 2; }();
     const bool lat = forced != 2;
-    if (g.pen_stream && !dp.piece_active) {                         // chip-filling grids: persistent workgroups with the next group's operands in flight (k_penalty_stream)
-        const int ngroups = (dp.P + g.pen_sppg - 1) / g.pen_sppg, grid = std::min(ngroups, g.pen_sgrid);
-        if (lat) hipLaunchKernelGGL(k_penalty_stream<true>, dim3(grid), dim3(64 * g.pen_sw), g.lds_pens, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.pen_sppg, g.Kmax, ngroups);
-        else hipLaunchKernelGGL(k_penalty_stream<false>, dim3(grid), dim3(64 * g.pen_sw), g.lds_pens, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.pen_sppg, g.Kmax, ngroups);
-        return (int)hipGetLastError();
-    }
     const int nwg = (dp.P + g.ppg - 1) / g.ppg;
     if (lat) hipLaunchKernelGGL(k_penalty_lat, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
     else hipLaunchKernelGGL(k_penalty, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);

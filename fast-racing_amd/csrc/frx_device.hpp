@@ -43,8 +43,6 @@ enum { SOLVER_KNOT_PCR = 0, SOLVER_BANDED_LU = 1 };
 struct LaunchGeom {
     int maxN, maxCN, Kmax, lpp, ppw;       // lpp lanes per piece; ppw = 64 / lpp pieces per WAVE (the resident round kernel's per-wave tasks)
     int pen_w, ppg;                        // stage kernel k_penalty: waves per workgroup (1..4, chosen for lane utilisation) and pieces per workgroup = 64 pen_w / lpp
-    int pen_stream = 0, pen_sw = 1, pen_sppg = 1, pen_sgrid = 0;   // k_penalty_stream (persistent workgroups, LDS-DMA double buffer): on/off, waves per workgroup, pieces per group, grid
-    size_t lds_pens = 0;
     size_t lds_fwd, lds_bwd, lds_pen;      // banded-LU kernels + penalty kernel
     int solver;                            // SOLVER_KNOT_PCR (default) | SOLVER_BANDED_LU
     int knot_threads;                      // workgroup size of the knot kernels: 64 * ceil(maxN / 64)

@@ -379,55 +379,11 @@ __global__ __launch_bounds__(256, 3) void k_penalty_lat(DevProblem dp, const dou
     penalty_body<false, true>(dp, T, C, out20, lpp, ppg, Kmax, gp0, min(ppg, dp.P - gp0), sm, threadIdx.x, true, blockDim.x);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_penalty_stream: the same integrand for grids that fill the chip several times over (hundreds of candidates).  PERSISTENT workgroups
-// walk over the groups of pieces; the next group's coefficients, durations and corridor blocks travel global -> LDS with
-// global_load_lds_dwordx4 (no VGPRs, nothing for the sample's register allocation to give up) into the second of two buffers while the
-// current group's samples are evaluated, so a wave no longer spends the first third of every task waiting for its operands (round 2:
-// VALU busy 50 % at 2.15 resident waves per SIMD; the register-prefetching form of round 2 was slower because the prefetch forced the
-// phased sample).  Rules of the LDS-DMA path (CDNA guide): one `extern __shared__` array, no ordinary global load inside the loop
-// (hipcc would wait vmcnt(0) at its use and drain the DMA), raw s_barrier with lgkmcnt-only waits, one explicit vmcnt(0) where the
-// buffer is first read.  Arithmetic, lane mapping and reduction order are penalty_body's: bit-equal results.
-// Dynamic LDS (doubles): 2 x { cS[ppg 18] | tS[ppg, even] | hS[ppg hstride] } | red[nthr 21]
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void *lds_vptr;
-typedef const __attribute__((address_space(1))) void *glb_cvptr;
-template <bool LAT>
-__global__ __launch_bounds__(256, 3) void k_penalty_stream(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
-                                                           double *__restrict__ out20, int lpp, int ppg, int Kmax, int ngroups) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int nthr = blockDim.x, lane = threadIdx.x, w64 = (lane >> 6) << 6;
-    const int hstride = (Kmax + 1) * 4;
-    const int cD = ppg * 18, tD = (ppg + 1) & ~1, hD = ppg * hstride, BUFD = cD + tD + hD;
-    double *red = sm + 2 * BUFD;
-    const int pl = lane / lpp, jl = lane - pl * lpp;
-    auto issue = [&](int grp, double *buf) {
-        const int gp0 = grp * ppg, np = min(ppg, dp.P - gp0);
-        const int nc = np * 9, nh = (np * hstride) >> 1, nt = 2 * np;          // 16-byte chunks of coefficients and corridor blocks, dwords of durations
-        const double *csrc = C + (size_t)gp0 * 18, *hsrc = dp.hblk + (size_t)gp0 * hstride;
-        const unsigned *tsrc = (const unsigned *)(T + gp0);
-        for (int q0 = 0; q0 < nc; q0 += nthr) if (q0 + lane < nc) __builtin_amdgcn_global_load_lds((glb_cvptr)(csrc + 2 * (q0 + lane)), (lds_vptr)(buf + 2 * (q0 + w64)), 16, 0, 0);
-        for (int q0 = 0; q0 < nh; q0 += nthr) if (q0 + lane < nh) __builtin_amdgcn_global_load_lds((glb_cvptr)(hsrc + 2 * (q0 + lane)), (lds_vptr)(buf + cD + tD + 2 * (q0 + w64)), 16, 0, 0);
-        for (int q0 = 0; q0 < nt; q0 += nthr) if (q0 + lane < nt) __builtin_amdgcn_global_load_lds((glb_cvptr)(tsrc + q0 + lane), (lds_vptr)((unsigned *)(buf + cD) + q0 + w64), 4, 0, 0);
-    };
-    int grp = blockIdx.x, cur = 0;
-    if (grp < ngroups) issue(grp, sm);
-    for (; grp < ngroups; grp += gridDim.x, cur ^= 1) {
-        double *buf = sm + cur * BUFD;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // this group's operands have landed (every wave's share); the previous group's reduction is over
-        const int nxt = grp + gridDim.x;
-        if (nxt < ngroups) issue(nxt, sm + (cur ^ 1) * BUFD);                         // into the buffer the previous group was read from
-        const int gp0 = grp * ppg, np = min(ppg, dp.P - gp0);
-        if (pl < np) penalty_lane_samples<LAT>(dp, buf + pl * 18, buf + cD + tD + (size_t)pl * hstride, buf[cD + pl], jl, lpp, red + lane * 21);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        penalty_reduce<false>(red, np, lpp, out20 + (size_t)gp0 * 20, lane, nthr, true);
-    }
-}
-
-// (A streaming form for large batches - 3072 one-wave workgroups walking over the wave-tasks with the next task's global reads in flight during
-// the current task's samples - was built and measured in round 2: correct, but SLOWER than one task per workgroup, 43.9 vs 40.2 us at 1024
-// candidates and 164 vs 145 us at 4096; the prefetched registers force the phased form of the sample, and load latency was not what the
-// launch was waiting for: DESIGN.md 3.2.)
+// (Streaming forms for large batches - persistent workgroups walking over the groups of pieces with the next group's operands in flight during the
+// current group's samples - were built twice and measured slower than one group per workgroup both times: with the operands prefetched into
+// registers (round 2: 43.9 vs 40.2 us at 1024 candidates; the prefetch forces the phased sample) and with global_load_lds_dwordx4 into a second
+// LDS buffer, no registers involved (round 3: bit-equal, 44.9-55.2 vs 36.3 us at 1024 candidates, 166-210 vs 134 us at 4096,
+// profiles/r03_penalty_stream.jsonl).  Operand latency is not what the launch waits for: DESIGN.md 3.2.)
 
 // ---------------------------------------------------------------------------------------------
 // k_backward: grid = B, block = 64.  Dynamic LDS: band[6N*13] | gd[6N*3] | cL[6N*3] | Tf[N] | gT[N] | gC[cN]

@@ -19,11 +19,8 @@ for kappa in (16, 48):
     for B in (32, 256, 1024, 4096 if kappa == 16 else 1024):
         rep = B // B0
         ref = None
-        for W in (1, 2, 3, 4, 11, 12, 13, 14):                 # 1..4: one group per workgroup; 11..14: persistent workgroups of 1..4 waves with LDS-DMA double buffering (k_penalty_stream)
-            stream = W > 10
-            os.environ["FRX_PENALTY_STREAM"] = "1" if stream else "0"
-            if stream: os.environ["FRX_PENALTY_STREAM_WAVES"] = str(W - 10)
-            else: os.environ["FRX_PENALTY_WAVES"] = str(W)
+        for W in (1, 2, 3, 4):
+            os.environ["FRX_PENALTY_WAVES"] = str(W)
             prob = frx.Problem(base * rep, sc.ZHANGJIAJIE, qd_intervals=kappa)
             xb = np.concatenate([xs] * rep)
             T, Cf = prob.forward(xb)
@@ -38,10 +35,9 @@ for kappa in (16, 48):
             us = e0.elapsed_time(e1) * 1e3 / reps
             o = out.cpu().numpy()
             if ref is None: ref = o
-            print(json.dumps(dict(kappa=kappa, B=B, W=W % 10, stream=stream, pen_us=round(us, 2), hbm_frac=round(prob.algorithmic_bytes() / us / 1e3 / 8000, 4),
+            print(json.dumps(dict(kappa=kappa, B=B, W=W, pen_us=round(us, 2), hbm_frac=round(prob.algorithmic_bytes() / us / 1e3 / 8000, 4),
                                   Gsamples=round(prob.samples() / us / 1e3, 2), equal_to_W1=bool(np.array_equal(o, ref)))), flush=True)
             prob.close()
             if B == 4096 and W == 1: pass
         if B >= 4096: break
 os.environ.pop("FRX_PENALTY_WAVES", None)
-for k in ("FRX_PENALTY_STREAM", "FRX_PENALTY_STREAM_WAVES"): os.environ.pop(k, None)
