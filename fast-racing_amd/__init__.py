@@ -482,7 +482,9 @@ class Problem:
         out = np.zeros(n, dtype=np.uint64)
         lib().frx_resident_profile(self.h, out.ctypes.data, n)
         self.last_stamps = out[-32:].astype(np.int64)                  # shader-clock stamps of candidate 0's forward (0..6) / adjoint (16..24) bodies
-        return out[:-32].reshape(self.B, -1, 16).astype(np.float64) / 100.0
+        body = out[:-32]
+        self.last_host_wait_hist = body[-16 * self.B:].reshape(self.B, 16).astype(np.int64)   # per leader: waits for a host command, bin k = shorter than 2^k us
+        return body[:-16 * self.B].reshape(self.B, -1, 16).astype(np.float64) / 100.0
 
     def initial_guess(self):
         x = np.zeros(self.NX)

@@ -1118,8 +1118,8 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     const bool want_prof = std::getenv("FRX_RESIDENT_PROF") != nullptr;
     if (want_prof) {
-        if ((!p->d_rprof.p || p->d_rprof.n < (size_t)B * G * 16) && p->d_rprof.alloc((size_t)B * G * 16) != hipSuccess) return 1;
-        HIP_TRY(hipMemsetAsync(p->d_rprof.p, 0, sizeof(unsigned long long) * (size_t)B * G * 16, p->stream));
+        if ((!p->d_rprof.p || p->d_rprof.n < (size_t)B * (G + 1) * 16) && p->d_rprof.alloc((size_t)B * (G + 1) * 16) != hipSuccess) return 1;
+        HIP_TRY(hipMemsetAsync(p->d_rprof.p, 0, sizeof(unsigned long long) * (size_t)B * (G + 1) * 16, p->stream));
     }
     p->rprof.clear();
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
@@ -1146,36 +1146,36 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         p->dp.stamps = p->d_stamps.p;
     }
 
-    std::vector<frx::SolverDV> sv(B);
-    std::vector<frx::DvCommand> cmd(B);
-    std::vector<unsigned long long> seq(B, 0);
-    std::vector<char> waiting(B, 0), quit_sent(B, 0);
-    std::vector<long> ncmd(B, 0);
+    // Per-candidate host state, one cache-line-aligned slot each and a CONTIGUOUS range of slots per service thread: with the state in
+    // parallel arrays and candidate b served by thread b % nsrv (round 2), every line of `seq`, `waiting`, `cmd` and the solvers was
+    // written by all threads - two service threads answered SLOWER than one (leader's wait for a command at 32 candidates: median
+    // 8-16 us with two threads, 4-8 us with one, 2-4 us at 8 candidates; profiles/r03_hostwait_probe.jsonl) and more threads bought nothing.
+    struct alignas(128) Slot { frx::SolverDV sv; frx::DvCommand cmd; unsigned long long seq = 0; long ncmd = 0; char waiting = 0, quit_sent = 0; };
+    std::vector<Slot> slot_(B);
     volatile unsigned long long *hc = p->h_rcmd.p, *hr = p->h_rres.p;
     { const char *cs = std::getenv("FRX_RESIDENT_CMD_STRIDE"); rl.cmd_stride = cs && std::atoi(cs) == 1 ? 1 : 4; }   // 4: one cache line per candidate
     const size_t cs2 = 2 * (size_t)rl.cmd_stride;
     auto post = [&](int b, int flags, int slot, int bound, double step) {
         std::memcpy((void *)(hc + cs2 * b + 1), &step, sizeof(double));
         std::atomic_thread_fence(std::memory_order_release);
-        ++seq[b];
+        ++slot_[b].seq;
         if (step == 1.0 && !(flags & 128)) flags |= 64;                                // DV_STEP_IS_ONE: lets the leader confirm a predicted command from this word alone
-        hc[cs2 * b] = (seq[b] << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
-        ncmd[b]++;
+        hc[cs2 * b] = (slot_[b].seq << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
+        slot_[b].ncmd++;
     };
     const bool tracing = std::getenv("FRX_TRACE") != nullptr;
     p->trace.clear();
-    for (int b = 0; b < B; b++) sv[b].start(p->xoff[b + 1] - p->xoff[b], pm, &cmd[b]);
+    for (int b = 0; b < B; b++) slot_[b].sv.start(p->xoff[b + 1] - p->xoff[b], pm, &slot_[b].cmd);
     std::unique_lock<std::mutex> device_slot(resident_device_lock(p->device));        // one resident grid per device at a time (see above)
     const auto t0 = clk::now();
     HIP_TRY((hipError_t)frx::launch_round(p->dp, p->geo, rl, p->stream));
     for (int b = 0; b < B; b++) {
-        if (cmd[b].flags != 0) { post(b, cmd[b].flags, cmd[b].slot, cmd[b].bound, cmd[b].step); waiting[b] = 1; }
-        else { post(b, 128, 0, 0, 0.0); quit_sent[b] = 1; }                            // invalid parameters: nothing to run (DV_QUIT)
+        if (slot_[b].cmd.flags != 0) { post(b, slot_[b].cmd.flags, slot_[b].cmd.slot, slot_[b].cmd.bound, slot_[b].cmd.step); slot_[b].waiting = 1; }
+        else { post(b, 128, 0, 0, 0.0); slot_[b].quit_sent = 1; }                            // invalid parameters: nothing to run (DV_QUIT)
     }
-    // Mailbox service: candidate b belongs to service thread b % nsrv (the caller is thread 0).  One thread keeps up with ~8 clusters
-    // (a result every ~10 us); at the headline batch the device measured 8.6 us between posting a result and seeing the next command
-    // with a single thread, 3.2 us when the thread serves one candidate.
-    int nsrv = B >= 32 ? 2 : 1;                                                       // (more threads measured no better: 1 / 4 / 8 / 32 threads -> 60.5 / 60.9 / 63.7 / 67.7 us per round)
+    // Mailbox service: thread tid serves the candidates [B tid / nsrv, B (tid + 1) / nsrv) (the caller is thread 0).  The clusters of a batch
+    // run in near lock-step, so their results arrive together and a thread's k-th mailbox waits for the k - 1 before it.
+    int nsrv = std::max(1, std::min(8, B / 4));                                       // four candidates per thread (see Slot above)
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), B));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     std::vector<double> t_host_thr(nsrv, 0.0);
@@ -1183,28 +1183,29 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     auto serve = [&](int tid) {
         int mine = 0;
         long nscan = 0;
-        for (int b = tid; b < B; b += nsrv) mine += waiting[b] ? 1 : 0;
+        const int lo = (int)((long)B * tid / nsrv), hi = (int)((long)B * (tid + 1) / nsrv);      // this thread's candidates
+        for (int b = lo; b < hi; b++) mine += slot_[b].waiting ? 1 : 0;
         auto t_last = clk::now();
         while (mine > 0 && abort_code.load(std::memory_order_relaxed) == 0) {
             bool progress = false;
             nscan++;
-            for (int b = tid; b < B; b += nsrv) {
-                if (!waiting[b]) continue;
+            for (int b = lo; b < hi; b++) {
+                if (!slot_[b].waiting) continue;
                 const unsigned long long rs = hr[8 * b + 7];
                 if (rs == ~0ull) { abort_code.store(1); break; }                        // the device gave up on this candidate
-                if (rs != seq[b]) continue;
+                if (rs != slot_[b].seq) continue;
                 std::atomic_thread_fence(std::memory_order_acquire);
                 progress = true;
                 const auto th = clk::now();
-                frx::DvCommand &c = cmd[b];
+                frx::DvCommand &c = slot_[b].cmd;
                 if (c.flags & frx::DV_EVAL) {
                     frx::DvResult r;
                     std::memcpy(&r, (const void *)(hr + 8 * b), 5 * sizeof(double));
                     if (tracing && b == 0) { const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
-                    if (sv[b].saw_nonfinite(r.f)) sv[b].give_up(frx::LBERR_ROUNDING); else sv[b].feed(r);
+                    if (slot_[b].sv.saw_nonfinite(r.f)) slot_[b].sv.give_up(frx::LBERR_ROUNDING); else slot_[b].sv.feed(r);
                 } else c.flags = 0;                                                     // a RESTORE has been executed
                 if (c.flags != 0) post(b, c.flags, c.slot, c.bound, c.step);
-                else { post(b, 128, 0, 0, 0.0); quit_sent[b] = 1; waiting[b] = 0; mine--; }   // this candidate's cluster leaves the chip
+                else { post(b, 128, 0, 0, 0.0); slot_[b].quit_sent = 1; slot_[b].waiting = 0; mine--; }   // this candidate's cluster leaves the chip
                 t_host_thr[tid] += ms_since(th);
             }
             if (progress) t_last = clk::now();
@@ -1214,7 +1215,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
                 // process's work; a device fault) will never answer: notice it from the stream instead of sitting out the whole timeout
                 if (tid == 0 && (nscan & 0x3FFF) == 0 && hipStreamQuery(p->stream) != hipErrorNotReady) {
                     bool answered = true;
-                    for (int b = 0; b < B; b++) if (waiting[b] && hr[8 * b + 7] != seq[b]) answered = false;
+                    for (int b = 0; b < B; b++) if (slot_[b].waiting && hr[8 * b + 7] != slot_[b].seq) answered = false;
                     if (!answered) abort_code.store(1);
                 }
                 __builtin_ia32_pause();
@@ -1230,14 +1231,14 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     if (std::getenv("FRX_RESIDENT_HOST_STATS")) {                                     // diagnostic: how often a service thread looks at each of its mailboxes
         const double wall_us = 1e3 * ms_since(t0);
-        for (int tid = 0; tid < nsrv; tid++) std::fprintf(stderr, "[frx] mailbox thread %d: %ld scans of %d mailboxes in %.0f us = %.3f us per scan, busy %.1f ms\n", tid, scans[tid], (B - tid + nsrv - 1) / nsrv, wall_us, wall_us / std::max(1L, scans[tid]), t_host_thr[tid]);
+        for (int tid = 0; tid < nsrv; tid++) std::fprintf(stderr, "[frx] mailbox thread %d: %ld scans of %d mailboxes in %.0f us = %.3f us per scan, busy %.1f ms\n", tid, scans[tid], (int)((long)B * (tid + 1) / nsrv) - (int)((long)B * tid / nsrv), wall_us, wall_us / std::max(1L, scans[tid]), t_host_thr[tid]);
     }
     int rc = FRX_OK;
     double t_host = 0.0;
     for (double v : t_host_thr) t_host = std::max(t_host, v);
     if (abort_code.load() == 1) rc = 1;
     else if (abort_code.load() == 2) rc = fail(FRX_ERR_TIMEOUT, "resident round kernel: no result within FRX_ROUND_TIMEOUT_MS");
-    for (int b = 0; b < B; b++) if (!quit_sent[b]) post(b, 128, 0, 0, 0.0);
+    for (int b = 0; b < B; b++) if (!slot_[b].quit_sent) post(b, 128, 0, 0, 0.0);
     {   // bounded drain: the kernel's own spins expire after the same timeout
         const auto tw = clk::now();
         for (;;) {
@@ -1259,20 +1260,20 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (rc < 0) return rc;
     if (rc != FRX_OK || st[1] != 0) return 1;
     long rounds = 0;
-    for (int b = 0; b < B; b++) rounds = std::max(rounds, ncmd[b]);
+    for (int b = 0; b < B; b++) rounds = std::max(rounds, slot_[b].ncmd);
     p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
     if (want_prof) {
-        p->rprof.resize((size_t)B * G * 16 + 32);                                      // the last 32 words: the bodies' cycle stamps
-        HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)B * G * 16, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)B * G * 16, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+        p->rprof.resize((size_t)B * (G + 1) * 16 + 32);                                // [B][G][16] segment sums, [B][16] host-wait histogram; the last 32 words: the bodies' cycle stamps
+        HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)B * (G + 1) * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)B * (G + 1) * 16, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     }
     for (int b = 0; b < B; b++) {
-        status[b] = sv[b].status();
+        status[b] = slot_[b].sv.status();
         if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) p->resident_failed++;
-        if (iters) iters[b] = sv[b].iterations();
-        if (evals) evals[b] = sv[b].evaluations();
-        if (objective) objective[b] = sv[b].value();
+        if (iters) iters[b] = slot_[b].sv.iterations();
+        if (evals) evals[b] = slot_[b].sv.evaluations();
+        if (objective) objective[b] = slot_[b].sv.value();
     }
     p->resident_used = G;
     return FRX_OK;

@@ -106,7 +106,7 @@ struct RoundArgs {
     int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
     double *dbg;                             // optional direction log (frx_debug.h, frx_debug_direction_log): [B] record counts, then per candidate c < dbg_cands
     int dbg_cap, dbg_cands;                  // dbg_cap records of 4 NXP + 2 doubles: s, y, g (the pair and the gradient the direction was built from), d, slot, pair count
-    rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*
+    rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*; then [B][16]: histogram of the leaders' waits for a host command
 };
 // profile segments (thread 0 of every workgroup accumulates the time since its previous checkpoint into one of these)
 enum { RK_P_WAIT_HOST = 0, RK_P_VECTORS = 1, RK_P_FORWARD = 2, RK_P_WAIT_PHASE = 3, RK_P_PASS_A = 4, RK_P_WAIT_PART = 5, RK_P_DENSE_IN = 6, RK_P_SOLVE = 7,
@@ -264,13 +264,19 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             kind = PH_ADV; lstage = 1;
         } else if (lstage == 0) {
             if (t == 0) {
-                const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+                const rk_u64 tw0 = wall_clock64(), dl = tw0 + a.timeout_ticks;
                 rk_u64 w = 0, stp = 0;
                 bool ok = true;
                 for (unsigned spins = 0;; spins++) {
                     rk_load_cmd(a.h_cmd + c * a.cmd_stride, w, stp);
                     if ((w >> 32) == hseq + 1) break;
                     if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
+                }
+                if (PROF && a.prof) {                                       // histogram of the waits for a command: bin k = shorter than 2^k us (behind the [B][G][16] segment sums)
+                    const unsigned us = (unsigned)((wall_clock64() - tw0) / 100);
+                    int bin = 0;
+                    while (bin < 15 && (1u << bin) <= us) bin++;
+                    a.prof[(size_t)a.B * a.G * 16 + (size_t)c * 16 + bin] += 1;
                 }
                 if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
                 ctlU[1] = (unsigned)w;

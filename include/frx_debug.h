@@ -18,7 +18,9 @@ extern "C" {
  * {flags, step, f, g.d, gp.d_new, x.x, g.g}; returns the number of rows and copies up to cap_rows of them (7 doubles each). */
 int frx_debug_trace(const frx_problem *p, double *out, int cap_rows);
 /* Diagnostic: with FRX_RESIDENT_PROF set, the resident kernel runs its instrumented instantiation and leaves 16 counters of 100 MHz
- * ticks per workgroup ([B][G][16], segments RK_P_* of csrc/frx_round_kernel.hpp); returns the word count, copies up to cap_words. */
+ * ticks per workgroup ([B][G][16], segments RK_P_* of csrc/frx_round_kernel.hpp), then per leader a 16-bin histogram of its waits for a
+ * host command ([B][16]: bin k = shorter than 2^k us), then 32 shader-clock stamps of candidate 0's last forward / adjoint bodies;
+ * returns the word count, copies up to cap_words. */
 int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_words);
 
 /* Direction log of the resident round kernel (csrc/frx_round_kernel.hpp).  The kernel computes the L-BFGS direction in the compact

@@ -24,6 +24,7 @@ out = {"B": B, "N": N, "kappa": kappa, "G": G, "rounds_cand0": rounds, "iters_ca
 for name, wg in (("leader", 0), ("member1", 1), ("dense", G - 1)):
     out[name] = {SEG[i]: round(float(pr[0, wg, i]) / rounds, 2) for i in range(16) if pr[0, wg, i] > 0}
     out[name]["total"] = round(float(pr[0, wg].sum()) / rounds, 2)
+out["host_wait_histogram_all_leaders (bin k: < 2^k us)"] = [int(v) for v in prob.last_host_wait_hist.sum(axis=0)]
 st = prob.last_stamps
 # cycle stamps of candidate 0's last evaluation, relative to the body's entry (wave-specialised bodies of <= 64 pieces):
 #   forward: matrix wave (thread 0) = staged, T ready, all steps done, left; axis wave 1 (thread 64) = waypoint map done, met the matrix
