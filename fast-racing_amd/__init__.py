@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
 # diagnostics, include/frx_debug.h: not part of the drop-in boundary
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
-    "frx_debug_resident_counts", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables",
+    "frx_debug_resident_counts", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables",
 ]
 
 _lib = None
@@ -110,6 +110,7 @@ def lib():
         L.frx_debug_direction_log_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.frx_debug_set_resident_retry.argtypes = [C.c_void_p, C.c_int]
         L.frx_debug_resident_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.frx_debug_resident_predictions.argtypes = [C.c_void_p, C.c_void_p]
         L.frx_dilate_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
         L.frx_eval_stage_times.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
@@ -468,6 +469,12 @@ class Problem:
         """Diagnostic: re-run candidates that fail on the resident kernel on the per-stage rounds (round-2 behaviour; default off)."""
         _check(lib().frx_debug_set_resident_retry(self.h, 1 if enable else 0))
 
+    def resident_predictions(self):
+        """(rounds on a predicted ADVANCE, rounds on a predicted trial step, predictions redone) of the last resident plan, all candidates."""
+        out = np.zeros(3, dtype=np.uint64)
+        _check(lib().frx_debug_resident_predictions(self.h, out.ctypes.data))
+        return tuple(int(v) for v in out)
+
     def resident_counts(self):
         """(failed, retried) candidates of the last resident plan."""
         a = C.c_int(); b = C.c_int()
@@ -525,7 +532,7 @@ class Problem:
         resident, dev_status = self.optimize_path()
         return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
                     ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status,
-                    resident_failed=self.resident_counts()[0], resident_retried=self.resident_counts()[1])
+                    resident_failed=self.resident_counts()[0], resident_retried=self.resident_counts()[1], predictions=self.resident_predictions())
 
     def stage_times(self, x, reps: int = 100):
         """Average microseconds of the forward, penalty and adjoint kernels at x (HIP events inside the library)."""

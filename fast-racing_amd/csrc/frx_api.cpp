@@ -222,6 +222,7 @@ struct frx_problem {
     int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident)
     int resident_retry = 0;                                 // 1 = re-run candidates that fail on the resident kernel on the per-stage rounds (diagnostic, frx_debug_set_resident_retry); the reference takes no second chance and neither does the default
     int resident_retried = 0;                               // candidates of the last plan re-run on the per-stage rounds after an L-BFGS error
+    unsigned long long spec_counts[4] = {0, 0, 0, 0};       // last resident plan, summed over candidates: rounds started on a predicted ADVANCE / trial step, predictions redone, reserved
     int resident_failed = 0;                                // candidates of the last resident plan that ended with an L-BFGS error other than the iteration limit
     int resident_used = 0;                                  // diagnostics: 1 = the last frx_optimize ran on the resident kernel
     unsigned resident_status = 0;                           // device-side error code of the last resident launch (RK_ERR_*)
@@ -1100,7 +1101,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
         if ((e = p->d_pubsyg.alloc((size_t)B * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)B * G * 512)) != hipSuccess ||
             (e = p->d_upub.alloc((size_t)B * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)B * NXP)) != hipSuccess ||
-            (e = p->d_rwords.alloc((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
+            (e = p->d_rwords.alloc((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G + 4 * (size_t)B)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
@@ -1124,7 +1125,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     p->rprof.clear();
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
-    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G), p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G + 4 * (size_t)B), p->stream));
     HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)B * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
     std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * B);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
@@ -1137,7 +1138,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
-    rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_max_linesearch = pm.max_linesearch;
+    rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;
     { const char *sp = std::getenv("FRX_RESIDENT_SPECULATE"); rl.speculate = !(sp && sp[0] == '0') && pm.min_step <= 1.0 && 1.0 <= pm.max_step; }   // the predicted command carries step 1 (lbfgs.hpp:1418)
     struct StampGuard { frx_problem *q; ~StampGuard() { q->dp.stamps = nullptr; } } stamp_guard{p};
     if (want_prof) {                                                                  // phase stamps of candidate 0's forward / adjoint bodies (last evaluation)
@@ -1160,6 +1161,10 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         std::atomic_thread_fence(std::memory_order_release);
         ++slot_[b].seq;
         if (step == 1.0 && !(flags & 128)) flags |= 64;                                // DV_STEP_IS_ONE: lets the leader confirm a predicted command from this word alone
+        if ((flags & frx::DV_TRIAL) && !(flags & frx::DV_ADVANCE)) {                   // a trial inside a search: slot and pair count mean nothing here, a fold of the step's bits rides in their place
+            const unsigned h = frx::dv_step_hash(step);
+            slot = (int)(h & 0xFFFu); bound = (int)(h >> 12);
+        }
         hc[cs2 * b] = (slot_[b].seq << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
         slot_[b].ncmd++;
     };
@@ -1178,6 +1183,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     int nsrv = std::max(1, std::min(8, B / 4));                                       // four candidates per thread (see Slot above)
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), B));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
+    const int scan_pause = [] { const char *e = std::getenv("FRX_RESIDENT_SCAN_PAUSE"); return e ? std::max(0, std::atoi(e)) : 0; }();   // extra pauses between two scans of a thread's mailboxes (experiments)
     std::vector<double> t_host_thr(nsrv, 0.0);
     std::vector<long> scans(nsrv, 0);
     auto serve = [&](int tid) {
@@ -1218,7 +1224,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
                     for (int b = 0; b < B; b++) if (slot_[b].waiting && hr[8 * b + 7] != slot_[b].seq) answered = false;
                     if (!answered) abort_code.store(1);
                 }
-                __builtin_ia32_pause();
+                for (int q = 0; q <= scan_pause; q++) __builtin_ia32_pause();
             }
         }
         scans[tid] = nscan;
@@ -1253,6 +1259,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     unsigned st[2] = {0, 0};
     HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * B, sizeof(st), hipMemcpyDeviceToHost));
     p->resident_status = st[1];
+    {
+        std::vector<unsigned> sc(4 * (size_t)B, 0u);
+        HIP_TRY(hipMemcpy(sc.data(), p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G, sizeof(unsigned) * sc.size(), hipMemcpyDeviceToHost));
+        for (int q = 0; q < 4; q++) { p->spec_counts[q] = 0; for (int b = 0; b < B; b++) p->spec_counts[q] += sc[4 * (size_t)b + q]; }
+    }
     if (want_dbg) {
         p->dirlog.resize(log_doubles);
         HIP_TRY(hipMemcpy(p->dirlog.data(), p->d_rdbg.p, sizeof(double) * log_doubles, hipMemcpyDeviceToHost));
@@ -1428,6 +1439,11 @@ int frx_debug_direction_log_read(const frx_problem *p, int cand, double *out, in
 int frx_debug_set_resident_retry(frx_problem *p, int enable) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
     p->resident_retry = enable ? 1 : 0;
+    return FRX_OK;
+}
+int frx_debug_resident_predictions(const frx_problem *p, unsigned long long *out3) {
+    if (!p || !out3) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    for (int q = 0; q < 3; q++) out3[q] = p->spec_counts[q];
     return FRX_OK;
 }
 int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried) {

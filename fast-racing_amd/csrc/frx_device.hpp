@@ -85,13 +85,13 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 struct RoundLaunch {
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20;              // leader vectors and stage buffers (the handle's own)
     double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([B][3 NXP + 2], [B][G][512], [B][258], [B][NXP])
-    unsigned *words;                                               // [ROUND_WORDS_PER_CAND B + 2 + B G]: a 512-byte block per candidate (phase, cntA, uflag, cntL in separate lines), then census, status, XCC ids
+    unsigned *words;                                               // [ROUND_WORDS_PER_CAND B + 2 + B G + 4 B]: a 512-byte block per candidate (phase, cntA, uflag, cntL in separate lines), then census, status, XCC ids, prediction counters
     void *h_cmd, *h_res;                                           // mapped host mailboxes, [B] x 16 B and [B] x 64 B
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
     int B, G, m, E, NXP;
     int dbg_cap = 0, dbg_cands = 0;                                 // direction log (dbg): [B] counts + dbg_cands x dbg_cap records of 4 NXP + 2 doubles
-    double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
+    double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20, ls_xtol = 1e-16;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;
     int cmd_stride = 4;                                            // h_cmd: candidate b's 16-byte command at 16 * cmd_stride * b
 };

@@ -28,6 +28,17 @@
 
 #include "../../include/frx.h"
 
+// The scalar line-search logic below also runs ON THE DEVICE (the leader of the resident round kernel predicts the host's next command,
+// frx_round_kernel.hpp): same source for both compilers, and no floating-point contraction in either - the host side and the CPU oracle are
+// built with -ffp-contract=off (like the reference, whose own build has no FMA: -O3 without -march, CMakeLists.txt:7), hipcc is told per function.
+#if defined(__HIPCC__)
+#define FRX_LS_HD __host__ __device__ __forceinline__
+#define FRX_LS_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define FRX_LS_HD inline
+#define FRX_LS_NO_CONTRACT
+#endif
+
 namespace frx {
 
 enum {   // numeric values of lbfgs.hpp:149-206
@@ -66,12 +77,19 @@ inline int lbfgs_check(int n, const frx_lbfgs_params &p) {   // lbfgs.hpp:1143-1
 //           r == PENDING: another trial at step();  otherwise r = ls (>0 evaluations, <0 error)
 //    same with bt_begin / bt_feed.
 // ---------------------------------------------------------------------------------------------
+// 24-bit fold of a step's bit pattern: rides in the slot / pair-count fields of a resident-kernel command that carries TRIAL without ADVANCE
+// (those fields are unused there), so that the leader can confirm a predicted trial step from the command WORD alone (frx_round_kernel.hpp)
+FRX_LS_HD unsigned dv_step_hash(double step) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, step);
+    return (unsigned)((b ^ (b >> 24) ^ (b >> 48)) & 0xFFFFFFull);
+}
+
 class LineSearch {
 public:
     static constexpr int PENDING = 1 << 30;
-    double step() const { return stp; }
+    FRX_LS_HD double step() const { return stp; }
 
-    int mt_begin(const frx_lbfgs_params &pm, double step0, double f0, double dginit0) {     // lbfgs.hpp:743-788
+    FRX_LS_HD int mt_begin(const frx_lbfgs_params &pm, double step0, double f0, double dginit0) { FRX_LS_NO_CONTRACT     // lbfgs.hpp:743-788
         count = 0; brackt = 0; stage1 = 1; uinfo = 0;
         stp = step0;
         if (stp <= 0.) return LBERR_INVALIDPARAMETERS;
@@ -87,7 +105,7 @@ public:
         mt_propose(pm);
         return 0;
     }
-    int mt_feed(const frx_lbfgs_params &pm, double f, double dg) {                          // lbfgs.hpp:829-935
+    FRX_LS_HD int mt_feed(const frx_lbfgs_params &pm, double f, double dg) { FRX_LS_NO_CONTRACT                          // lbfgs.hpp:829-935
         const double ftest1 = finit + stp * dgtest;
         ++count;
         if ((std::isinf(f) || std::isnan(f)) || (brackt && ((stp <= stmin || stmax <= stp) || uinfo != 0))) return LBERR_ROUNDING;
@@ -98,18 +116,17 @@ public:
         if (f <= ftest1 && std::fabs(dg) <= pm.s_curv_coeff * (-dginit)) return count;
         if (stage1 && f <= ftest1 && (pm.f_dec_coeff <= pm.s_curv_coeff ? pm.f_dec_coeff : pm.s_curv_coeff) * dginit <= dg)
             stage1 = 0;
-        if (stage1 && ftest1 < f && f <= fxl) {
-            double fm = f - stp * dgtest, fxm = fxl - stx * dgtest, fym = fy - sty * dgtest;
-            double dgm = dg - dgtest, dgxm = dgx - dgtest, dgym = dgy - dgtest;
-            uinfo = update_trial(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, stmin, stmax, brackt);
-            fxl = fxm + stx * dgtest;
-            fy = fym + sty * dgtest;
-            dgx = dgxm + dgtest;
-            dgy = dgym + dgtest;
-        } else {
-            double ff = f, dgg = dg;
-            uinfo = update_trial(stx, fxl, dgx, sty, fy, dgy, stp, ff, dgg, stmin, stmax, brackt);
-        }
+        // (one call of update_trial on LOCAL copies for both branches: with the members passed by reference from two call sites the device
+        // compiler selected between member addresses and put the whole object into scratch memory)
+        const bool modified = stage1 && ftest1 < f && f <= fxl;            // the modified function psi of lbfgs.hpp:870-905
+        double xs = stx, ys = sty, tt = stp, fxs, dxs, fys, dys, ft, dt;
+        int br = brackt;
+        if (modified) { ft = f - stp * dgtest; fxs = fxl - stx * dgtest; fys = fy - sty * dgtest; dt = dg - dgtest; dxs = dgx - dgtest; dys = dgy - dgtest; }
+        else { ft = f; fxs = fxl; fys = fy; dt = dg; dxs = dgx; dys = dgy; }
+        uinfo = update_trial(xs, fxs, dxs, ys, fys, dys, tt, ft, dt, stmin, stmax, br);
+        stx = xs; sty = ys; stp = tt; brackt = br;
+        if (modified) { fxl = fxs + stx * dgtest; fy = fys + sty * dgtest; dgx = dxs + dgtest; dgy = dys + dgtest; }
+        else { fxl = fxs; fy = fys; dgx = dxs; dgy = dys; }
         if (brackt) {
             if (0.66 * prev_width <= std::fabs(sty - stx)) stp = stx + 0.5 * (sty - stx);
             prev_width = width;
@@ -119,7 +136,7 @@ public:
         return PENDING;
     }
 
-    int bt_begin(double step0, double f0, double dginit0, const frx_lbfgs_params &pm) {      // lbfgs.hpp:954-974
+    FRX_LS_HD int bt_begin(double step0, double f0, double dginit0, const frx_lbfgs_params &pm) { FRX_LS_NO_CONTRACT      // lbfgs.hpp:954-974
         count = 0;
         stp = step0;
         if (stp <= 0.) return LBERR_INVALIDPARAMETERS;
@@ -130,7 +147,7 @@ public:
         return 0;
     }
     // dg is only consulted when the sufficient-decrease test passes, like the reference (lbfgs.hpp:986-1010)
-    int bt_feed(const frx_lbfgs_params &pm, double f, double dg) {
+    FRX_LS_HD int bt_feed(const frx_lbfgs_params &pm, double f, double dg) { FRX_LS_NO_CONTRACT
         const double dec = 0.5, inc = 2.1;
         double wd;
         ++count;
@@ -146,14 +163,14 @@ public:
         stp *= wd;
         return PENDING;
     }
-    bool bt_needs_dg(double f) const { return !(f > finit + stp * dgtest); }
+    FRX_LS_HD bool bt_needs_dg(double f) const { FRX_LS_NO_CONTRACT return !(f > finit + stp * dgtest); }
 
 private:
     int count = 0, brackt = 0, stage1 = 0, uinfo = 0;
     double stp = 0, stx = 0, fxl = 0, dgx = 0, sty = 0, fy = 0, dgy = 0, finit = 0, dginit = 0, dgtest = 0, width = 0, prev_width = 0,
            stmin = 0, stmax = 0;
 
-    void mt_propose(const frx_lbfgs_params &pm) {             // loop head up to the evaluation, lbfgs.hpp:790-826
+    FRX_LS_HD void mt_propose(const frx_lbfgs_params &pm) { FRX_LS_NO_CONTRACT             // loop head up to the evaluation, lbfgs.hpp:790-826
         if (brackt) { stmin = stx <= sty ? stx : sty; stmax = stx >= sty ? stx : sty; }
         else        { stmin = stx; stmax = stp + 4.0 * (stp - stx); }
         if (stp < pm.min_step) stp = pm.min_step;
@@ -164,7 +181,7 @@ private:
     }
 
     // ---- interpolants, lbfgs.hpp:318-406 ----
-    static double cubic_min(double u, double fu, double du, double v, double fv, double dv) {
+    FRX_LS_HD static double cubic_min(double u, double fu, double du, double v, double fv, double dv) { FRX_LS_NO_CONTRACT
         const double dd = v - u;
         const double theta = (fu - fv) * 3 / dd + du + dv;
         double p = std::fabs(theta), q = std::fabs(du), r = std::fabs(dv);
@@ -178,7 +195,7 @@ private:
         r = p / q;
         return u + r * dd;
     }
-    static double cubic_min_bounded(double u, double fu, double du, double v, double fv, double dv, double xmin, double xmax) {
+    FRX_LS_HD static double cubic_min_bounded(double u, double fu, double du, double v, double fv, double dv, double xmin, double xmax) { FRX_LS_NO_CONTRACT
         const double dd = v - u;
         const double theta = (fu - fv) * 3 / dd + du + dv;
         double p = std::fabs(theta), q = std::fabs(du), r = std::fabs(dv);
@@ -194,17 +211,17 @@ private:
         if (r < 0. && gamm != 0.) return v - r * dd;
         return a < 0 ? xmax : xmin;
     }
-    static double quad_min(double u, double fu, double du, double v, double fv) {
+    FRX_LS_HD static double quad_min(double u, double fu, double du, double v, double fv) { FRX_LS_NO_CONTRACT
         const double a = v - u;
         return u + du / ((fu - fv) / a + du) / 2 * a;
     }
-    static double secant_min(double u, double du, double v, double dv) {
+    FRX_LS_HD static double secant_min(double u, double du, double v, double dv) { FRX_LS_NO_CONTRACT
         const double a = u - v;
         return v + dv / (dv - du) * a;
     }
     // update_trial_interval, lbfgs.hpp:520-728
-    static int update_trial(double &xs, double &fxs, double &dxs, double &ys, double &fys, double &dys,
-                            double &t, double &ft, double &dt, double tmin, double tmax, int &br) {
+    FRX_LS_HD static int update_trial(double &xs, double &fxs, double &dxs, double &ys, double &fys, double &dys,
+                            double &t, double &ft, double &dt, double tmin, double tmax, int &br) { FRX_LS_NO_CONTRACT
         int bound;
         const int dsign = dt * (dxs / std::fabs(dxs)) < 0.;
         double mc, mq, newt;
@@ -235,10 +252,11 @@ private:
             else if (xs < t) newt = tmax;
             else             newt = tmin;
         }
-        if (fxs < ft) { ys = t; fys = ft; dys = dt; }
-        else {
-            if (dsign) { ys = xs; fys = fxs; dys = dxs; }
-            xs = t; fxs = ft; dxs = dt;
+        {   // interval update (lbfgs.hpp:690-712) as selections: the branchy form made the device compiler index the six values in scratch memory
+            const bool up = fxs < ft, sw = !up && dsign;
+            const double nys = up ? t : (sw ? xs : ys), nfys = up ? ft : (sw ? fxs : fys), ndys = up ? dt : (sw ? dxs : dys);
+            const double nxs = up ? xs : t, nfxs = up ? fxs : ft, ndxs = up ? dxs : dt;
+            xs = nxs; fxs = nfxs; dxs = ndxs; ys = nys; fys = nfys; dys = ndys;
         }
         if (tmax < newt) newt = tmax;
         if (newt < tmin) newt = tmin;

@@ -98,7 +98,8 @@ struct RoundArgs {
     RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
     rk_u64 census_ticks;                     // bound of the start-up census (all workgroups resident)
-    double ls_ftol, ls_gtol, ls_min_step, ls_max_step;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
+    double ls_ftol, ls_gtol, ls_min_step, ls_max_step, ls_xtol;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
+    unsigned *spec;                                      // [B][4] counters: rounds started on a predicted ADVANCE / on a predicted trial step, predictions the host's command did not confirm (redone), reserved
     int ls_max_linesearch, speculate;
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
@@ -246,23 +247,34 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     // host actually sent before the next result is posted.  The host keeps every decision: if it stopped instead (convergence,
     // iteration limit) the leader restores the accepted point and leaves; any other disagreement ends the launch with
     // RK_ERR_SPECULATION and the plan is re-run on the per-stage path.
-    bool unconfirmed = false, spec_ready = false;
+    bool unconfirmed = false, spec_ready = false, have_cmd = false, ls_ok = false;
+    int pred_kind = 0, run_kind = 0;                                        // 1 = ADVANCE predicted, 2 = another trial of the running search predicted (kind of the NEXT / of the RUNNING round)
+    double pred_step = 1.0;
+    LineSearch ls;                                                          // the host's More-Thuente state machine (frx_lbfgs.hpp), run in step with it on the same numbers
+    frx_lbfgs_params lpm = {};                                              // only the line-search constants are consulted on the device
+    lpm.f_dec_coeff = a.ls_ftol; lpm.s_curv_coeff = a.ls_gtol; lpm.min_step = a.ls_min_step; lpm.max_step = a.ls_max_step; lpm.xtol = a.ls_xtol; lpm.max_linesearch = a.ls_max_linesearch;
     rk_u64 pred_word = 0, seq_pending = 0;
     double f_acc = 0.0, gg0 = 0.0;
     int last_slot = -1, last_bound = 0;
     for (;;) {
         int kind = 0;
         if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
-            spec_ready = false; unconfirmed = true;
+            spec_ready = false; unconfirmed = true; run_kind = pred_kind;
             hseq++;
-            flags = (int)(pred_word & 0xFFu) & ~(int)DV_STEP_IS_ONE; jnew = (int)((pred_word >> 8) & 0xFFFu); bound = (int)((pred_word >> 20) & 0xFFFu);
-            step = 1.0;
-            f_acc = ctlD[0];
-            last_slot = jnew; last_bound = bound;
-            accept_step();                                                  // same as the DV_ADVANCE branch below
-            if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
-            kind = PH_ADV; lstage = 1;
+            flags = (int)(pred_word & 0xFFu) & ~(int)DV_STEP_IS_ONE;
+            if (t == 0 && a.spec) a.spec[c * 4 + (pred_kind == 1 ? 0 : 1)] += 1u;
+            if (pred_kind == 1) {
+                jnew = (int)((pred_word >> 8) & 0xFFFu); bound = (int)((pred_word >> 20) & 0xFFFu);
+                step = 1.0;
+                f_acc = ctlD[0];
+                last_slot = jnew; last_bound = bound;
+                accept_step();                                              // same as the DV_ADVANCE branch below
+                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
+                kind = PH_ADV;
+            } else step = pred_step;                                        // another trial of the running search: straight to x = xp + step d
+            lstage = 1;
         } else if (lstage == 0) {
+            if (!have_cmd) {
             if (t == 0) {
                 const rk_u64 tw0 = wall_clock64(), dl = tw0 + a.timeout_ticks;
                 rk_u64 w = 0, stp = 0;
@@ -283,11 +295,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 if (ok) ctlD[5] = __longlong_as_double((long long)stp);
             }
             __syncthreads();
+            hseq++;
+            }
+            have_cmd = false;                                               // (a command the confirmation step fetched after a wrong prediction is decoded like any other)
             RK_PROF(RK_P_WAIT_HOST);
             const unsigned w = ctlU[1];
             flags = (int)(w & 0xFFu) & ~(int)DV_STEP_IS_ONE; jnew = (int)((w >> 8) & 0xFFFu); bound = (int)((w >> 20) & 0xFFFu);
             step = ctlD[5];
-            hseq++;
             __syncthreads();
             if (flags & DV_QUIT) { kind = PH_QUIT; flush(x, g); }
             else if (flags & DV_RESTORE) {                                  // lbfgs.hpp:1287-1288; no evaluation follows
@@ -412,16 +426,35 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                         w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
                         if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                     }
-                    unsigned verdict = 0u;                                   // 0 confirmed, 1 host stopped (QUIT), 2 anything else
+                    // 0 confirmed; 1 the host stopped (QUIT): the accepted point is the result; 2 a disagreement that cannot be undone (the history has
+                    // moved on, or the accepted point was overwritten): the launch ends and the plan is re-run per stage; 3 a predicted TRIAL step the
+                    // host did not send - it sent another command of the same search (a different step, RESTORE): the evaluation is thrown away and the
+                    // host's command executed (xp, gp, d are untouched by a trial)
+                    unsigned verdict = 0u;
                     if (!ok) { rk_fail(a, RK_ERR_HOST); verdict = 2u; }
-                    else if ((unsigned)w != (unsigned)pred_word) verdict = ((unsigned)w & (unsigned)DV_QUIT) ? 1u : 2u;
+                    else if ((unsigned)w != (unsigned)pred_word) {
+                        if ((unsigned)w & (unsigned)DV_QUIT) verdict = 1u;
+                        else verdict = (run_kind == 2 && !((unsigned)w & (unsigned)(DV_ADVANCE | DV_INIT))) ? 3u : 2u;
+                    }
                     if (verdict == 2u) { rk_fail(a, RK_ERR_SPECULATION); __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
+                    if (verdict == 3u) {                                     // the whole command, word and step in one 16-byte read
+                        rk_u64 w2 = 0, stp = 0;
+                        rk_load_cmd(a.h_cmd + c * a.cmd_stride, w2, stp);
+                        ctlU[2] = (unsigned)w2; ctlD[5] = __longlong_as_double((long long)stp);
+                        if (a.spec) a.spec[c * 4 + 2] += 1u;
+                    }
                     ctlU[1] = verdict;
                 }
                 __syncthreads();
                 const unsigned verdict = ctlU[1];
                 __syncthreads();
                 unconfirmed = false;
+                if (verdict == 3u) {
+                    if (t == 0) ctlU[1] = ctlU[2];                          // where the command decoder looks
+                    have_cmd = true; ls_ok = false; lstage = 0;             // no more predictions in this search: the device's copy of the line search has left the host's
+                    __syncthreads();
+                    continue;
+                }
                 if (verdict != 0u) {
                     if (verdict == 1u) flush(xp, gp); else flush(x, g);                     // host stopped: the accepted point is the result
                     rk_drain_and_meet();
@@ -430,16 +463,34 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     break;
                 }
             }
-            if (a.speculate && (flags & (DV_ADVANCE | DV_INIT))) {          // first trial of a search: predict the host's verdict (lbfgs.hpp:829-850)
+            // Prediction of the host's next command.  The host feeds (f, g.d) of this trial to its More-Thuente search (SolverDV::feed ->
+            // LineSearch::mt_begin / mt_feed, lbfgs.hpp:743-935) and answers with either ADVANCE | TRIAL | EVAL, next slot, step 1 (the trial is
+            // accepted: lbfgs.hpp:1418) or TRIAL | EVAL with the search's next step.  Every thread of the leader runs the SAME search object on the
+            // same numbers (same source, no contraction on either side), so the answer is known here ~10 us before it could arrive over PCIe
+            // (leader's wait for a command at 32 candidates: 8-16 us, profiles/r03_hostwait_probe.jsonl).  The leader starts on it at once and
+            // checks it against the host's command word before the NEXT result is posted; the host keeps every decision.  Round 2 predicted only
+            // the acceptance of a search's first trial.
+            pred_kind = 0;
+            if (a.speculate) {
                 const double fv = ctlD[0], dgv = ctlD[1];
-                const double dgi = (flags & DV_ADVANCE) ? ctlD[4] : -gg0;  // slope at the start of the search (lbfgs.hpp:756; d = -g after INIT)
-                const double dgtest = a.ls_ftol * dgi, ftest1 = f_acc + step * dgtest;
-                const bool accept = !(isnan(fv) || isinf(fv)) && !(0.0 < dgi) && step != a.ls_max_step && step != a.ls_min_step && a.ls_max_linesearch > 1 &&
-                                    fv <= ftest1 && fabs(dgv) <= a.ls_gtol * (-dgi);
-                if (accept) {
-                    const int nslot = last_slot < 0 ? 0 : (last_slot + 1 == v.m ? 0 : last_slot + 1), nbound = min(v.m, last_bound + 1);
-                    pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL | DV_STEP_IS_ONE);
-                    spec_ready = true;
+                if (flags & (DV_ADVANCE | DV_INIT)) {                       // first trial of a new search: the host begins it with the slope at its start (lbfgs.hpp:756; d = -g after INIT)
+                    const double dgi = (flags & DV_ADVANCE) ? ctlD[4] : -gg0;
+                    ls_ok = step != a.ls_min_step && step != a.ls_max_step && ls.mt_begin(lpm, step, f_acc, dgi) == 0;
+                }
+                if (ls_ok) {
+                    const int rc = ls.mt_feed(lpm, fv, dgv);
+                    if (rc == LineSearch::PENDING) {
+                        pred_step = ls.step();
+                        pred_word = ((rk_u64)dv_step_hash(pred_step) << 8) | (rk_u64)(DV_EVAL | DV_TRIAL | (pred_step == 1.0 ? DV_STEP_IS_ONE : 0));
+                        pred_kind = 2; spec_ready = true;
+                    } else {
+                        ls_ok = false;                                      // accepted (the next search begins with the next ADVANCE) or failed (the host falls back to backtracking: its commands are awaited)
+                        if (rc > 0) {
+                            const int nslot = last_slot < 0 ? 0 : (last_slot + 1 == v.m ? 0 : last_slot + 1), nbound = min(v.m, last_bound + 1);
+                            pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL | DV_STEP_IS_ONE);
+                            pred_kind = 1; spec_ready = true;
+                        }
+                    }
                 }
             }
             if (spec_ready) seq_pending = hseq;                             // nobody waits for the host's answer to this one: posted behind the next phase word (above)

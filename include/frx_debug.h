@@ -38,6 +38,11 @@ int frx_debug_direction_log_read(const frx_problem *p, int cand, double *out, in
  * other than the iteration limit, and how many of them were re-run. */
 int frx_debug_set_resident_retry(frx_problem *p, int enable);
 int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried);
+/* The leader of a cluster runs the host's line-search state machine in step with it and starts on the command it expects (ADVANCE after an
+ * accepted trial, or the search's next trial step) before the host's answer arrives; every prediction is checked against the command the
+ * host really sent.  out3 = {rounds started on a predicted ADVANCE, rounds started on a predicted trial step, predictions the host's command
+ * did not confirm and that were redone} of the last resident plan, summed over the candidates. */
+int frx_debug_resident_predictions(const frx_problem *p, unsigned long long *out3);
 
 /* Diagnostic (bench): average microseconds of each stage kernel of an evaluation at x - {forward, penalty, adjoint} - over `reps`
  * back-to-back launches of one kernel at a time, HIP events on the handle's stream. */
