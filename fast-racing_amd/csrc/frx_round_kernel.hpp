@@ -480,9 +480,11 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 if (ls_ok) {
                     const int rc = ls.mt_feed(lpm, fv, dgv);
                     if (rc == LineSearch::PENDING) {
+                        if (a.speculate >= 2) {                             // (level 1 follows the search without starting on its next step: see optimize_resident)
                         pred_step = ls.step();
                         pred_word = ((rk_u64)dv_step_hash(pred_step) << 8) | (rk_u64)(DV_EVAL | DV_TRIAL | (pred_step == 1.0 ? DV_STEP_IS_ONE : 0));
                         pred_kind = 2; spec_ready = true;
+                        }
                     } else {
                         ls_ok = false;                                      // accepted (the next search begins with the next ADVANCE) or failed (the host falls back to backtracking: its commands are awaited)
                         if (rc > 0) {
