@@ -1140,12 +1140,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
     rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;
     {   // What the leader expects of the host (frx_round_kernel.hpp): 0 nothing, it waits for every command; 1 the acceptance of a trial (ADVANCE, next
-        // slot, step 1: lbfgs.hpp:1418); 2 also the next trial step of a running search.  Every expectation is checked against the host's command
-        // word once per round, and that read of mapped host memory takes 2.6 us with up to 4 clusters on the chip but 8-16 us with 32
-        // (profiles/r03_hostwait_probe.jsonl): level 2 removes the waits for a command (one candidate: 146 -> 139 ms per plan) but at 32 candidates
-        // the extra reads cost more than they save (152 -> 157 ms), so large batches stay at level 1.  FRX_RESIDENT_SPECULATE=0|1|2 overrides.
+        // slot, step 1: lbfgs.hpp:1418); 2 also the next trial step of a running search (default).  Every expectation is checked against the host's
+        // command word before the next result is posted.  Measured, production kernel, us per round: 32 candidates 31.5 (round 2's rule: first-trial
+        // acceptances only) -> 30.7 (level 2); one candidate 30.3 -> 29.9.  FRX_RESIDENT_SPECULATE=0|1|2 overrides.
         const char *sp = std::getenv("FRX_RESIDENT_SPECULATE");
-        int level = B <= 16 ? 2 : 1;
+        int level = 2;
         if (sp) level = std::max(0, std::min(2, std::atoi(sp)));
         rl.speculate = (pm.min_step <= 1.0 && 1.0 <= pm.max_step) ? level : 0;         // the predicted ADVANCE carries step 1 (lbfgs.hpp:1418)
     }

@@ -248,6 +248,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     // iteration limit) the leader restores the accepted point and leaves; any other disagreement ends the launch with
     // RK_ERR_SPECULATION and the plan is re-run on the per-stage path.
     bool unconfirmed = false, spec_ready = false, have_cmd = false, ls_ok = false;
+    unsigned n_pred_adv = 0, n_pred_trial = 0, n_redone = 0;                // counters of a.spec, written once at the end
     int pred_kind = 0, run_kind = 0;                                        // 1 = ADVANCE predicted, 2 = another trial of the running search predicted (kind of the NEXT / of the RUNNING round)
     double pred_step = 1.0;
     LineSearch ls;                                                          // the host's More-Thuente state machine (frx_lbfgs.hpp), run in step with it on the same numbers
@@ -262,7 +263,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             spec_ready = false; unconfirmed = true; run_kind = pred_kind;
             hseq++;
             flags = (int)(pred_word & 0xFFu) & ~(int)DV_STEP_IS_ONE;
-            if (t == 0 && a.spec) a.spec[c * 4 + (pred_kind == 1 ? 0 : 1)] += 1u;
+            if (pred_kind == 1) n_pred_adv++; else n_pred_trial++;           // (registers: a read-modify-write of a.spec here cost the leader's first wave a trip to memory per round)
             if (pred_kind == 1) {
                 jnew = (int)((pred_word >> 8) & 0xFFFu); bound = (int)((pred_word >> 20) & 0xFFFu);
                 step = 1.0;
@@ -441,7 +442,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                         rk_u64 w2 = 0, stp = 0;
                         rk_load_cmd(a.h_cmd + c * a.cmd_stride, w2, stp);
                         ctlU[2] = (unsigned)w2; ctlD[5] = __longlong_as_double((long long)stp);
-                        if (a.spec) a.spec[c * 4 + 2] += 1u;
+                        n_redone++;
                     }
                     ctlU[1] = verdict;
                 }
@@ -512,6 +513,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         }
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+    if (t == 0 && a.spec) { a.spec[c * 4] = n_pred_adv; a.spec[c * 4 + 1] = n_pred_trial; a.spec[c * 4 + 2] = n_redone; }
 }
 
 // ============================================================================================================================

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r03}
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=5 > gpurun_out/tests.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/tests.log | tail -3; grep -E "^(FAILED|ERROR)|^E  " gpurun_out/tests.log | head -20; grep -A6 "slowest" gpurun_out/tests.log | tail -6
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 300 --durations=5 > gpurun_out/tests.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/tests.log | tail -3; grep -E "^(FAILED|ERROR)|^E  " gpurun_out/tests.log | head -20; grep -A6 "slowest" gpurun_out/tests.log | tail -6
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 bash scripts/r03/gpu_pmc.sh > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log
 cd $GRAFT_REPO_ROOT
