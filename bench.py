@@ -70,7 +70,7 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     return {
         "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "node_cores": cores, "threads": workers, "kind": "port",
         "sample": f"{done} objective evaluations (x->f,grad) of the {len(cands)} headline candidates at the bench state, "
-                  f"{workers} threads on a node with {cores} logical cores, oracle built -O3 -march=x86-64-v3",
+                  f"{workers} threads on a node with {cores} logical cores, oracle built -O3 -march=x86-64-v3 -ffp-contract=off",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
         "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
         "plan_ms_batch": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_objective_min": float(min(x["objective"] for x in rs)),
