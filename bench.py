@@ -268,6 +268,13 @@ def main():
             prob.set_resident(False)
             r_ps = prob.optimize(params["opt_rel_tol"], x0=x0)
             prob.set_resident(True)
+            r_q = None
+            if r["resident"] == 0 or r["clusters"] < B:
+                # a batch larger than the chip holds at once (Monte-Carlo share: 512 per GPU): the resident kernel's work queue, whatever
+                # the default chose for this size - both paths on the line
+                prob.set_resident(2)
+                r_q = prob.optimize(params["opt_rel_tol"], x0=x0)
+                prob.set_resident(True)
             p1 = frx.Problem(cands[:1], params, device=local_rank, qd_intervals=kappa)
             r_b1 = p1.optimize(params["opt_rel_tol"])
             p1.close()
@@ -280,12 +287,18 @@ def main():
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
                 "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min()),
                 "plan_resident_failed": int(r["resident_failed"]), "plan_resident_retried": int(r["resident_retried"]),
-                "plan_path": ("resident round kernel, %d workgroups per candidate" % r["resident"]) if r["resident"] else "one launch per stage and round",
+                "plan_path": ("resident round kernel, %d workgroups per candidate, %d clusters%s" % (r["resident"], r["clusters"], " (work queue)" if r["clusters"] < B else "")) if r["resident"] else "one launch per stage and round",
+                "plan_clusters": int(r["clusters"]),
                 "plan_us_per_round": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
         if rank == 0:
             plan.update({"plan_ms_per_stage_path": r_ps["ms_total"], "plan_rounds_per_stage_path": r_ps["rounds"],
                          "plan_ms_one_candidate": r_b1["ms_total"], "plan_rounds_one_candidate": r_b1["rounds"],
-                         "plan_path_one_candidate": "resident" if r_b1["resident"] else "per-stage"})
+                         "plan_path_one_candidate": "resident" if r_b1["resident"] else "per-stage",
+                         "plans_per_s_per_stage_path": B / (r_ps["ms_total"] * 1e-3)})
+            if r_q is not None:
+                plan.update({"plan_ms_work_queue": r_q["ms_total"], "plan_clusters_work_queue": int(r_q["clusters"]), "plans_per_s_work_queue": B / (r_q["ms_total"] * 1e-3),
+                             "plan_commands_of_the_busiest_cluster": r_q["rounds"], "plan_evals_mean": float(r_q["evals"].mean()),
+                             "work_queue_equals_default_path_status": bool(np.array_equal(r_q["status"], r["status"]))})
         # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
         from fast_racing_amd.dist import select_winner
         ids = np.arange(rank * B, rank * B + B)

@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
 # diagnostics, include/frx_debug.h: not part of the drop-in boundary
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
-    "frx_debug_resident_counts", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables",
+    "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def lib():
         L.frx_debug_set_resident_retry.argtypes = [C.c_void_p, C.c_int]
         L.frx_debug_resident_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.frx_debug_resident_predictions.argtypes = [C.c_void_p, C.c_void_p]
+        L.frx_debug_resident_clusters.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.frx_dilate_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
         L.frx_eval_stage_times.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
@@ -432,9 +433,16 @@ class Problem:
         """'device' (default: vectors on the GPU, decisions on the host) or 'host' (reference-exact host vectors)."""
         _check(lib().frx_problem_set_lbfgs_mode(self.h, {"device": 0, "host": 1}[name]))
 
-    def set_resident(self, enable: bool):
-        """Resident round kernel (default, when the batch fits the chip) or one launch per stage and round."""
-        _check(lib().frx_problem_set_resident(self.h, 1 if enable else 0))
+    def set_resident(self, enable):
+        """0 / False: one launch per stage and round; 1 / True: resident round kernel when the batch fits the chip, its work queue for batches up
+        to a few times that size (default); 2: the work queue for every batch that exceeds the chip."""
+        _check(lib().frx_problem_set_resident(self.h, int(enable)))
+
+    def resident_clusters(self):
+        """Clusters of the last resident plan (< B: the candidates went through the work queue)."""
+        a = C.c_int()
+        _check(lib().frx_debug_resident_clusters(self.h, C.byref(a)))
+        return int(a.value)
 
     def optimize_path(self):
         """(resident_used, device_status) of the last optimize()."""
@@ -482,7 +490,7 @@ class Problem:
         return int(a.value), int(b.value)
 
     def resident_profile(self):
-        """[B][G][16] microseconds per segment of the last resident plan (needs FRX_RESIDENT_PROF in the environment)."""
+        """[S][G][16] microseconds per segment of the last resident plan, S clusters (needs FRX_RESIDENT_PROF in the environment)."""
         n = lib().frx_resident_profile(self.h, None, 0)
         if n <= 0:
             return None
@@ -490,8 +498,9 @@ class Problem:
         lib().frx_resident_profile(self.h, out.ctypes.data, n)
         self.last_stamps = out[-32:].astype(np.int64)                  # shader-clock stamps of candidate 0's forward (0..6) / adjoint (16..24) bodies
         body = out[:-32]
-        self.last_host_wait_hist = body[-16 * self.B:].reshape(self.B, 16).astype(np.int64)   # per leader: waits for a host command, bin k = shorter than 2^k us
-        return body[:-16 * self.B].reshape(self.B, -1, 16).astype(np.float64) / 100.0
+        S = self.resident_clusters()
+        self.last_host_wait_hist = body[-16 * S:].reshape(S, 16).astype(np.int64)   # per leader: waits for a host command, bin k = shorter than 2^k us
+        return body[:-16 * S].reshape(S, -1, 16).astype(np.float64) / 100.0
 
     def initial_guess(self):
         x = np.zeros(self.NX)
@@ -532,7 +541,8 @@ class Problem:
         resident, dev_status = self.optimize_path()
         return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
                     ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status,
-                    resident_failed=self.resident_counts()[0], resident_retried=self.resident_counts()[1], predictions=self.resident_predictions())
+                    resident_failed=self.resident_counts()[0], resident_retried=self.resident_counts()[1], predictions=self.resident_predictions(),
+                    clusters=self.resident_clusters() if resident else 0)
 
     def stage_times(self, x, reps: int = 100):
         """Average microseconds of the forward, penalty and adjoint kernels at x (HIP events inside the library)."""

@@ -217,9 +217,11 @@ struct frx_problem {
     DevBuf<unsigned long long> d_rprof;                     // FRX_RESIDENT_PROF: [B][G][16] per-segment ticks of the last resident launch
     std::vector<unsigned long long> rprof;
     DevBuf<unsigned> d_rwords;
-    PinBuf<unsigned long long> h_rcmd, h_rres;              // [B] x 2 words, [B] x 8 words
-    int rk_B = 0, rk_G = 0, rk_NXP = 0;
-    int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident)
+    PinBuf<unsigned long long> h_rcmd, h_rres;              // [S] x 8 words each (S clusters: one mailbox per cluster)
+    int rk_B = 0, rk_S = 0, rk_G = 0, rk_NXP = 0;
+    int resident_clusters = 0;                              // clusters of the last resident launch (< B: the candidates went through the work queue)
+    int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident); 2 = also when the batch
+                                                            // is larger than the chip holds at once, whatever its size (work queue); 0 = never
     int resident_retry = 0;                                 // 1 = re-run candidates that fail on the resident kernel on the per-stage rounds (diagnostic, frx_debug_set_resident_retry); the reference takes no second chance and neither does the default
     int resident_retried = 0;                               // candidates of the last plan re-run on the per-stage rounds after an L-BFGS error
     unsigned long long spec_counts[4] = {0, 0, 0, 0};       // last resident plan, summed over candidates: rounds started on a predicted ADVANCE / trial step, predictions redone, reserved
@@ -1084,6 +1086,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
     int G = 2 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each) + dense
+    const int G_min = std::max(G, 3);
     {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them
         const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
         const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(B, 1)});
@@ -1091,22 +1094,39 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
     G = std::max(G, 3);
-    if ((long)8 * G * ((B + 7) / 8) > cus) return 1;                                  // every workgroup must be resident at once (one per CU; grid = 8 G ceil(B/8))
+    // Every workgroup must be resident at once (one per CU; grid = 8 G ceil(S / 8)).  A batch the chip cannot hold at once runs on
+    // S < B clusters that stay on the chip and take the remaining candidates one after the other (work queue: a cluster whose candidate is
+    // finished gets the next one with its DV_NEXT command instead of DV_QUIT).  The clusters run independently, so the batch takes
+    // ~sum(evaluations) / S rounds where the per-stage path - every candidate in every launch - takes max(evaluations) rounds of a
+    // launch that grows with B: measured (profiles/r03_queue_sizes.jsonl) the queue wins up to a few times the chip's capacity, the
+    // per-stage path beyond; resident_mode 2 / FRX_RESIDENT_QUEUE=1 force the queue, FRX_RESIDENT_QUEUE=0 forbids it.
+    int S = B;
+    const char *ce = std::getenv("FRX_RESIDENT_CLUSTERS");                            // experiments / tests: no more than this many clusters
+    if ((long)8 * G * ((B + 7) / 8) > cus) { G = G_min; S = std::min(B, 8 * (cus / (8 * G))); }
+    if (ce) S = std::min(S, std::max(1, std::atoi(ce)));
+    if (S < 1) return 1;
+    if (S < B) {
+        const char *qe = std::getenv("FRX_RESIDENT_QUEUE");
+        const int queue_max = [] { const char *e = std::getenv("FRX_RESIDENT_QUEUE_MAX"); return e ? std::atoi(e) : 4; }();   // x capacity
+        const bool allowed = qe ? qe[0] != '0' : (ce || p->resident_mode == 2 || B <= queue_max * S);
+        if (!allowed) return 1;
+    }
     const size_t lds = frx::round_lds_bytes(p->geo, m, E);
     if (lds == 0 || lds > 160 * 1024) return 1;
     const int NXP = (G - 2) * 2 * E;
+    const size_t n_words = (size_t)frx::ROUND_WORDS_PER_CAND * S + 2 + (size_t)S * G + 4 * (size_t)B;
     hipError_t e = hipSuccess;
-    if (p->rk_B != B || p->rk_G != G || p->rk_NXP != NXP) {
+    if (p->rk_B != B || p->rk_S != S || p->rk_G != G || p->rk_NXP != NXP) {
         p->rk_B = 0;
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
-        if ((e = p->d_pubsyg.alloc((size_t)B * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)B * G * 512)) != hipSuccess ||
-            (e = p->d_upub.alloc((size_t)B * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)B * NXP)) != hipSuccess ||
-            (e = p->d_rwords.alloc((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G + 4 * (size_t)B)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * B)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * B)) != hipSuccess ||
+        if ((e = p->d_pubsyg.alloc((size_t)S * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)S * G * 512)) != hipSuccess ||
+            (e = p->d_upub.alloc((size_t)S * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)S * NXP)) != hipSuccess ||
+            (e = p->d_rwords.alloc(n_words)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * S)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * S)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
         }
-        p->rk_B = B; p->rk_G = G; p->rk_NXP = NXP;
+        p->rk_B = B; p->rk_S = S; p->rk_G = G; p->rk_NXP = NXP;
     }
     // direction log (frx_debug.h): [B] record counts, then dirlog_cands x dirlog_cap records {s, y, g, d, slot, pair count}
     const int log_cands = std::min(p->dirlog_cands, B);
@@ -1119,16 +1139,16 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     const bool want_prof = std::getenv("FRX_RESIDENT_PROF") != nullptr;
     if (want_prof) {
-        if ((!p->d_rprof.p || p->d_rprof.n < (size_t)B * (G + 1) * 16) && p->d_rprof.alloc((size_t)B * (G + 1) * 16) != hipSuccess) return 1;
-        HIP_TRY(hipMemsetAsync(p->d_rprof.p, 0, sizeof(unsigned long long) * (size_t)B * (G + 1) * 16, p->stream));
+        if ((!p->d_rprof.p || p->d_rprof.n < (size_t)S * (G + 1) * 16) && p->d_rprof.alloc((size_t)S * (G + 1) * 16) != hipSuccess) return 1;
+        HIP_TRY(hipMemsetAsync(p->d_rprof.p, 0, sizeof(unsigned long long) * (size_t)S * (G + 1) * 16, p->stream));
     }
     p->rprof.clear();
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
-    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * ((size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G + 4 * (size_t)B), p->stream));
-    HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)B * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
-    std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * B);
-    std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * B);
+    HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * n_words, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)S * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
+    std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * S);
+    std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * S);
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
     frx::RoundLaunch rl;
@@ -1136,7 +1156,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr; rl.dbg_cap = want_dbg ? p->dirlog_cap : 0; rl.dbg_cands = want_dbg ? log_cands : 0;
     rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
-    rl.B = B; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
+    rl.B = B; rl.S = S; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
     rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;
     {   // What the leader expects of the host (frx_round_kernel.hpp): 0 nothing, it waits for every command; 1 the acceptance of a trial (ADVANCE, next
@@ -1155,41 +1175,64 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         p->dp.stamps = p->d_stamps.p;
     }
 
-    // Per-candidate host state, one cache-line-aligned slot each and a CONTIGUOUS range of slots per service thread: with the state in
+    // Host state per CLUSTER, one cache-line-aligned slot each and a CONTIGUOUS range of slots per service thread: with the state in
     // parallel arrays and candidate b served by thread b % nsrv (round 2), every line of `seq`, `waiting`, `cmd` and the solvers was
     // written by all threads - two service threads answered SLOWER than one (leader's wait for a command at 32 candidates: median
     // 8-16 us with two threads, 4-8 us with one, 2-4 us at 8 candidates; profiles/r03_hostwait_probe.jsonl) and more threads bought nothing.
-    struct alignas(128) Slot { frx::SolverDV sv; frx::DvCommand cmd; unsigned long long seq = 0; long ncmd = 0; char waiting = 0, quit_sent = 0; };
-    std::vector<Slot> slot_(B);
+    // A slot holds the solver of the candidate its cluster is working on; with more candidates than clusters (S < B) a slot whose
+    // candidate is finished takes the next one of the batch (`next_cand`) and tells the cluster with DV_NEXT.
+    struct alignas(128) Slot { frx::SolverDV sv; frx::DvCommand cmd; unsigned long long seq = 0; long ncmd = 0; int cand = -1; char waiting = 0, quit_sent = 0, switching = 0; };
+    std::vector<Slot> slot_(S);
+    std::atomic<int> next_cand{S};
     volatile unsigned long long *hc = p->h_rcmd.p, *hr = p->h_rres.p;
-    { const char *cs = std::getenv("FRX_RESIDENT_CMD_STRIDE"); rl.cmd_stride = cs && std::atoi(cs) == 1 ? 1 : 4; }   // 4: one cache line per candidate
+    { const char *cs = std::getenv("FRX_RESIDENT_CMD_STRIDE"); rl.cmd_stride = cs && std::atoi(cs) == 1 ? 1 : 4; }   // 4: one cache line per cluster
     const size_t cs2 = 2 * (size_t)rl.cmd_stride;
-    auto post = [&](int b, int flags, int slot, int bound, double step) {
-        std::memcpy((void *)(hc + cs2 * b + 1), &step, sizeof(double));
+    auto post = [&](int k, int flags, int slot, int bound, double step) {
+        std::memcpy((void *)(hc + cs2 * k + 1), &step, sizeof(double));
         std::atomic_thread_fence(std::memory_order_release);
-        ++slot_[b].seq;
-        if (step == 1.0 && !(flags & 128)) flags |= 64;                                // DV_STEP_IS_ONE: lets the leader confirm a predicted command from this word alone
+        ++slot_[k].seq;
+        if (step == 1.0 && !(flags & (128 | 32))) flags |= 64;                         // DV_STEP_IS_ONE: lets the leader confirm a predicted command from this word alone
         if ((flags & frx::DV_TRIAL) && !(flags & frx::DV_ADVANCE)) {                   // a trial inside a search: slot and pair count mean nothing here, a fold of the step's bits rides in their place
             const unsigned h = frx::dv_step_hash(step);
             slot = (int)(h & 0xFFFu); bound = (int)(h >> 12);
         }
-        hc[cs2 * b] = (slot_[b].seq << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
-        slot_[b].ncmd++;
+        hc[cs2 * k] = (slot_[k].seq << 32) | ((unsigned long long)(bound & 0xFFF) << 20) | ((unsigned long long)(slot & 0xFFF) << 8) | (unsigned long long)(flags & 0xFF);
+        slot_[k].ncmd++;
     };
     const bool tracing = std::getenv("FRX_TRACE") != nullptr;
     p->trace.clear();
-    for (int b = 0; b < B; b++) slot_[b].sv.start(p->xoff[b + 1] - p->xoff[b], pm, &slot_[b].cmd);
+    auto record = [&](int k) {                                                       // the finished plan of slot k's candidate (the point itself is read from the device at the end)
+        const int b = slot_[k].cand;
+        status[b] = slot_[k].sv.status();
+        if (iters) iters[b] = slot_[k].sv.iterations();
+        if (evals) evals[b] = slot_[k].sv.evaluations();
+        if (objective) objective[b] = slot_[k].sv.value();
+    };
+    // slot k's candidate is finished (or had nothing to run): the next candidate of the batch for its cluster, or DV_QUIT.  Returns true
+    // while the slot has work.
+    auto hand_over = [&](int k) -> bool {
+        record(k);
+        const int nb = next_cand.load(std::memory_order_relaxed) < B ? next_cand.fetch_add(1) : B;
+        if (nb >= B) { post(k, 128, 0, 0, 0.0); slot_[k].quit_sent = 1; slot_[k].waiting = 0; return false; }   // this cluster leaves the chip
+        slot_[k].cand = nb;
+        slot_[k].sv.start(p->xoff[nb + 1] - p->xoff[nb], pm, &slot_[k].cmd);
+        post(k, 32, nb & 0xFFF, nb >> 12, 0.0);                                      // DV_NEXT: the cluster re-binds and answers with the command's sequence number
+        slot_[k].switching = 1; slot_[k].waiting = 1;
+        return true;
+    };
+    for (int b = 0; b < B; b++) status[b] = 0;
+    for (int k = 0; k < S; k++) { slot_[k].cand = k; slot_[k].sv.start(p->xoff[k + 1] - p->xoff[k], pm, &slot_[k].cmd); }
     std::unique_lock<std::mutex> device_slot(resident_device_lock(p->device));        // one resident grid per device at a time (see above)
     const auto t0 = clk::now();
     HIP_TRY((hipError_t)frx::launch_round(p->dp, p->geo, rl, p->stream));
-    for (int b = 0; b < B; b++) {
-        if (slot_[b].cmd.flags != 0) { post(b, slot_[b].cmd.flags, slot_[b].cmd.slot, slot_[b].cmd.bound, slot_[b].cmd.step); slot_[b].waiting = 1; }
-        else { post(b, 128, 0, 0, 0.0); slot_[b].quit_sent = 1; }                            // invalid parameters: nothing to run (DV_QUIT)
+    for (int k = 0; k < S; k++) {
+        if (slot_[k].cmd.flags != 0) { post(k, slot_[k].cmd.flags, slot_[k].cmd.slot, slot_[k].cmd.bound, slot_[k].cmd.step); slot_[k].waiting = 1; }
+        else hand_over(k);                                                           // invalid parameters: nothing to run
     }
-    // Mailbox service: thread tid serves the candidates [B tid / nsrv, B (tid + 1) / nsrv) (the caller is thread 0).  The clusters of a batch
+    // Mailbox service: thread tid serves the clusters [S tid / nsrv, S (tid + 1) / nsrv) (the caller is thread 0).  The clusters of a batch
     // run in near lock-step, so their results arrive together and a thread's k-th mailbox waits for the k - 1 before it.
-    int nsrv = std::max(1, std::min(8, B / 4));                                       // four candidates per thread (see Slot above)
-    if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), B));
+    int nsrv = std::max(1, std::min(8, S / 4));                                       // four clusters per thread (see Slot above)
+    if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), S));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     const int scan_pause = [] { const char *e = std::getenv("FRX_RESIDENT_SCAN_PAUSE"); return e ? std::max(0, std::atoi(e)) : 0; }();   // extra pauses between two scans of a thread's mailboxes (experiments)
     std::vector<double> t_host_thr(nsrv, 0.0);
@@ -1197,39 +1240,40 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     auto serve = [&](int tid) {
         int mine = 0;
         long nscan = 0;
-        const int lo = (int)((long)B * tid / nsrv), hi = (int)((long)B * (tid + 1) / nsrv);      // this thread's candidates
-        for (int b = lo; b < hi; b++) mine += slot_[b].waiting ? 1 : 0;
+        const int lo = (int)((long)S * tid / nsrv), hi = (int)((long)S * (tid + 1) / nsrv);      // this thread's clusters
+        for (int k = lo; k < hi; k++) mine += slot_[k].waiting ? 1 : 0;
         auto t_last = clk::now();
         while (mine > 0 && abort_code.load(std::memory_order_relaxed) == 0) {
             bool progress = false;
             nscan++;
-            for (int b = lo; b < hi; b++) {
-                if (!slot_[b].waiting) continue;
-                const unsigned long long rs = hr[8 * b + 7];
-                if (rs == ~0ull) { abort_code.store(1); break; }                        // the device gave up on this candidate
-                if (rs != slot_[b].seq) continue;
+            for (int k = lo; k < hi; k++) {
+                if (!slot_[k].waiting) continue;
+                const unsigned long long rs = hr[8 * k + 7];
+                if (rs == ~0ull) { abort_code.store(1); break; }                        // the device gave up on this cluster
+                if (rs != slot_[k].seq) continue;
                 std::atomic_thread_fence(std::memory_order_acquire);
                 progress = true;
                 const auto th = clk::now();
-                frx::DvCommand &c = slot_[b].cmd;
-                if (c.flags & frx::DV_EVAL) {
+                frx::DvCommand &c = slot_[k].cmd;
+                if (slot_[k].switching) slot_[k].switching = 0;                         // the cluster is on its new candidate: c holds the first command of that plan (SolverDV::start)
+                else if (c.flags & frx::DV_EVAL) {
                     frx::DvResult r;
-                    std::memcpy(&r, (const void *)(hr + 8 * b), 5 * sizeof(double));
-                    if (tracing && b == 0) { const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
-                    if (slot_[b].sv.saw_nonfinite(r.f)) slot_[b].sv.give_up(frx::LBERR_ROUNDING); else slot_[b].sv.feed(r);
+                    std::memcpy(&r, (const void *)(hr + 8 * k), 5 * sizeof(double));
+                    if (tracing && slot_[k].cand == 0) { const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
+                    if (slot_[k].sv.saw_nonfinite(r.f)) slot_[k].sv.give_up(frx::LBERR_ROUNDING); else slot_[k].sv.feed(r);
                 } else c.flags = 0;                                                     // a RESTORE has been executed
-                if (c.flags != 0) post(b, c.flags, c.slot, c.bound, c.step);
-                else { post(b, 128, 0, 0, 0.0); slot_[b].quit_sent = 1; slot_[b].waiting = 0; mine--; }   // this candidate's cluster leaves the chip
+                if (c.flags != 0) post(k, c.flags, c.slot, c.bound, c.step);
+                else if (!hand_over(k)) mine--;
                 t_host_thr[tid] += ms_since(th);
             }
             if (progress) t_last = clk::now();
             else if (ms_since(t_last) > timeout_ms) abort_code.store(2);
             else {
-                // a kernel that has LEFT while candidates still wait (start-up census failed: the grid did not fit next to another
+                // a kernel that has LEFT while clusters still wait (start-up census failed: the grid did not fit next to another
                 // process's work; a device fault) will never answer: notice it from the stream instead of sitting out the whole timeout
                 if (tid == 0 && (nscan & 0x3FFF) == 0 && hipStreamQuery(p->stream) != hipErrorNotReady) {
                     bool answered = true;
-                    for (int b = 0; b < B; b++) if (slot_[b].waiting && hr[8 * b + 7] != slot_[b].seq) answered = false;
+                    for (int k = 0; k < S; k++) if (slot_[k].waiting && hr[8 * k + 7] != slot_[k].seq) answered = false;
                     if (!answered) abort_code.store(1);
                 }
                 for (int q = 0; q <= scan_pause; q++) __builtin_ia32_pause();
@@ -1252,7 +1296,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     for (double v : t_host_thr) t_host = std::max(t_host, v);
     if (abort_code.load() == 1) rc = 1;
     else if (abort_code.load() == 2) rc = fail(FRX_ERR_TIMEOUT, "resident round kernel: no result within FRX_ROUND_TIMEOUT_MS");
-    for (int b = 0; b < B; b++) if (!slot_[b].quit_sent) post(b, 128, 0, 0, 0.0);
+    for (int k = 0; k < S; k++) if (!slot_[k].quit_sent) post(k, 128, 0, 0, 0.0);
     {   // bounded drain: the kernel's own spins expire after the same timeout
         const auto tw = clk::now();
         for (;;) {
@@ -1265,11 +1309,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     device_slot.unlock();                                                             // the kernel has left the chip
     unsigned st[2] = {0, 0};
-    HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * B, sizeof(st), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st, p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * S, sizeof(st), hipMemcpyDeviceToHost));
     p->resident_status = st[1];
     {
         std::vector<unsigned> sc(4 * (size_t)B, 0u);
-        HIP_TRY(hipMemcpy(sc.data(), p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * B + 2 + (size_t)B * G, sizeof(unsigned) * sc.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sc.data(), p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * S + 2 + (size_t)S * G, sizeof(unsigned) * sc.size(), hipMemcpyDeviceToHost));
         for (int q = 0; q < 4; q++) { p->spec_counts[q] = 0; for (int b = 0; b < B; b++) p->spec_counts[q] += sc[4 * (size_t)b + q]; }
     }
     if (want_dbg) {
@@ -1279,22 +1323,17 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (rc < 0) return rc;
     if (rc != FRX_OK || st[1] != 0) return 1;
     long rounds = 0;
-    for (int b = 0; b < B; b++) rounds = std::max(rounds, slot_[b].ncmd);
+    for (int k = 0; k < S; k++) rounds = std::max(rounds, slot_[k].ncmd);                 // commands of the busiest cluster (S < B: over all the candidates it took)
     p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
     if (want_prof) {
-        p->rprof.resize((size_t)B * (G + 1) * 16 + 32);                                // [B][G][16] segment sums, [B][16] host-wait histogram; the last 32 words: the bodies' cycle stamps
-        HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)B * (G + 1) * 16, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)B * (G + 1) * 16, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+        p->rprof.resize((size_t)S * (G + 1) * 16 + 32);                                // [S][G][16] segment sums, [S][16] host-wait histogram; the last 32 words: the bodies' cycle stamps
+        HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)S * (G + 1) * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)S * (G + 1) * 16, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     }
-    for (int b = 0; b < B; b++) {
-        status[b] = slot_[b].sv.status();
+    for (int b = 0; b < B; b++)
         if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) p->resident_failed++;
-        if (iters) iters[b] = slot_[b].sv.iterations();
-        if (evals) evals[b] = slot_[b].sv.evaluations();
-        if (objective) objective[b] = slot_[b].sv.value();
-    }
-    p->resident_used = G;
+    p->resident_used = G; p->resident_clusters = S;
     return FRX_OK;
 }
 
@@ -1413,7 +1452,7 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
 
 int frx_problem_set_resident(frx_problem *p, int enable) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
-    p->resident_mode = enable ? 1 : 0;
+    p->resident_mode = enable == 0 ? 0 : enable == 2 ? 2 : 1;
     return FRX_OK;
 }
 int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device_status) {
@@ -1452,6 +1491,11 @@ int frx_debug_set_resident_retry(frx_problem *p, int enable) {
 int frx_debug_resident_predictions(const frx_problem *p, unsigned long long *out3) {
     if (!p || !out3) return fail(FRX_ERR_INVALID_ARG, "null argument");
     for (int q = 0; q < 3; q++) out3[q] = p->spec_counts[q];
+    return FRX_OK;
+}
+int frx_debug_resident_clusters(const frx_problem *p, int *clusters) {
+    if (!p || !clusters) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    *clusters = p->resident_clusters;
     return FRX_OK;
 }
 int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried) {

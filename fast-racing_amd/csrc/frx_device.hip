@@ -106,21 +106,22 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.x = r.x; a.g = r.g; a.xp = r.xp; a.gp = r.gp; a.d = r.d; a.f = r.f; a.T = r.T; a.C = r.C; a.out20 = r.out20; a.pcrw = g.pcrw;
     a.pubsyg = r.pubsyg; a.part = r.part; a.upub = r.upub; a.dpub = r.dpub; a.dbg = r.dbg; a.dbg_cap = r.dbg_cap; a.dbg_cands = r.dbg_cands;
     a.phase = r.words; a.cntA = r.words + 32; a.uflag = r.words + 64; a.cntL = r.words + 96;                     // one 512-byte block per candidate, one 128-byte line per word
-    a.census = r.words + (size_t)RK_WORDS_PER_CAND * r.B; a.status = a.census + 1; a.xcc = a.census + 2; a.spec = a.xcc + (size_t)r.B * r.G;
+    if (r.S < 1 || r.S > r.B) return (int)hipErrorInvalidValue;
+    a.census = r.words + (size_t)RK_WORDS_PER_CAND * r.S; a.status = a.census + 1; a.xcc = a.census + 2; a.spec = a.xcc + (size_t)r.S * r.G;
     a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
     a.timeout_ticks = r.timeout_ticks;
     a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms
     a.ls_ftol = r.ls_ftol; a.ls_gtol = r.ls_gtol; a.ls_min_step = r.ls_min_step; a.ls_max_step = r.ls_max_step; a.ls_xtol = r.ls_xtol; a.ls_max_linesearch = r.ls_max_linesearch; a.speculate = r.speculate;
     { static const int ps = [] { const char *e = std::getenv("FRX_RESIDENT_POLL"); return e ? std::atoi(e) : 0; }(); a.poll_sleep = ps < 0 ? 0 : ps > 4 ? 4 : ps; }
     a.cmd_stride = r.cmd_stride;
-    a.B = r.B; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g); a.maxN19 = g.maxN * 19;
+    a.B = r.B; a.S = r.S; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g); a.maxN19 = g.maxN * 19;
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;
     const void *fn = r.prof ? (const void *)k_round<ROUND_E, true> : (const void *)k_round<ROUND_E, false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(8 * r.G * ((r.B + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(8 * r.G * ((r.B + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
+    if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(8 * r.G * ((r.S + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(8 * r.G * ((r.S + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -84,12 +84,12 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 // ---- resident round kernel (frx_round_kernel.hpp): one launch per plan ----
 struct RoundLaunch {
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20;              // leader vectors and stage buffers (the handle's own)
-    double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([B][3 NXP + 2], [B][G][512], [B][258], [B][NXP])
-    unsigned *words;                                               // [ROUND_WORDS_PER_CAND B + 2 + B G + 4 B]: a 512-byte block per candidate (phase, cntA, uflag, cntL in separate lines), then census, status, XCC ids, prediction counters
-    void *h_cmd, *h_res;                                           // mapped host mailboxes, [B] x 16 B and [B] x 64 B
+    double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([S][3 NXP + 2], [S][G][512], [S][258], [S][NXP])
+    unsigned *words;                                               // [ROUND_WORDS_PER_CAND S + 2 + S G + 4 B]: a 512-byte block per cluster (phase, cntA, uflag, cntL in separate lines), then census, status, XCC ids, prediction counters per candidate
+    void *h_cmd, *h_res;                                           // mapped host mailboxes, [S] x 16 B (x cmd_stride) and [S] x 64 B
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
-    int B, G, m, E, NXP;
+    int B, S, G, m, E, NXP;                                         // B candidates on S <= B clusters of G workgroups (S < B: the host hands candidates S .. B-1 to clusters that finish, DV_NEXT)
     int dbg_cap = 0, dbg_cands = 0;                                 // direction log (dbg): [B] counts + dbg_cands x dbg_cap records of 4 NXP + 2 doubles
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20, ls_xtol = 1e-16;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;

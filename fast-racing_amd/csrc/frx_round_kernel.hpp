@@ -46,13 +46,14 @@ typedef volatile __attribute__((address_space(3))) unsigned *rk_ldsword;
 #define FRX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define FRX_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
-enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3, PH_INIT = 4 };
+enum { PH_ADV = 1, PH_CT = 2, PH_QUIT = 3, PH_INIT = 4, PH_NEXT = 5 };
 enum { RK_OK = 0, RK_ERR_CENSUS = 1, RK_ERR_HOST = 2, RK_ERR_PHASE = 3, RK_ERR_ARRIVE = 4, RK_ERR_DENSE = 5, RK_ERR_UFLAG = 6, RK_ERR_HOST_ABORT = 7, RK_ERR_SPECULATION = 8 };
-enum { DV_QUIT = 128, DV_STEP_IS_ONE = 64 };   // extra command flags of the resident kernel (frx_lbfgs.hpp: DV_* are < 32); the second one lets the
-                                               // leader confirm a predicted command from the command WORD alone (no second read over PCIe)
+enum { DV_QUIT = 128, DV_STEP_IS_ONE = 64, DV_NEXT = 32 };   // extra command flags of the resident kernel (frx_lbfgs.hpp: DV_* are < 32); the second one lets
+                                               // the leader confirm a predicted command from the command WORD alone (no second read over PCIe); DV_NEXT: this
+                                               // candidate is finished, the cluster takes candidate slot | bound << 12 of the batch (work queue, see k_round)
 
 // host -> device: word = seq << 32 | bound << 20 | slot << 8 | flags (written last); step first.  device -> host: seq written last.
-struct RoundCmd { rk_u64 word; double step; };                          // candidate c's command is h_cmd[c * cmd_stride] (cmd_stride 4: one cache line per candidate)
+struct RoundCmd { rk_u64 word; double step; };                          // cluster k's command is h_cmd[k * cmd_stride] (cmd_stride 4: one cache line per cluster)
 struct RoundRes { double f, dg, xx, gg, dginit, pad[2]; rk_u64 seq; };
 static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 
@@ -88,14 +89,14 @@ struct RoundArgs {
     DevProblem dp;
     int maxCN, maxXb, maxVb, nrow, nsteps, lpp, ppw, Kmax, pen_lds;   // geometry of the evaluation bodies (LaunchGeom); pen_lds in doubles per wave
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20, *pcrw;           // leader-private vectors + the evaluation's stage buffers
-    double *pubsyg;          // [B][3 NXP + 2] leader -> cluster: the point x and its gradient g (first 2 NXP doubles, zero beyond n), then (slot, pair count)
-    double *part;            // [B][G][4][128] cluster -> dense: partial dot products
-    double *upub;            // [B][258]      dense -> cluster: -u, gamma w, gamma
-    double *dpub;            // [B][NXP]      cluster -> leader: direction chunks
-    unsigned *phase, *cntA, *uflag, *cntL;   // word c * RK_WSTRIDE of each (zeroed before every launch); the four bases are 32 words apart
+    double *pubsyg;          // [S][3 NXP + 2] leader -> cluster: the point x and its gradient g (first 2 NXP doubles, zero beyond n), then (slot, pair count)
+    double *part;            // [S][G][4][128] cluster -> dense: partial dot products
+    double *upub;            // [S][258]      dense -> cluster: -u, gamma w, gamma
+    double *dpub;            // [S][NXP]      cluster -> leader: direction chunks
+    unsigned *phase, *cntA, *uflag, *cntL;   // word k * RK_WSTRIDE of each (k: cluster) (zeroed before every launch); the four bases are 32 words apart
     unsigned *census, *status;               // [1] each (zeroed before every launch)
-    unsigned *xcc;                           // [B][G] XCC id + 1 of every workgroup (zeroed before every launch)
-    RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [B] each
+    unsigned *xcc;                           // [S][G] XCC id + 1 of every workgroup (zeroed before every launch)
+    RoundCmd *h_cmd; RoundRes *h_res;        // mapped host memory, [S] each: one mailbox per CLUSTER
     rk_u64 timeout_ticks;                    // bound of every spin, in wall_clock64 ticks (100 MHz)
     rk_u64 census_ticks;                     // bound of the start-up census (all workgroups resident)
     double ls_ftol, ls_gtol, ls_min_step, ls_max_step, ls_xtol;   // line-search constants of the plan (frx_lbfgs_params), for the leader's prediction
@@ -104,7 +105,7 @@ struct RoundArgs {
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
-    int B, G, m, NXP, eval_doubles, ct_doubles;                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
+    int B, S, G, m, NXP, eval_doubles, ct_doubles;                    // B candidates, S <= B clusters (S < B: work queue, DV_NEXT);                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
     double *dbg;                             // optional direction log (frx_debug.h, frx_debug_direction_log): [B] record counts, then per candidate c < dbg_cands
     int dbg_cap, dbg_cands;                  // dbg_cap records of 4 NXP + 2 doubles: s, y, g (the pair and the gradient the direction was built from), d, slot, pair count
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*; then [B][16]: histogram of the leaders' waits for a host command
@@ -161,8 +162,8 @@ __device__ __forceinline__ void rk_drain_and_meet() {
 
 
 // ---- pieces shared by the two role loops ----
-struct RoundView {                       // per-workgroup constants
-    int c, wg, t, lane, wave, m, n, xbase, p0, N;
+struct RoundView {                       // per-workgroup constants; c, n, xbase, p0, N change when the cluster takes another candidate (DV_NEXT)
+    int k, c, wg, t, lane, wave, m, n, xbase, p0, N;
     bool wt;
     double *pub, *part, *upub, *dpub;
 };
@@ -184,8 +185,9 @@ __device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const Round
 // LEADER (workgroup 0 of a cluster)
 // ============================================================================================================================
 template <bool PROF>
-__device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
-    const int c = v.c, t = v.t, lane = v.lane, wave = v.wave, n = v.n;
+__device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, const RoundLds &L, double *sm) {
+    const int k = v.k, t = v.t, lane = v.lane, wave = v.wave;
+    int c = v.c, n = v.n;                                                   // the candidate this cluster works on (changes with DV_NEXT)
     const bool wt = v.wt;
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
     double *ctlD = sm + L.ctl + 8, *pair = sm + L.pair, *ctl = sm + L.role, *ev = sm + L.role + a.ct_doubles;
@@ -203,18 +205,18 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
     double *x = ro.xs, *g = ro.gs, *xp = ro.gs + xpad, *gp = xp + xpad, *dv = ro.dsv;
     ro.wq = gp + xpad;                                                    // [nrow][4], forward map -> adjoint of the same evaluation
     ro.gpub = pub + a.NXP; ro.gwt = wt;                                   // the adjoint also stores the gradient where the history workgroups read it
-    {
-        const int v0 = a.dp.cvoff[c], nvd = 3 * (a.dp.cvoff[c + 1] - v0);
+    ro.vskew = 1;
+    auto load_candidate = [&]() {                                           // candidate c's constants and start point into the leader's LDS (once per plan)
+        const int v0 = a.dp.cvoff[c];
         const double *vsrc = a.dp.vrec + 3 * (size_t)v0;
-        (void)nvd;
-        ro.vskew = 1;
         for (int w = t >> 2; w < v.N - 1; w += 64) {                       // a quad of lanes copies the polytope of waypoint w, w doubles further on
             const int gw = v.p0 - c + w, beg = 3 * (a.dp.wp_vbeg[gw] - v0), cnt = 3 * a.dp.wp_nv[gw];
             for (int j = t & 3; j < cnt; j += 4) ro.vs[beg + w + j] = vsrc[beg + j];
         }
         for (int i = t; i < n; i += 256) { x[i] = xglob[i]; dv[i] = 0.0; g[i] = 0.0; xp[i] = 0.0; gp[i] = 0.0; }
         __syncthreads();
-    }
+    };
+    load_candidate();
     // An accepted step (lbfgs.hpp:1354-1360: s = x - xp, y = g - gp, then the point becomes the base).  The cluster already HAS the point
     // and its gradient: every trial point goes to the first NXP doubles of `pub` when it is formed and every gradient to the next NXP
     // straight from the adjoint (ResidentOps::gpub), and each history workgroup keeps its chunk of the previous point and gradient in LDS,
@@ -281,7 +283,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 rk_u64 w = 0, stp = 0;
                 bool ok = true;
                 for (unsigned spins = 0;; spins++) {
-                    rk_load_cmd(a.h_cmd + c * a.cmd_stride, w, stp);
+                    rk_load_cmd(a.h_cmd + k * a.cmd_stride, w, stp);
                     if ((w >> 32) == hseq + 1) break;
                     if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                 }
@@ -289,9 +291,9 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     const unsigned us = (unsigned)((wall_clock64() - tw0) / 100);
                     int bin = 0;
                     while (bin < 15 && (1u << bin) <= us) bin++;
-                    a.prof[(size_t)a.B * a.G * 16 + (size_t)c * 16 + bin] += 1;
+                    a.prof[(size_t)a.S * a.G * 16 + (size_t)k * 16 + bin] += 1;
                 }
-                if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
+                if (!ok) { rk_fail(a, RK_ERR_HOST); w = DV_QUIT; __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); }
                 ctlU[1] = (unsigned)w;
                 if (ok) ctlD[5] = __longlong_as_double((long long)stp);
             }
@@ -305,10 +307,30 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             step = ctlD[5];
             __syncthreads();
             if (flags & DV_QUIT) { kind = PH_QUIT; flush(x, g); }
+            else if (flags & DV_NEXT) {
+                // Work queue (more candidates than clusters): the host has finished candidate c - its point goes to global memory as with
+                // QUIT - and hands this cluster candidate jnew | bound << 12.  The cluster stays on the chip: the leader loads the new
+                // candidate's polytopes and start point, the members re-bind their penalty share, the dense workgroup clears R^-1 and Y^T Y
+                // (phase NEXT); the history registers need nothing - pairs are valid by (slot, pair count) of the new plan's steps.
+                flush(x, g);
+                if (t == 0 && a.spec) { a.spec[c * 4] = n_pred_adv; a.spec[c * 4 + 1] = n_pred_trial; a.spec[c * 4 + 2] = n_redone; }
+                n_pred_adv = n_pred_trial = n_redone = 0;
+                __syncthreads();
+                const int n_old = n;
+                c = jnew | (bound << 12);
+                v.c = c; v.xbase = a.dp.xoff[c]; n = v.n = a.dp.xoff[c + 1] - v.xbase; v.p0 = a.dp.poff[c]; v.N = a.dp.poff[c + 1] - v.p0;
+                xglob = a.x + v.xbase; gglob = a.g + v.xbase;
+                load_candidate();
+                for (int i = n + t; i < n_old; i += 256) { stg<true>(pub + i, 0.0, wt); stg<true>(pub + a.NXP + i, 0.0, wt); }   // s and y are zero beyond n (a shorter candidate after a longer one)
+                if (t == 0) stg<true>(pub + 2 * a.NXP, (double)c, wt);
+                nadv_l = 0; trial_done = false; dg_pending = false; spec_ready = false; unconfirmed = false; ls_ok = false; pred_kind = 0;
+                last_slot = -1; last_bound = 0;
+                kind = PH_NEXT;
+            }
             else if (flags & DV_RESTORE) {                                  // lbfgs.hpp:1287-1288; no evaluation follows
                 for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }
                 rk_drain_and_meet();
-                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
+                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[k].seq, hseq, FRX_RLX_SYS); }
                 continue;
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
                 f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
@@ -340,7 +362,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                 RK_PROF(RK_P_FORWARD);
             } else {
                 rk_drain_and_meet();
-                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[c].seq, hseq, FRX_RLX_SYS); }
+                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[k].seq, hseq, FRX_RLX_SYS); }
                 lstage = 0;
                 continue;
             }
@@ -350,7 +372,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
         pseq++;
-        if (t == 0) __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
         if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
         if (seq_pending != 0) {
             // The result of the round whose acceptance the leader predicted goes to the host only NOW, behind the phase word of the step it
@@ -359,7 +381,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             // rounds out of four.  Thread 0 alone waits for them (the others meet it at the arrival barrier, behind which the whole
             // direction phase lies anyway); no release fence: its L2 write-back would serve cached stores, and there are none to publish.
             if (t == 0) {
-                RoundRes *r = a.h_res + c;
+                RoundRes *r = a.h_res + k;
                 __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
@@ -375,9 +397,9 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
         // ---- the phase is complete when every workgroup of the cluster has reported ----
         rk_drain_and_meet();
-        if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
         nphase++;
-        if (t == 0) { const bool ok = rk_wait_eq(a.cntL + c * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
+        if (t == 0) { const bool ok = rk_wait_eq(a.cntL + k * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
         __syncthreads();
         const bool ok = ctlU[0] != 0u;
         __syncthreads();
@@ -385,8 +407,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (!ok) {                                                          // tell the host and the cluster, then leave
             flush(x, g);
             pseq++;
-            if (t == 0) { __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
+            if (t == 0) { __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
             break;
+        }
+        if (kind == PH_NEXT) {                                              // every workgroup of the cluster is on the new candidate: tell the host, whose next command starts its plan
+            if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[k].seq, hseq, FRX_RLX_SYS); }
+            lstage = 0;
+            continue;
         }
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
             // ... and, in the same sweep, the first trial point of the new search x = xp + step d (lbfgs.hpp:825-826; every ADVANCE command
@@ -414,7 +441,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
             if (dg_pending) { if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]); dg_pending = false; }   // gp . d of this round's ADVANCE (read behind the adjoint's barrier)
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
-            if (unconfirmed) tap.early_cmd = &a.h_cmd[c * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
+            if (unconfirmed) tap.early_cmd = &a.h_cmd[k * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
@@ -424,7 +451,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     rk_u64 w = (rk_u64)__double_as_longlong(ctlD[7]);
                     bool ok = true;
                     for (unsigned spins = 0; (w >> 32) != hseq; spins++) {
-                        w = __hip_atomic_load(&a.h_cmd[c * a.cmd_stride].word, FRX_RLX_SYS);
+                        w = __hip_atomic_load(&a.h_cmd[k * a.cmd_stride].word, FRX_RLX_SYS);
                         if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                     }
                     // 0 confirmed; 1 the host stopped (QUIT): the accepted point is the result; 2 a disagreement that cannot be undone (the history has
@@ -434,13 +461,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     unsigned verdict = 0u;
                     if (!ok) { rk_fail(a, RK_ERR_HOST); verdict = 2u; }
                     else if ((unsigned)w != (unsigned)pred_word) {
-                        if ((unsigned)w & (unsigned)DV_QUIT) verdict = 1u;
+                        if ((unsigned)w & (unsigned)(DV_QUIT | DV_NEXT)) { verdict = 1u; ctlU[2] = (unsigned)w; }
                         else verdict = (run_kind == 2 && !((unsigned)w & (unsigned)(DV_ADVANCE | DV_INIT))) ? 3u : 2u;
                     }
-                    if (verdict == 2u) { rk_fail(a, RK_ERR_SPECULATION); __hip_atomic_store(&a.h_res[c].seq, ~(rk_u64)0, FRX_RLX_SYS); }
+                    if (verdict == 2u) { rk_fail(a, RK_ERR_SPECULATION); __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); }
                     if (verdict == 3u) {                                     // the whole command, word and step in one 16-byte read
                         rk_u64 w2 = 0, stp = 0;
-                        rk_load_cmd(a.h_cmd + c * a.cmd_stride, w2, stp);
+                        rk_load_cmd(a.h_cmd + k * a.cmd_stride, w2, stp);
                         ctlU[2] = (unsigned)w2; ctlD[5] = __longlong_as_double((long long)stp);
                         n_redone++;
                     }
@@ -456,11 +483,18 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
                     __syncthreads();
                     continue;
                 }
+                if (verdict == 1u && (ctlU[2] & (unsigned)DV_NEXT)) {           // the host stopped this plan and hands over the next candidate: the accepted
+                    for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }   // point is the result (the command decoder flushes x, g)
+                    if (t == 0) ctlU[1] = ctlU[2];
+                    have_cmd = true; ls_ok = false; lstage = 0;
+                    __syncthreads();
+                    continue;
+                }
                 if (verdict != 0u) {
                     if (verdict == 1u) flush(xp, gp); else flush(x, g);                     // host stopped: the accepted point is the result
                     rk_drain_and_meet();
                     pseq++;
-                    if (t == 0) __hip_atomic_store(a.phase + c * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT);
+                    if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT);
                     break;
                 }
             }
@@ -498,7 +532,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             }
             if (spec_ready) seq_pending = hseq;                             // nobody waits for the host's answer to this one: posted behind the next phase word (above)
             else if (t == 0) {
-                RoundRes *r = a.h_res + c;
+                RoundRes *r = a.h_res + k;
                 __hip_atomic_store((rk_u64 *)&r->f, (rk_u64)__double_as_longlong(ctlD[0]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->dg, (rk_u64)__double_as_longlong(ctlD[1]), FRX_RLX_SYS);
                 __hip_atomic_store((rk_u64 *)&r->xx, (rk_u64)__double_as_longlong(ctlD[2]), FRX_RLX_SYS);
@@ -512,7 +546,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
             RK_PROF(RK_P_POST);
         }
     }
-    if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+    if (PROF && a.prof && t < 16) a.prof[((size_t)k * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
     if (t == 0 && a.spec) { a.spec[c * 4] = n_pred_adv; a.spec[c * 4 + 1] = n_pred_trial; a.spec[c * 4 + 2] = n_redone; }
 }
 
@@ -520,9 +554,9 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, const RoundVi
 // MEMBERS (workgroups 1..G-1): history in registers, penalty share; the last one is also the dense workgroup
 // ============================================================================================================================
 template <int E, bool PROF>
-__device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
+__device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, const RoundLds &L, double *sm) {
     constexpr int CHT = 2 * E;
-    const int c = v.c, wg = v.wg, t = v.t, lane = v.lane, wave = v.wave, m = v.m;
+    const int k = v.k, wg = v.wg, t = v.t, lane = v.lane, wave = v.wave, m = v.m;
     const bool wt = v.wt;
     const int hg = wg - 1;                                                  // history chunk of this workgroup (workgroups 1 .. G-2)
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
@@ -541,7 +575,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             unsigned w = 0;
             bool ok = true;
             for (unsigned spins = 0;; spins++) {
-                w = __hip_atomic_load(a.phase + c * RK_WSTRIDE, FRX_RLX_AGENT);
+                w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 RK_PAUSE(a);
@@ -555,6 +589,12 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
         __syncthreads();
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
+        if (kind == PH_NEXT) {                                              // work queue: the cluster takes another candidate - the penalty share follows it
+            if (t == 0) ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP);
+            __syncthreads();
+            const int cn = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
+            v.c = cn; v.p0 = a.dp.poff[cn]; v.N = a.dp.poff[cn + 1] - v.p0;
+        }
         if (kind == PH_INIT) {                                              // this workgroup's chunk of the start point and its gradient: the first pair's "previous point"
             const int e0 = hg * CHT;
             for (int i = t; i < CHT; i += 256) { xpC[i] = ldg<true>(pub + e0 + i); gpC[i] = ldg<true>(pub + a.NXP + e0 + i); }
@@ -597,10 +637,10 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
             __syncthreads();
             for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)hg * 512 + o, pair[o] + pair[512 + o], wt);
             rk_drain_and_meet();
-            if (t == 0) __hip_atomic_fetch_add(a.cntA + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+            if (t == 0) __hip_atomic_fetch_add(a.cntA + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
             RK_PROF(RK_P_PASS_A);
             // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
-            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + c * RK_WSTRIDE, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
+            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + k * RK_WSTRIDE, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
             __syncthreads();
             RK_PROF(RK_P_WAIT_U);
             {
@@ -641,9 +681,9 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, wg); RK_PROF(RK_P_PENALTY); }
         // ---- report the end of this workgroup's part of the phase to the leader ----
         rk_drain_and_meet();
-        if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
     }
-    if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+    if (PROF && a.prof && t < 16) a.prof[((size_t)k * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }
 
 
@@ -658,7 +698,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, const RoundVi
 // ============================================================================================================================
 template <bool PROF>
 __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
-    const int c = v.c, t = v.t;
+    const int k = v.k, t = v.t;
     const bool wt = v.wt;
     const int nh = a.G - 2;                                                 // history workgroups
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);
@@ -680,7 +720,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             unsigned w = 0;
             bool ok = true;
             for (unsigned spins = 0;; spins++) {
-                w = __hip_atomic_load(a.phase + c * RK_WSTRIDE, FRX_RLX_AGENT);
+                w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 RK_PAUSE(a);
@@ -694,9 +734,15 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
         __syncthreads();
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
+        if (kind == PH_NEXT) {                                              // work queue: a new plan starts with an empty history
+#pragma unroll
+            for (int u = 0; u < 32; u++) { Ya[u] = 0.0; Yb[u] = 0.0; }
+            for (int i = L.Rf + t; i < L.mv + 512; i += 256) sm[i] = 0.0;
+            __syncthreads();
+        }
         if (kind == PH_ADV) {
             nadv++;
-            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); const bool ok = rk_wait_eq(a.cntA + c * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); const bool ok = rk_wait_eq(a.cntA + k * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
             __syncthreads();
             const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
             RK_PROF(RK_P_WAIT_PART);
@@ -796,7 +842,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             }
             if (t == 128) stg<true>(upub + 256, gamma, wt);
             rk_drain_and_meet();
-            if (t == 0) __hip_atomic_store(a.uflag + c * RK_WSTRIDE, nadv, FRX_RLX_AGENT);
+            if (t == 0) __hip_atomic_store(a.uflag + k * RK_WSTRIDE, nadv, FRX_RLX_AGENT);
             RK_PROF(RK_P_SOLVE);
             {   // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are) - behind the publication
                 const int uj = jnew - q0;
@@ -812,9 +858,9 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             RK_PROF(RK_P_VECTORS);                                          // (dense workgroup: Y^T Y update)
         }
         rk_drain_and_meet();
-        if (t == 0) __hip_atomic_fetch_add(a.cntL + c * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
     }
-    if (PROF && a.prof && t < 16) a.prof[((size_t)c * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
+    if (PROF && a.prof && t < 16) a.prof[((size_t)k * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }
 
 template <int E, bool PROF>
@@ -827,28 +873,29 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     // its members on one XCD switches its payload stores from write-through to plain (`wt`).
     const int lane8 = blockIdx.x & 7, rest = blockIdx.x >> 3;
     RoundView v;
-    v.wg = rest % a.G; v.c = lane8 + 8 * (rest / a.G);
+    v.wg = rest % a.G; v.k = lane8 + 8 * (rest / a.G);
     v.t = threadIdx.x; v.lane = v.t & 63; v.wave = v.t >> 6;
-    if (v.c >= a.B) return;                                               // grid is 8 G ceil(B / 8) blocks
+    if (v.k >= a.S) return;                                               // grid is 8 G ceil(S / 8) blocks
+    v.c = v.k;                                                            // cluster k starts on candidate k; with more candidates than clusters the host hands out the rest (DV_NEXT)
     v.m = a.m;
     const RoundLds L = round_lds(a.m, CHT, a.eval_doubles);
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
     v.xbase = a.dp.xoff[v.c]; v.n = a.dp.xoff[v.c + 1] - v.xbase;
     v.p0 = a.dp.poff[v.c]; v.N = a.dp.poff[v.c + 1] - v.p0;
-    v.pub = a.pubsyg + (size_t)v.c * (3 * a.NXP + 2); v.part = a.part + (size_t)v.c * a.G * 512; v.upub = a.upub + (size_t)v.c * 258; v.dpub = a.dpub + (size_t)v.c * a.NXP;
+    v.pub = a.pubsyg + (size_t)v.k * (3 * a.NXP + 2); v.part = a.part + (size_t)v.k * a.G * 512; v.upub = a.upub + (size_t)v.k * 258; v.dpub = a.dpub + (size_t)v.k * a.NXP;
     // ---- census: every workgroup of the launch must be resident before anybody waits for anybody ----
     if (v.t == 0) {
         unsigned my_xcc = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
         my_xcc = (my_xcc & 15u) + 1u;
-        __hip_atomic_store(a.xcc + v.c * a.G + v.wg, my_xcc, FRX_RLX_AGENT);
+        __hip_atomic_store(a.xcc + v.k * a.G + v.wg, my_xcc, FRX_RLX_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(a.census, 1u, FRX_RLX_AGENT);
         bool ok;
         {   // the census has its own, shorter bound: a chip that cannot host the whole grid at once is a configuration, not a fault
             const rk_u64 dl = wall_clock64() + a.census_ticks;
             for (unsigned spins = 0;; spins++) {
-                if (__hip_atomic_load(a.census, FRX_RLX_AGENT) == (unsigned)(a.B * a.G)) { ok = true; break; }
+                if (__hip_atomic_load(a.census, FRX_RLX_AGENT) == (unsigned)(a.S * a.G)) { ok = true; break; }
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -857,10 +904,10 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             // Tell the HOST, which can poll the mailboxes but not the status word: without this its service loop sat out the whole round
             // timeout (5 s against the 250 ms census bound) and frx_optimize failed hard instead of taking the per-stage path.
             rk_fail(a, RK_ERR_CENSUS);
-            if (v.wg == 0) __hip_atomic_store(&a.h_res[v.c].seq, ~(rk_u64)0, FRX_RLX_SYS);
+            if (v.wg == 0) __hip_atomic_store(&a.h_res[v.k].seq, ~(rk_u64)0, FRX_RLX_SYS);
         }
         bool same = ok;
-        for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + v.c * a.G + k, FRX_RLX_AGENT) == my_xcc;
+        for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + v.k * a.G + k, FRX_RLX_AGENT) == my_xcc;
         ctlU[0] = ok ? 1u : 0u;
         ctlU[3] = same ? 1u : 0u;
     }

@@ -294,11 +294,15 @@ int frx_optimize_stats(const frx_problem *p, double *out4);
  * How frx_optimize runs a plan on the device.  The reference's device side is ONE kernel that stays resident and is driven through
  * a mailbox in mapped host memory (cc.cu:51-64, 396-405, 454-466, 535-548); the default here has the same shape: the RESIDENT ROUND
  * KERNEL (csrc/frx_round_kernel.hpp) - one launch per plan, a cluster of workgroups per candidate, history of the L-BFGS in
- * registers, per-candidate command/result mailboxes - whenever the batch fits the chip (B x G workgroups <= CUs, mem_size <= 128).
- * Larger batches, and any launch on which a device-side wait expires, run one launch per stage and round (k_lbfgs_pre ->
- * k_forward_knot -> k_penalty -> k_backward_knot).  frx_problem_set_resident(p, 0) pins a handle to the per-stage rounds
- * (environment: FRX_RESIDENT=0).  frx_optimize_path reports what the last plan used (0 = per-stage rounds, G > 0 = resident kernel with G workgroups per candidate) and the resident
- * kernel's device-side status word (0 = clean; otherwise the code of the wait that expired).
+ * registers, per-cluster command/result mailboxes - whenever the batch fits the chip (B x G workgroups <= CUs, mem_size <= 128).
+ * A batch of up to a few times that many candidates runs on the same kernel through a WORK QUEUE: as many clusters as the chip holds
+ * stay resident, and a cluster whose candidate is finished is handed the next one of the batch instead of leaving.  Still larger
+ * batches, and any launch on which a device-side wait expires, run one launch per stage and round (k_lbfgs_pre -> k_forward_knot ->
+ * k_penalty -> k_backward_knot) - the faster form for many hundreds of candidates.  frx_problem_set_resident(p, 0) pins a handle to
+ * the per-stage rounds (environment: FRX_RESIDENT=0), 1 is the default just described, 2 takes the work queue for every batch that
+ * exceeds the chip (environment: FRX_RESIDENT_QUEUE=0|1 forbids / forces the queue).  frx_optimize_path reports what the last plan used
+ * (0 = per-stage rounds, G > 0 = resident kernel with G workgroups per candidate) and the resident kernel's device-side status word
+ * (0 = clean; otherwise the code of the wait that expired).
  */
 int frx_problem_set_resident(frx_problem *p, int enable);
 int frx_optimize_path(const frx_problem *p, int *resident_used, unsigned *device_status);

@@ -38,6 +38,8 @@ int frx_debug_direction_log_read(const frx_problem *p, int cand, double *out, in
  * other than the iteration limit, and how many of them were re-run. */
 int frx_debug_set_resident_retry(frx_problem *p, int enable);
 int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried);
+/* Clusters of the last resident plan: = batch size when the batch fitted the chip, fewer when the candidates went through the work queue. */
+int frx_debug_resident_clusters(const frx_problem *p, int *clusters);
 /* The leader of a cluster runs the host's line-search state machine in step with it and starts on the command it expects (ADVANCE after an
  * accepted trial, or the search's next trial step) before the host's answer arrives; every prediction is checked against the command the
  * host really sent.  out3 = {rounds started on a predicted ADVANCE, rounds started on a predicted trial step, predictions the host's command

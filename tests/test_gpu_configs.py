@@ -57,7 +57,7 @@ def _device_plans(frx, sc, cands, kappa, tol, batch=32):
     return out
 
 
-def _share_check(frx, sc, ob, cands, kappa, label):
+def _share_check(frx, sc, ob, cands, kappa, label, queue=False):
     tol = sc.ZHANGJIAJIE["opt_rel_tol"]
     r = _device_plans(frx, sc, cands, kappa, tol)
     assert min(r["resident"]) >= 3 and r["resident_retried"] == 0          # every batch ran on the resident round kernel, once
@@ -97,6 +97,18 @@ def _share_check(frx, sc, ob, cands, kappa, label):
                "cpu_vs_cpu_objective_spread": {"median": float(np.median(spread)), "p95": float(np.percentile(spread, 95)), "max": float(spread.max())},
                "device_vs_cpu_objective": {"median": float(np.median(dev)), "p95": float(np.percentile(dev, 95)), "max": float(dev.max())},
                "plan_ms": r["ms_total"], "rounds": r["rounds"]}
+    if queue:
+        # the same share as ONE batch through the resident kernel's work queue (as many clusters as the chip holds; a cluster whose candidate is
+        # finished is handed the next one): a candidate's plan does not depend on the cluster that runs it or on what ran there before
+        prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+        prob.set_resident(2)
+        q = prob.optimize(tol)
+        prob.close()
+        assert q["device_status"] == 0 and q["resident"] == min(r["resident"]) and 0 < q["clusters"] < len(cands), (q["resident"], q["clusters"])
+        assert np.array_equal(q["status"], r["status"]) and np.array_equal(q["objective"], r["objective"])
+        assert q["resident_failed"] == r["resident_failed"] and q["resident_retried"] == 0
+        summary["work_queue"] = {"clusters": q["clusters"], "plan_ms": q["ms_total"], "plans_per_s": 1e3 * len(cands) / q["ms_total"],
+                                 "batches_of_32_plan_ms": r["ms_total"], "commands_of_the_busiest_cluster": q["rounds"], "statuses_and_objectives_equal_the_batches": True}
     print(json.dumps(summary))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"share_{label}.json"), "w"), indent=1)
@@ -119,10 +131,11 @@ def test_config3_share_of_one_gpu(frx, sc, ob):
 def test_config4_share_of_one_gpu(frx, sc, ob):
     """BASELINE.json configs[4]: Monte-Carlo sweep, independent scenarios; 128 of one GPU's 512 (ids 64..191, which include the
     infeasible scenario 170), run as four resident batches of 32: the reference's verdict (LBFGS status) reproduced for every scenario
-    by the resident kernel itself, objectives inside the CPU-vs-CPU' envelope."""
+    by the resident kernel itself, objectives inside the CPU-vs-CPU' envelope; then as one batch of 128 through the resident kernel's work
+    queue: bit-identical verdicts and objectives."""
     B, N, gates, kappa = sc.CONFIGS["montecarlo4096"]
     cands = [sc.make_candidate(64 + b, N, gates) for b in range(128)]
-    s = _share_check(frx, sc, ob, cands, kappa, "montecarlo4096_128")
+    s = _share_check(frx, sc, ob, cands, kappa, "montecarlo4096_128", queue=True)
     assert s["failed_on_cpu"] >= 1                        # the share does contain an infeasible scenario
 
 

@@ -142,17 +142,64 @@ def test_resident_plans_end_like_per_stage_plans(frx, sc):
     prob.close()
 
 
-def test_batches_that_do_not_fit_the_chip_or_are_too_small_take_the_per_stage_path(frx, sc):
+def test_batches_larger_than_the_chip_take_the_work_queue_and_small_problems_the_per_stage_path(frx, sc, monkeypatch):
     cands = [sc.make_candidate(7, 32, 8, perturb_id=i) for i in range(70)]        # 70 clusters x >= 5 workgroups > 256 CUs
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
     r = prob.optimize(1e-5, max_iterations=30)
-    assert r["resident"] == 0 and np.all(np.isfinite(r["objective"]))
+    assert r["resident"] >= 3 and 0 < r["clusters"] < 70 and r["device_status"] == 0 and np.all(np.isfinite(r["objective"]))
+    monkeypatch.setenv("FRX_RESIDENT_QUEUE", "0")                                 # the same batch, one launch per stage and round
+    s = prob.optimize(1e-5, max_iterations=30)
+    monkeypatch.delenv("FRX_RESIDENT_QUEUE")
+    assert s["resident"] == 0 and np.array_equal(s["status"], r["status"]) and np.array_equal(s["evals"], r["evals"])
+    assert np.max(np.abs(s["objective"] - r["objective"]) / np.abs(s["objective"])) < 1e-6
     prob.close()
     # fewer variables than twice the history length: the compact representation would invert an ill-conditioned R (frx_api.cpp)
     small = frx.Problem(sc.make_batch(2, 2, 5, 1), sc.ZHANGJIAJIE, qd_intervals=8)
     r = small.optimize(1e-6)
     assert r["resident"] == 0 and np.all(r["status"] >= 0)
     small.close()
+
+
+def test_work_queue_plans_do_not_depend_on_the_cluster_that_runs_them(frx, sc, monkeypatch):
+    """Seven candidates of DIFFERENT length on two clusters (FRX_RESIDENT_CLUSTERS): every cluster takes several candidates one after the
+    other - longer after shorter and shorter after longer (the zero padding of the cluster's exchange buffers), a history that starts
+    empty again - and every plan is bit for bit the plan of the same candidate on a cluster of its own."""
+    Ns = [64, 40, 56, 64, 48, 36, 64]
+    cands = [sc.make_candidate(20 + b, Ns[b], 8) for b in range(len(Ns))]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    a = _plan(prob, tol, True)
+    assert a["resident"] >= 3 and a["clusters"] == len(Ns) and a["device_status"] == 0
+    for clusters in (2, 3):
+        monkeypatch.setenv("FRX_RESIDENT_CLUSTERS", str(clusters))
+        q = _plan(prob, tol, True)
+        monkeypatch.delenv("FRX_RESIDENT_CLUSTERS")
+        assert q["resident"] == a["resident"] and q["clusters"] == clusters and q["device_status"] == 0
+        for key in ("x", "status", "iters", "evals", "objective"):
+            assert np.array_equal(q[key], a[key]), key
+        adv, trial, redone = q["predictions"]
+        assert (adv, trial, redone) == tuple(a["predictions"]) and redone == 0
+    prob.close()
+
+
+def test_work_queue_at_the_headline_size(frx, sc):
+    """40 headline candidates = the chip's 32 clusters + 8 through the queue; the same plans as a batch of 32 and a batch of 8."""
+    B, N, gates, kappa = 40, 64, 16, 16
+    cands = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)]
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    q = prob.optimize(tol)
+    prob.close()
+    assert q["resident"] >= 3 and q["clusters"] == 32 and q["device_status"] == 0
+    parts = []
+    for lo, hi in ((0, 32), (32, 40)):
+        pb = frx.Problem(cands[lo:hi], sc.ZHANGJIAJIE, qd_intervals=kappa)
+        parts.append(pb.optimize(tol))
+        pb.close()
+        assert parts[-1]["resident"] == q["resident"]
+    for key in ("x", "status", "evals", "objective"):
+        assert np.array_equal(q[key], np.concatenate([r[key] for r in parts])), key
+    print(json.dumps({"queue_ms": q["ms_total"], "batches_ms": [r["ms_total"] for r in parts], "evals_max": int(q["evals"].max()), "evals_mean": float(q["evals"].mean())}))
 
 
 def test_resident_kernel_handles_failing_and_finishing_candidates(frx, sc, ob):
