@@ -615,8 +615,8 @@ int frx_problem_set_solver(frx_problem *p, int solver) {
 int frx_profile_phases(frx_problem *p, const double *x, long long *out32) {
     if (!p || !x || !out32) return fail(FRX_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
-    if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(32));
-    HIP_TRY(hipMemset(p->d_stamps.p, 0, 32 * sizeof(long long)));
+    if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(64));
+    HIP_TRY(hipMemset(p->d_stamps.p, 0, 64 * sizeof(long long)));
     std::vector<double> f(p->B), g(p->NX);
     int rc = frx_objective_eval(p, x, f.data(), g.data());          // warm
     if (rc != FRX_OK) return rc;
@@ -1107,7 +1107,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (S < 1) return 1;
     if (S < B) {
         const char *qe = std::getenv("FRX_RESIDENT_QUEUE");
-        const int queue_max = [] { const char *e = std::getenv("FRX_RESIDENT_QUEUE_MAX"); return e ? std::atoi(e) : 4; }();   // x capacity
+        const int queue_max = [] { const char *e = std::getenv("FRX_RESIDENT_QUEUE_MAX"); return e ? std::atoi(e) : 3; }();   // x capacity (measured: queue 484 ms against 498 ms per stage at 96 = 3 x 32 candidates, 626 against 514 at 128)
         const bool allowed = qe ? qe[0] != '0' : (ce || p->resident_mode == 2 || B <= queue_max * S);
         if (!allowed) return 1;
     }
@@ -1158,6 +1158,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.S = S; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
+    { const char *sr = std::getenv("FRX_RESIDENT_STAMP_ROUND"); rl.stamp_round = want_prof && sr ? std::max(0, std::atoi(sr)) : 0; }
     rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;
     {   // What the leader expects of the host (frx_round_kernel.hpp): 0 nothing, it waits for every command; 1 the acceptance of a trial (ADVANCE, next
         // slot, step 1: lbfgs.hpp:1418); 2 also the next trial step of a running search (default).  Every expectation is checked against the host's
@@ -1169,9 +1170,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         rl.speculate = (pm.min_step <= 1.0 && 1.0 <= pm.max_step) ? level : 0;         // the predicted ADVANCE carries step 1 (lbfgs.hpp:1418)
     }
     struct StampGuard { frx_problem *q; ~StampGuard() { q->dp.stamps = nullptr; } } stamp_guard{p};
-    if (want_prof) {                                                                  // phase stamps of candidate 0's forward / adjoint bodies (last evaluation)
-        if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(32));
-        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, 32 * sizeof(long long), p->stream));
+    const bool want_stamps = want_prof && std::getenv("FRX_RESIDENT_PROF")[0] != '2';   // FRX_RESIDENT_PROF=2: segment times only (the stamps' stores perturb what they measure)
+    if (want_prof && !want_stamps && p->d_stamps.p) HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, 64 * sizeof(long long), p->stream));
+    if (want_stamps) {                                                                // phase stamps of candidate 0's forward / adjoint bodies (last evaluation)
+        if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(64));
+        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, 64 * sizeof(long long), p->stream));
         p->dp.stamps = p->d_stamps.p;
     }
 
@@ -1316,6 +1319,21 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         HIP_TRY(hipMemcpy(sc.data(), p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * S + 2 + (size_t)S * G, sizeof(unsigned) * sc.size(), hipMemcpyDeviceToHost));
         for (int q = 0; q < 4; q++) { p->spec_counts[q] = 0; for (int b = 0; b < B; b++) p->spec_counts[q] += sc[4 * (size_t)b + q]; }
     }
+    if (std::getenv("FRX_RESIDENT_HOST_STATS")) {                                     // diagnostic: where the workgroups of every cluster ran (XCC id of each)
+        std::vector<unsigned> xc((size_t)S * G, 0u);
+        HIP_TRY(hipMemcpy(xc.data(), p->d_rwords.p + (size_t)frx::ROUND_WORDS_PER_CAND * S + 2, sizeof(unsigned) * xc.size(), hipMemcpyDeviceToHost));
+        int one_xcd = 0;
+        std::string line;
+        for (int k = 0; k < S; k++) {
+            bool same = true;
+            for (int w = 1; w < G; w++) same = same && xc[(size_t)k * G + w] == xc[(size_t)k * G];
+            one_xcd += same ? 1 : 0;
+            line += " [";
+            for (int w = 0; w < G; w++) line += std::to_string((int)xc[(size_t)k * G + w] - 1);
+            line += "]";
+        }
+        std::fprintf(stderr, "[frx] clusters on one XCD: %d of %d;%s\n", one_xcd, S, line.c_str());
+    }
     if (want_dbg) {
         p->dirlog.resize(log_doubles);
         HIP_TRY(hipMemcpy(p->dirlog.data(), p->d_rdbg.p, sizeof(double) * log_doubles, hipMemcpyDeviceToHost));
@@ -1329,7 +1347,8 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (want_prof) {
         p->rprof.resize((size_t)S * (G + 1) * 16 + 32);                                // [S][G][16] segment sums, [S][16] host-wait histogram; the last 32 words: the bodies' cycle stamps
         HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)S * (G + 1) * 16, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)S * (G + 1) * 16, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+        if (!p->d_stamps.p) { HIP_TRY(p->d_stamps.alloc(64)); HIP_TRY(hipMemset(p->d_stamps.p, 0, 64 * sizeof(long long))); }
+        HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)S * (G + 1) * 16, p->d_stamps.p + (rl.stamp_round > 0 ? 32 : 0), 32 * sizeof(long long), hipMemcpyDeviceToHost));   // the last evaluation's stamps, or those of evaluation FRX_RESIDENT_STAMP_ROUND
     }
     for (int b = 0; b < B; b++)
         if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) p->resident_failed++;

@@ -35,7 +35,7 @@ struct DevProblem {
     const int *cand_active, *piece_active;
     double *wq_glob;                          // [number of waypoints][4] scratch: {|xi|^2, sum_a V_a xi_a^2} per waypoint, written by the forward map and read by the
                                               // adjoint of the same evaluation (stage kernels; the resident kernel keeps them in LDS, ResidentOps::wq)
-    long long *stamps;                        // optional (null): s_memtime stamps of candidate 0's phases, [2][16] (frx_profile_phases)
+    long long *stamps;                        // optional (null): s_memtime stamps of candidate 0's phases, [2][16] (frx_profile_phases); the resident kernel keeps a second copy of one chosen evaluation behind them ([64])
 };
 
 enum { SOLVER_KNOT_PCR = 0, SOLVER_BANDED_LU = 1 };
@@ -93,7 +93,8 @@ struct RoundLaunch {
     int dbg_cap = 0, dbg_cands = 0;                                 // direction log (dbg): [B] counts + dbg_cands x dbg_cap records of 4 NXP + 2 doubles
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20, ls_xtol = 1e-16;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;
-    int cmd_stride = 4;                                            // h_cmd: candidate b's 16-byte command at 16 * cmd_stride * b
+    int cmd_stride = 4;                                            // h_cmd: cluster k's 16-byte command at 16 * cmd_stride * k
+    int stamp_round = 0;                                           // profiling: keep the cycle stamps of cluster 0's evaluation number stamp_round (0: of its last one)
 };
 enum { ROUND_E = 56, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)

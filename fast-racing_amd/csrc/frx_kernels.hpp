@@ -961,6 +961,9 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     // Every global read of the kernel is issued here, before the first barrier, so the whole kernel pays ONE memory
     // latency (loads placed in later phases cannot be hoisted over the barriers by the compiler: measured +4 us).
     int r_pc = 0, r_piv = 1, r_wnv = 1, r_wvb = 0, r_wxb = 0;
+    // (first vertex of this candidate: the compiler fetches dp.* through VECTOR loads - it cannot prove that nothing in the kernel writes
+    // there - and where the expression stood in the waypoint loops below, each axis wave paid a trip to L2 in the middle of its chain)
+    const int cv0 = __builtin_amdgcn_readfirstlane(dp.cvoff[b]);
     double r_bs[6] = {0, 0, 0, 0, 0, 0};
     if (k < N) { r_pc = dp.piece_coarse[p0 + k]; r_piv = dp.piece_iv[p0 + k]; }
     // waypoint w is handled by the quad k >> 2 - or, when wave 0 is the free-running matrix wave (wsp64 below), by the PAIR (k - 64) >> 1
@@ -1037,7 +1040,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                     int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;          // prefetched for the first (usually only) pass
                     if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
                     const int nv1 = wnv - 1;
-                    V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
+                    V = vs + 3 * (wvb - cv0) + (ro ? ro->vskew * w : 0);
                     xi = xs + (wxb - x0);
                     for (int a0 = sub; a0 < nv1; a0 += 8) {               // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
                         double xv[4], v0[4], v1[4], v2[4];
@@ -1154,7 +1157,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;                  // prefetched for the first (usually only) pass
             if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
             nv1 = wnv - 1;
-            V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
+            V = vs + 3 * (wvb - cv0) + (ro ? ro->vskew * w : 0);
             xi = xs + (wxb - x0);
             for (int a = sub; a < nv1; a += 4) {
                 const double x2 = xi[a] * xi[a];
@@ -1279,6 +1282,12 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     bool gwt = true;
     if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; pw = ro->pw; gs = ro->gs; gpub = ro->gpub; gwt = ro->gwt; }
     const int pws = nsteps * 8 + 5;
+    // A resident caller that reads the host's command word while this body runs (tap.early_cmd) must find thread 0's wave WITHOUT stores of
+    // its own behind that read: vmcnt retires in order and the compiler can only wait for the read with vmcnt(0), i.e. for the acknowledgement
+    // of every younger store as well - measured as 1.2 us at the end of the adjoint with four clusters on an XCD, time the leader otherwise
+    // spends on the line search before its next publication drains them anyway.  The time gradient's copy for the cluster (`gpub`) is
+    // therefore stored by wave 1 from the LDS copy, behind the last barrier.
+    const bool defer_time_gpub = gs != nullptr && gpub != nullptr && tap.early_cmd != nullptr;
     const bool tapped = tap.d != nullptr;
     const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
     double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
@@ -1287,7 +1296,8 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     const bool piece = kk < N;
     const int kp = piece ? kk : 0;                      // clamped piece index: loads are unconditional, results of lanes without a piece unused
     double h, o0 = 0.0, o1 = 0.0, c9[9], cq[6], cbq[6], r_tl[3] = {0, 0, 0};
-    int r_wnv = 1, r_wvb = 0, r_wxb = 0;
+    int r_wnv = 1, r_wvb = 0, r_wxb = 0, r_iv = 1, r_fb = 0;
+    const int cv0 = __builtin_amdgcn_readfirstlane(dp.cvoff[b]);     // (up here with the other loads: see forward_knot_body)
     double2 r_wq0 = make_double2(0.0, 0.0), r_wq1 = r_wq0;   // the forward map's sums of this pair's waypoint (stage kernels: through dp.wq_glob)
     {
         const double *ci = Cin + (size_t)(p0 + kp) * 18;
@@ -1295,6 +1305,9 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         h = ct_lds ? ct_lds[kp * 19 + 18] : ldg<SH>(Tin + p0 + kp);
         if (wave == 0) {
             o0 = ldg<SH>(o); o1 = ldg<SH>(o + 1);
+            // (the coarse-interval table of mergeToCoarseGradT too: loaded behind the barrier below, these two sat BEHIND the resident
+            // caller's read of the host's command word - vmcnt retires in order - and wave 0 waited out a PCIe round trip for them)
+            if (kk < cN) { r_iv = dp.coarse_iv[c0 + kk]; r_fb = dp.coarse_fbeg[c0 + kk] - p0; }
 #pragma unroll
             for (int q = 0; q < 9; q++) c9[q] = ct_lds ? ct_lds[kp * 19 + 9 + q] : ldg<SH>(ci + 9 + q);
         } else {
@@ -1346,6 +1359,12 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             costAcc = o0 + (36.0 * s33 * t1 + 144.0 * s43 * t2_ + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
             gTl = o1 + (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2_ + 720.0 * s53 * t2_ + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
         }
+        // Every load of this wave has to have LANDED before the read over PCIe is issued, and no later instruction may wait on vmcnt: the
+        // compiler waits for a loaded register at its first use, with vmcnt(0) when a conditional load may lie in between - for the
+        // coarse-interval table that use is the merge loop behind the barrier below, and the wait took the host read's round trip with it
+        // (s_waitcnt vmcnt(0) in front of the loop in the ISA, even with the values passed through an in/out asm).  The table entry
+        // therefore travels through LDS: lane kk parks it in gCo[kk], which the same lane overwrites with its result.
+        if (kk < cN) gCo[kk] = (double)(r_iv + (r_fb << 10));
         if (tap.early_cmd && k == 0) early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // behind the wave's first loads (see LineSearchTap)
     } else {
         const int ax = wave - 1;
@@ -1432,8 +1451,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         double sumTc = 0.0;
         if (kk < cN) {
-            const int gc = c0 + kk;
-            const int iv = dp.coarse_iv[gc], fb = dp.coarse_fbeg[gc] - p0;
+            const int packed = (int)gCo[kk], iv = packed & 1023, fb = packed >> 10;   // (parked above: see the note at the host read)
             double sg = 0.0, tt = 0.0;
             for (int a = 0; a < iv; a++) { sg += gT[fb + a]; tt += Tf[fb + a]; }
             gCo[kk] = sg / iv;
@@ -1446,7 +1464,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             if (kk < cN) {
                 const double gi = gCo[kk] * dT_dtau(xs[kk], dp.c2 != 0);
                 if (gs) gs[kk] = gi; else g[x0 + kk] = gi;
-                if (gpub) stg<SH>(gpub + kk, gi, gwt);
+                if (gpub && !defer_time_gpub) stg<SH>(gpub + kk, gi, gwt);
                 if (tapped) { t_dg += gi * dsv[kk]; t_xx += xs[kk] * xs[kk]; t_gg += gi * gi; }
             }
         } else {
@@ -1465,7 +1483,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                     const double de = dT_dtau(xs[i], dp.c2 != 0);
                     const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
                     if (gs) gs[i] = gi; else g[x0 + i] = gi;
-                    if (gpub) stg<SH>(gpub + i, gi, gwt);
+                    if (gpub && !defer_time_gpub) stg<SH>(gpub + i, gi, gwt);
                     if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
                 }
             }
@@ -1482,7 +1500,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                 int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
                 if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
                 nv1 = wnv - 1; xb = wxb;
-                V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
+                V = vs + 3 * (wvb - cv0) + (ro ? ro->vskew * w : 0);
                 xi = xs + (xb - x0);
                 g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
             }
@@ -1536,6 +1554,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         double *red3 = rowbuf;                                        // the row buffer is not used by this path
         if ((k & 63) == 0) { red3[w] = w0; red3[nw + w] = w1; red3[2 * nw + w] = w2; }
         __syncthreads();
+        if (defer_time_gpub && wave == 1 && kk < (dp.soft ? cN : cN - 1)) stg<SH>(gpub + kk, gs[kk], gwt);   // (see defer_time_gpub)
         if (k == 0 && ((tap_flags & DV_EVAL) || tap.lds_out)) {
             const double fval = red[0];
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -1586,6 +1605,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     // all global reads up front (see k_forward_knot)
     double h = 1.0, c[18], cb[18], o0 = 0.0, o1 = 0.0, r_tl[3] = {0, 0, 0};
     int r_wnv = 1, r_wvb = 0, r_wxb = 0;
+    const int cv0 = __builtin_amdgcn_readfirstlane(dp.cvoff[b]);
     if (k < N) {
         const double *ci = Cin + (size_t)(p0 + k) * 18;
         const double *o = out20 + (size_t)(p0 + k) * 20;
@@ -1810,7 +1830,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
             int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
             if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
             nv1 = wnv - 1; xb = wxb;
-            V = vs + 3 * (wvb - dp.cvoff[b]) + (ro ? ro->vskew * w : 0);
+            V = vs + 3 * (wvb - cv0) + (ro ? ro->vskew * w : 0);
             xi = xs + (xb - x0);
             g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
             for (int a = sub; a < nv1; a += 4) qn += xi[a] * xi[a];

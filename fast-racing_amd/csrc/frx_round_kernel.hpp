@@ -103,6 +103,7 @@ struct RoundArgs {
     unsigned *spec;                                      // [B][4] counters: rounds started on a predicted ADVANCE / on a predicted trial step, predictions the host's command did not confirm (redone), reserved
     int ls_max_linesearch, speculate;
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
+    int stamp_round;                                                  // PROF: the stamps of cluster 0's evaluation number stamp_round are kept in dp.stamps[32 .. 63]
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
     int B, S, G, m, NXP, eval_doubles, ct_doubles;                    // B candidates, S <= B clusters (S < B: work queue, DV_NEXT);                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
@@ -367,13 +368,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 continue;
             }
         }
-        if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
+        if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
+        if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
         pseq++;
         if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
-        if (PROF && a.dp.stamps && c == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
+        if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
         if (seq_pending != 0) {
             // The result of the round whose acceptance the leader predicted goes to the host only NOW, behind the phase word of the step it
             // started: posted right after the adjoint (round 2), its five stores to host memory sat in front of this publication's drain -
@@ -445,6 +446,14 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
+            if (PROF && a.dp.stamps && k == 0 && t == 0) a.dp.stamps[18] = (long long)__builtin_readcyclecounter();   // (18 .. 21: the leader's work behind the adjoint)
+            if (PROF && a.dp.stamps && a.poll_sleep == 3 && t == 0) {          // experiment (FRX_RESIDENT_POLL=3 + profile): one extra, TIMED read of the command word per round
+                const rk_u64 q0 = wall_clock64();
+                rk_u64 w_ = 0, s_ = 0;
+                rk_load_cmd(a.h_cmd + k * a.cmd_stride, w_, s_);
+                const rk_u64 dq = wall_clock64() - q0;
+                if (k == 0) { a.dp.stamps[19] += (long long)dq; a.dp.stamps[20] += 1; if ((long long)dq > a.dp.stamps[21]) a.dp.stamps[21] = (long long)dq; }
+            }
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
                     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
@@ -543,6 +552,11 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             }
             lstage = 0;
             __syncthreads();
+            if (PROF && a.dp.stamps && k == 0 && a.stamp_round > 0 && hseq == (rk_u64)a.stamp_round) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t < 32) a.dp.stamps[32 + t] = (long long)__hip_atomic_load((unsigned long long *)a.dp.stamps + t, FRX_RLX_AGENT);
+            }
             RK_PROF(RK_P_POST);
         }
     }

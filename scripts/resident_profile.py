@@ -14,7 +14,7 @@ cands = [sc.make_candidate(0, N, N // 4, perturb_id=b) for b in range(B)]
 prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
 x0 = prob.initial_guess()
 prob.optimize(1e-6, x0=x0, max_iterations=20)                     # warm
-os.environ["FRX_RESIDENT_PROF"] = "1"
+os.environ["FRX_RESIDENT_PROF"] = os.environ.get("FRX_PROFILE_MODE", "1")      # 2: segment times without the bodies' cycle stamps
 r = prob.optimize(1e-6, x0=x0, max_iterations=iters)
 del os.environ["FRX_RESIDENT_PROF"]
 pr = prob.resident_profile()
@@ -34,6 +34,8 @@ st = prob.last_stamps
 rel = lambda idx, base: {str(i): int(st[i] - st[base]) for i in idx if st[i] > 0}
 out["forward_stamps"] = {"matrix_wave": rel([1, 2, 5, 6], 0), "axis_wave": rel([8, 9, 10, 11, 12], 0), "publication (leader thread 0: before its drain, drained, phase word stored)": rel([13, 14, 15], 0)}
 out["adjoint_stamps"] = {"wave0": rel([17, 22, 23, 24], 16), "axis_wave": rel([25, 26, 27, 28, 30, 31, 29], 16)}
+if os.environ.get("FRX_RESIDENT_POLL") == "3" and st[20] > 0:           # experiment: an extra, timed 16-byte read of the command mailbox per round (leader 0)
+    out["timed_host_read_us"] = {"mean": float(st[19]) / float(st[20]) / 100.0, "max": float(st[21]) / 100.0, "reads": int(st[20])}
 print(json.dumps(out, indent=1))
 prob.set_resident(False)
 r2 = prob.optimize(1e-6, x0=x0, max_iterations=iters)
