@@ -113,7 +113,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms
     a.ls_ftol = r.ls_ftol; a.ls_gtol = r.ls_gtol; a.ls_min_step = r.ls_min_step; a.ls_max_step = r.ls_max_step; a.ls_xtol = r.ls_xtol; a.ls_max_linesearch = r.ls_max_linesearch; a.speculate = r.speculate;
     { static const int ps = [] { const char *e = std::getenv("FRX_RESIDENT_POLL"); return e ? std::atoi(e) : 0; }(); a.poll_sleep = ps < 0 ? 0 : ps > 4 ? 4 : ps; }
-    a.cmd_stride = r.cmd_stride; a.stamp_round = r.stamp_round;
+    a.cmd_stride = r.cmd_stride; a.stamp_round = r.stamp_round; a.fast_control = r.fast_control;
     a.B = r.B; a.S = r.S; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g); a.maxN19 = g.maxN * 19;
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;

@@ -94,6 +94,7 @@ struct RoundLaunch {
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20, ls_xtol = 1e-16;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)
     int ls_max_linesearch = 40, speculate = 1;
     int cmd_stride = 4;                                            // h_cmd: cluster k's 16-byte command at 16 * cmd_stride * k
+    int fast_control = 1;                                          // see RoundArgs
     int stamp_round = 0;                                           // profiling: keep the cycle stamps of cluster 0's evaluation number stamp_round (0: of its last one)
 };
 enum { ROUND_E = 56, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel

@@ -136,6 +136,20 @@ public:
         return PENDING;
     }
 
+    // What mt_begin followed by ONE mt_feed decides for the first trial of a search when that trial is ACCEPTED, on their operands in their
+    // order: true exactly when mt_begin(pm, step0, f0, dginit0) == 0 and the mt_feed(pm, f, dg) after it returns 1 (= count) - for a step
+    // strictly between min_step and max_step (the caller's precondition; the tests on those two and on a bracket cannot fire then).  The
+    // leader of the resident round kernel asks this first: four rounds in five end this way and the state machine need not run at all
+    // (tests/test_lbfgs.py checks the equivalence on the host).
+    FRX_LS_HD static bool first_trial_accepted(const frx_lbfgs_params &pm, double step0, double f0, double dginit0, double f, double dg) { FRX_LS_NO_CONTRACT
+        if (!(step0 > 0.) || 0 < dginit0) return false;                    // mt_begin's two refusals
+        const double dgtest = pm.f_dec_coeff * dginit0;
+        const double ftest1 = f0 + step0 * dgtest;
+        if (std::isinf(f) || std::isnan(f)) return false;
+        if (pm.max_linesearch <= 1) return false;
+        return f <= ftest1 && std::fabs(dg) <= pm.s_curv_coeff * (-dginit0);
+    }
+
     FRX_LS_HD int bt_begin(double step0, double f0, double dginit0, const frx_lbfgs_params &pm) { FRX_LS_NO_CONTRACT      // lbfgs.hpp:954-974
         count = 0;
         stp = step0;

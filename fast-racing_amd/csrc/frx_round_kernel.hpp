@@ -103,6 +103,7 @@ struct RoundArgs {
     unsigned *spec;                                      // [B][4] counters: rounds started on a predicted ADVANCE / on a predicted trial step, predictions the host's command did not confirm (redone), reserved
     int ls_max_linesearch, speculate;
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
+    int fast_control;                                                 // 1 (default): barrier-free confirmation and the first-trial shortcut of the prediction; 0: the long forms (A/B measurements)
     int stamp_round;                                                  // PROF: the stamps of cluster 0's evaluation number stamp_round are kept in dp.stamps[32 .. 63]
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
@@ -369,9 +370,11 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             }
         }
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
+        RK_PROF(RK_P_DENSE_IN);                                             // (leader: command decoded / accepted step taken over)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
+        RK_PROF(RK_P_SOLVE);                                                // (leader: drain of this phase's publications)
         pseq++;
         if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
@@ -454,6 +457,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 const rk_u64 dq = wall_clock64() - q0;
                 if (k == 0) { a.dp.stamps[19] += (long long)dq; a.dp.stamps[20] += 1; if ((long long)dq > a.dp.stamps[21]) a.dp.stamps[21] = (long long)dq; }
             }
+            if (unconfirmed) {
+                // Common case first, without a barrier: the word thread 0 read while the adjoint ran (ctlD[7], in LDS behind the adjoint's last
+                // barrier) is this round's command and equals the predicted one - every thread sees the same word and decides alike.
+                const rk_u64 we = (rk_u64)__double_as_longlong(ctlD[7]);
+                if (a.fast_control && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word) unconfirmed = false;
+            }
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
                     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
@@ -507,6 +516,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     break;
                 }
             }
+            RK_PROF(RK_P_PASS_A);                                           // (leader: confirmation of the command this round ran on)
             // Prediction of the host's next command.  The host feeds (f, g.d) of this trial to its More-Thuente search (SolverDV::feed ->
             // LineSearch::mt_begin / mt_feed, lbfgs.hpp:743-935) and answers with either ADVANCE | TRIAL | EVAL, next slot, step 1 (the trial is
             // accepted: lbfgs.hpp:1418) or TRIAL | EVAL with the search's next step.  Every thread of the leader runs the SAME search object on the
@@ -517,11 +527,21 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             pred_kind = 0;
             if (a.speculate) {
                 const double fv = ctlD[0], dgv = ctlD[1];
+                bool accepted_first = false;
                 if (flags & (DV_ADVANCE | DV_INIT)) {                       // first trial of a new search: the host begins it with the slope at its start (lbfgs.hpp:756; d = -g after INIT)
                     const double dgi = (flags & DV_ADVANCE) ? ctlD[4] : -gg0;
-                    ls_ok = step != a.ls_min_step && step != a.ls_max_step && ls.mt_begin(lpm, step, f_acc, dgi) == 0;
+                    // An ACCEPTED first trial - four rounds in five - is recognised without running the search object (LineSearch::
+                    // first_trial_accepted: mt_begin's and mt_feed's own tests on their own operands); it is not needed afterwards, the
+                    // next search begins from scratch.  The state machine runs only when this test says no.
+                    const bool plain = step != a.ls_min_step && step != a.ls_max_step;
+                    accepted_first = a.fast_control && plain && LineSearch::first_trial_accepted(lpm, step, f_acc, dgi, fv, dgv);
+                    ls_ok = !accepted_first && plain && ls.mt_begin(lpm, step, f_acc, dgi) == 0;
                 }
-                if (ls_ok) {
+                if (accepted_first) {
+                    const int nslot = last_slot < 0 ? 0 : (last_slot + 1 == v.m ? 0 : last_slot + 1), nbound = min(v.m, last_bound + 1);
+                    pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL | DV_STEP_IS_ONE);
+                    pred_kind = 1; spec_ready = true;
+                } else if (ls_ok) {
                     const int rc = ls.mt_feed(lpm, fv, dgv);
                     if (rc == LineSearch::PENDING) {
                         if (a.speculate >= 2) {                             // (level 1 follows the search without starting on its next step: see optimize_resident)
@@ -539,6 +559,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     }
                 }
             }
+            RK_PROF(RK_P_WAIT_PART);                                        // (leader: the line search's next command)
             if (spec_ready) seq_pending = hseq;                             // nobody waits for the host's answer to this one: posted behind the next phase word (above)
             else if (t == 0) {
                 RoundRes *r = a.h_res + k;

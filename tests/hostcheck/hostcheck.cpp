@@ -220,3 +220,15 @@ extern "C" int hostcheck_lbfgs_dv(int n, double *x, double *fx_out, double (*fn)
     if (evals) *evals = sv.evaluations();
     return sv.status();
 }
+
+// LineSearch::first_trial_accepted against the state machine it abbreviates: 1 = the two agree on this input
+extern "C" int hostcheck_first_trial(double ftol, double gtol, double min_step, double max_step, double xtol, int max_linesearch,
+                                     double step0, double f0, double dginit0, double f, double dg, int *fast, int *full) {
+    frx_lbfgs_params pm = {};
+    pm.f_dec_coeff = ftol; pm.s_curv_coeff = gtol; pm.min_step = min_step; pm.max_step = max_step; pm.xtol = xtol; pm.max_linesearch = max_linesearch;
+    const bool a = frx::LineSearch::first_trial_accepted(pm, step0, f0, dginit0, f, dg);
+    frx::LineSearch ls;
+    const bool b = ls.mt_begin(pm, step0, f0, dginit0) == 0 && ls.mt_feed(pm, f, dg) == 1;
+    if (fast) *fast = a; if (full) *full = b;
+    return a == b;
+}

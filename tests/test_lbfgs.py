@@ -141,6 +141,41 @@ def test_device_vector_protocol_is_bit_identical_on_host_emulation(problems, ob)
             assert rc == ret and fx.value == fr and np.array_equal(x, xr)
 
 
+def test_first_trial_shortcut_equals_the_line_search_state_machine():
+    """LineSearch::first_trial_accepted - what the leader of the resident round kernel asks before it runs the More-Thuente state machine -
+    says "accepted" exactly when mt_begin + one mt_feed do (lbfgs.hpp:743-788, 829-850): random and adversarial inputs, including values
+    ON the two thresholds, non-finite values, wrong-signed slopes and a search limit of one."""
+    import os, subprocess
+    from conftest import ROOT
+    d = os.path.join(ROOT, "tests", "hostcheck")
+    subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
+    H = C.CDLL(os.path.join(d, "libhostcheck.so"))
+    H.hostcheck_first_trial.restype = C.c_int
+    H.hostcheck_first_trial.argtypes = [C.c_double] * 5 + [C.c_int] + [C.c_double] * 5 + [C.POINTER(C.c_int)] * 2
+    rng = np.random.default_rng(5)
+    ftol, gtol, lo, hi, xtol = 1e-4, 0.9, 1e-20, 1e20, 1e-16
+    n_acc = 0
+    cases = []
+    for _ in range(20000):
+        step = float(10.0 ** rng.uniform(-6, 1)) if rng.random() < 0.7 else 1.0
+        f0 = float(rng.normal() * 10.0 ** rng.uniform(-2, 6))
+        dgi = -float(10.0 ** rng.uniform(-8, 4))
+        ftest = f0 + step * (ftol * dgi)
+        f = [ftest, np.nextafter(ftest, np.inf), np.nextafter(ftest, -np.inf), f0 + 2.0 * step * dgi * rng.random(), f0 + abs(f0) * 1e-3][rng.integers(5)]
+        thr = gtol * (-dgi)
+        dg = [thr, -thr, np.nextafter(thr, np.inf), -np.nextafter(thr, np.inf), dgi * rng.random(), -dgi * rng.random() * 2][rng.integers(6)]
+        cases.append((step, f0, dgi, float(f), float(dg), 40))
+    cases += [(1.0, 1.0, 1e-3, 0.5, 0.0, 40), (0.0, 1.0, -1.0, 0.5, 0.0, 40), (-1.0, 1.0, -1.0, 0.5, 0.0, 40), (1.0, 1.0, -1.0, float("nan"), 0.0, 40),
+              (1.0, 1.0, -1.0, float("inf"), 0.0, 40), (1.0, 1.0, -1.0, -float("inf"), 0.0, 40), (1.0, 1.0, -1.0, 0.5, float("nan"), 40),
+              (1.0, 1.0, -1.0, 0.5, 0.0, 1), (1.0, 1.0, 0.0, 1.0, 0.0, 40), (1.0, 1.0, -0.0, 1.0, 0.0, 40)]
+    for step, f0, dgi, f, dg, mls in cases:
+        a = C.c_int(); b = C.c_int()
+        same = H.hostcheck_first_trial(ftol, gtol, lo, hi, xtol, mls, step, f0, dgi, f, dg, C.byref(a), C.byref(b))
+        assert same == 1, (step, f0, dgi, f, dg, mls, a.value, b.value)
+        n_acc += a.value
+    assert 2000 < n_acc < len(cases) - 2000                  # both verdicts are well represented
+
+
 def test_value_after_a_failed_line_search_belongs_to_the_restored_point(frx):
     """When the line search gives up for good, x and g are reverted to the previous point (lbfgs.hpp:1287-1288); the objective
     that is reported with them must be the one AT that point (it ranks candidates), not the last rejected trial's."""
