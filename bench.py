@@ -61,11 +61,16 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     samples = done * oracles[0].fine_n * (kappa + 1)
     # one full plan of candidate 0 (stock tolerance), then the whole batch with one candidate per thread
     t0 = time.perf_counter()
-    r = oracles[0].optimize(params["opt_rel_tol"])
+    # (bounded: the reference runs L-BFGS without an iteration limit, CPU.hpp:1243-1247, and on an infeasible Monte-Carlo scenario - id 170 -
+    # it loops on NaN objectives for ever; 20 000 iterations is more than three times the longest feasible plan.  The batch leg is also bounded in SIZE:
+    # one plan per thread, so that a 512-candidate share does not turn the baseline into minutes)
+    CPU_PLAN_ITERATION_CAP = 20000
+    r = oracles[0].optimize(params["opt_rel_tol"], max_iterations=CPU_PLAN_ITERATION_CAP)
     plan_ms = (time.perf_counter() - t0) * 1e3
+    batch = oracles[:workers]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=workers) as ex:
-        rs = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"]), oracles))
+        rs = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"], max_iterations=CPU_PLAN_ITERATION_CAP), batch))
     plan_batch_ms = (time.perf_counter() - t0) * 1e3
     return {
         "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "node_cores": cores, "threads": workers, "kind": "port",
@@ -73,7 +78,7 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
                   f"{workers} threads on a node with {cores} logical cores, oracle built -O3 -march=x86-64-v3 -ffp-contract=off",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
         "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
-        "plan_ms_batch": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_objective_min": float(min(x["objective"] for x in rs)),
+        "plan_ms_batch": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_candidates": len(batch), "plan_iteration_cap": CPU_PLAN_ITERATION_CAP, "plan_batch_objective_min": float(min(x["objective"] for x in rs)),
     }
 
 
