@@ -103,7 +103,8 @@ struct RoundArgs {
     unsigned *spec;                                      // [B][4] counters: rounds started on a predicted ADVANCE / on a predicted trial step, predictions the host's command did not confirm (redone), reserved
     int ls_max_linesearch, speculate;
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
-    int fast_control;                                                 // 1 (default): barrier-free confirmation and the first-trial shortcut of the prediction; 0: the long forms (A/B measurements)
+    int fast_control;                                                 // bit 0 (default on): barrier-free confirmation and the first-trial shortcut of the prediction (off: the long forms, for A/B
+                                                                      // measurements); bit 1: PROF experiment, one extra timed read of the command mailbox per round (stamps 19 .. 21)
     int stamp_round;                                                  // PROF: the stamps of cluster 0's evaluation number stamp_round are kept in dp.stamps[32 .. 63]
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
@@ -450,7 +451,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
             if (PROF && a.dp.stamps && k == 0 && t == 0) a.dp.stamps[18] = (long long)__builtin_readcyclecounter();   // (18 .. 21: the leader's work behind the adjoint)
-            if (PROF && a.dp.stamps && a.poll_sleep == 3 && t == 0) {          // experiment (FRX_RESIDENT_POLL=3 + profile): one extra, TIMED read of the command word per round
+            if (PROF && a.dp.stamps && (a.fast_control & 2) && t == 0) {       // experiment (FRX_RESIDENT_TIMED_READ=1 + profile): one extra, TIMED read of the command mailbox per round
                 const rk_u64 q0 = wall_clock64();
                 rk_u64 w_ = 0, s_ = 0;
                 rk_load_cmd(a.h_cmd + k * a.cmd_stride, w_, s_);
@@ -461,7 +462,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 // Common case first, without a barrier: the word thread 0 read while the adjoint ran (ctlD[7], in LDS behind the adjoint's last
                 // barrier) is this round's command and equals the predicted one - every thread sees the same word and decides alike.
                 const rk_u64 we = (rk_u64)__double_as_longlong(ctlD[7]);
-                if (a.fast_control && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word) unconfirmed = false;
+                if ((a.fast_control & 1) && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word) unconfirmed = false;
             }
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
@@ -534,7 +535,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     // first_trial_accepted: mt_begin's and mt_feed's own tests on their own operands); it is not needed afterwards, the
                     // next search begins from scratch.  The state machine runs only when this test says no.
                     const bool plain = step != a.ls_min_step && step != a.ls_max_step;
-                    accepted_first = a.fast_control && plain && LineSearch::first_trial_accepted(lpm, step, f_acc, dgi, fv, dgv);
+                    accepted_first = (a.fast_control & 1) && plain && LineSearch::first_trial_accepted(lpm, step, f_acc, dgi, fv, dgv);
                     ls_ok = !accepted_first && plain && ls.mt_begin(lpm, step, f_acc, dgi) == 0;
                 }
                 if (accepted_first) {

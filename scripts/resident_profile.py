@@ -34,7 +34,7 @@ st = prob.last_stamps
 rel = lambda idx, base: {str(i): int(st[i] - st[base]) for i in idx if st[i] > 0}
 out["forward_stamps"] = {"matrix_wave": rel([1, 2, 5, 6], 0), "axis_wave": rel([8, 9, 10, 11, 12], 0), "publication (leader thread 0: before its drain, drained, phase word stored)": rel([13, 14, 15], 0)}
 out["adjoint_stamps"] = {"wave0": rel([17, 22, 23, 24], 16), "axis_wave": rel([25, 26, 27, 28, 30, 31, 29], 16)}
-if os.environ.get("FRX_RESIDENT_POLL") == "3" and st[20] > 0:           # experiment: an extra, timed 16-byte read of the command mailbox per round (leader 0)
+if os.environ.get("FRX_RESIDENT_TIMED_READ") == "1" and st[20] > 0:           # experiment: an extra, timed 16-byte read of the command mailbox per round (leader 0)
     out["timed_host_read_us"] = {"mean": float(st[19]) / float(st[20]) / 100.0, "max": float(st[21]) / 100.0, "reads": int(st[20])}
 print(json.dumps(out, indent=1))
 prob.set_resident(False)
