@@ -142,6 +142,25 @@ def test_resident_plans_end_like_per_stage_plans(frx, sc):
     prob.close()
 
 
+def test_shortcuts_of_the_round_kernel_do_not_change_a_plan(frx, sc, monkeypatch):
+    """The leader's barrier-free confirmation and first-trial shortcut (FRX_RESIDENT_FAST_CONTROL), the history workgroups' head start on pass A
+    (FRX_RESIDENT_EARLY_PASS) and the prediction levels (FRX_RESIDENT_SPECULATE) are ways to the SAME commands and the same arithmetic: with any
+    of them switched off the plan is bit for bit the default one."""
+    cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(4)]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    ref = _plan(prob, tol, True, max_iterations=600)
+    assert ref["resident"] >= 3 and ref["device_status"] == 0
+    for var, val in (("FRX_RESIDENT_FAST_CONTROL", "0"), ("FRX_RESIDENT_EARLY_PASS", "0"), ("FRX_RESIDENT_SPECULATE", "0"), ("FRX_RESIDENT_SPECULATE", "1")):
+        monkeypatch.setenv(var, val)
+        r = _plan(prob, tol, True, max_iterations=600)
+        monkeypatch.delenv(var)
+        assert r["device_status"] == 0 and r["resident"] == ref["resident"], (var, val)
+        for key in ("x", "status", "iters", "evals", "objective"):
+            assert np.array_equal(r[key], ref[key]), (var, val, key)
+    prob.close()
+
+
 def test_batches_larger_than_the_chip_take_the_work_queue_and_small_problems_the_per_stage_path(frx, sc, monkeypatch):
     cands = [sc.make_candidate(7, 32, 8, perturb_id=i) for i in range(70)]        # 70 clusters x >= 5 workgroups > 256 CUs
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
