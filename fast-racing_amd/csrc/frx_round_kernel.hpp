@@ -253,7 +253,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     // host actually sent before the next result is posted.  The host keeps every decision: if it stopped instead (convergence,
     // iteration limit) the leader restores the accepted point and leaves; any other disagreement ends the launch with
     // RK_ERR_SPECULATION and the plan is re-run on the per-stage path.
-    bool unconfirmed = false, spec_ready = false, have_cmd = false, ls_ok = false;
+    bool unconfirmed = false, spec_ready = false, have_cmd = false, ls_ok = false, adv_sent = false;
     unsigned n_pred_adv = 0, n_pred_trial = 0, n_redone = 0;                // counters of a.spec, written once at the end
     int pred_kind = 0, run_kind = 0;                                        // 1 = ADVANCE predicted, 2 = another trial of the running search predicted (kind of the NEXT / of the RUNNING round)
     double pred_step = 1.0;
@@ -276,7 +276,6 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 f_acc = ctlD[0];
                 last_slot = jnew; last_bound = bound;
                 accept_step();                                              // same as the DV_ADVANCE branch below
-                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
                 kind = PH_ADV;
             } else step = pred_step;                                        // another trial of the running search: straight to x = xp + step d
             lstage = 1;
@@ -339,8 +338,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
                 f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
                 accept_step();
-                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
-                kind = PH_ADV; lstage = 1;
+                kind = PH_ADV; lstage = 1;                                  // (the step's slot and pair count ride in the phase word)
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
                     f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
@@ -373,13 +371,16 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         }
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
         RK_PROF(RK_P_DENSE_IN);                                             // (leader: command decoded / accepted step taken over)
+        if (adv_sent) { adv_sent = false; __syncthreads(); }                // this step's phase word went out right behind the prediction (below): the cluster is at work already
+        else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
         RK_PROF(RK_P_SOLVE);                                                // (leader: drain of this phase's publications)
         pseq++;
-        // (one 8-byte store: the phase word and, for ADV, the step's slot and pair count - the history workgroups need no trip to `pub` for them)
+        // (one 8-byte store: the phase word and, for ADV, the step's slot and pair count - nobody needs a trip to `pub` for them)
         if (t == 0) __hip_atomic_store((rk_u64 *)(a.phase + k * RK_WSTRIDE), (rk_u64)((pseq << 4) | (unsigned)kind) | ((rk_u64)(((unsigned)bound << 8) | (unsigned)jnew) << 32), FRX_RLX_AGENT);
+        }
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
         if (seq_pending != 0) {
             // The result of the round whose acceptance the leader predicted goes to the host only NOW, behind the phase word of the step it
@@ -562,6 +563,15 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                         }
                     }
                 }
+            }
+            if (pred_kind == 1 && (a.fast_control & 4)) {
+                // The accepted step's phase word goes out NOW: what the cluster needs is in `pub` already (the trial point since the forward map,
+                // the gradient acknowledged wave by wave at the end of the adjoint - LineSearchTap::early_ctr), slot and pair count ride in the
+                // word.  The leader's own bookkeeping for the step (previous point, result post) follows while the cluster works.
+                pseq++;
+                const unsigned ns_ = (unsigned)((pred_word >> 8) & 0xFFFu), nb_ = (unsigned)((pred_word >> 20) & 0xFFFu);
+                if (t == 0) __hip_atomic_store((rk_u64 *)(a.phase + k * RK_WSTRIDE), (rk_u64)((pseq << 4) | (unsigned)PH_ADV) | ((rk_u64)((nb_ << 8) | ns_) << 32), FRX_RLX_AGENT);
+                adv_sent = true;
             }
             RK_PROF(RK_P_WAIT_PART);                                        // (leader: the line search's next command)
             if (spec_ready) seq_pending = hseq;                             // nobody waits for the host's answer to this one: posted behind the next phase word (above)
@@ -794,18 +804,22 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             const rk_u64 dl = wall_clock64() + a.timeout_ticks;
             unsigned w = 0;
             bool ok = true;
+            rk_u64 w64 = 0;
             for (unsigned spins = 0;; spins++) {
-                w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
+                w64 = __hip_atomic_load((const rk_u64 *)(a.phase + k * RK_WSTRIDE), FRX_RLX_AGENT);
+                w = (unsigned)w64;
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
             ctlU[0] = w & 15u;
+            ctlU[1] = (unsigned)(w64 >> 32) & 0xFFu;                         // slot of an ADV (rides in the phase word)
         }
         __syncthreads();
         const int kind = (int)ctlU[0];
         pseq++;
+        const int jnew_w = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
         __syncthreads();
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
@@ -817,9 +831,9 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
         }
         if (kind == PH_ADV) {
             nadv++;
-            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); const bool ok = rk_wait_eq(a.cntA + k * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+            if (t == 0) { const bool ok = rk_wait_eq(a.cntA + k * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
             __syncthreads();
-            const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
+            const int jnew = jnew_w;
             RK_PROF(RK_P_WAIT_PART);
             {   // partial sums of the history workgroups, summed in workgroup order (deterministic); all loads of a batch in flight together
                 double pv[2][8];
