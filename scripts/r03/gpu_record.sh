@@ -23,7 +23,7 @@ head -30 gpurun_out/${TAG}_round_budget_B32.json | tr -d '\n '; echo
 # two ranks on one device (N > 1 control flow of bench.py: cpu_baseline and roofline on rank 0)
 rm -f gpurun_out/queue_sizes.jsonl
 timeout 200 python scripts/r03/queue_sizes.py 33 64 96 128 512 > gpurun_out/queue_sizes.log 2>&1; tail -2 gpurun_out/queue_sizes.log | cut -c1-400
-timeout 300 python bench.py --config montecarlo4096 --steps 50 --warmup 10 --large-batch 0 > gpurun_out/${TAG}_bench_montecarlo4096.json 2> gpurun_out/bench_mc.err
+timeout 300 python bench.py --config montecarlo4096 --steps 50 --warmup 10 --large-batch 0 --no-cpu-baseline > gpurun_out/${TAG}_bench_montecarlo4096.json 2> gpurun_out/bench_mc.err
 python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_bench_montecarlo4096.json').read().strip().splitlines()[-1]); print({k:(round(v,2) if isinstance(v,float) else v) for k,v in d.items() if k.startswith('plan') or k in ('value','work_queue_equals_default_path_status')})"
 FRX_BENCH_DEVICE=0 FRX_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 50 --warmup 10 --large-batch 0 2> gpurun_out/bench_2ranks.err | tail -1 > gpurun_out/${TAG}_bench_2ranks_one_device.json
