@@ -1159,7 +1159,6 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.B = B; rl.S = S; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
     { const char *fc = std::getenv("FRX_RESIDENT_FAST_CONTROL"); rl.fast_control = fc && fc[0] == '0' ? 0 : 1; }
-    { const char *ep = std::getenv("FRX_RESIDENT_EARLY_PASS"); if (!(ep && ep[0] == '0')) rl.fast_control |= 4; }      // history workgroups start pass A on the adjoint's completion count (rk_member_loop)
     { const char *tr = std::getenv("FRX_RESIDENT_TIMED_READ"); if (tr && tr[0] == '1') rl.fast_control |= 2; }
     { const char *sr = std::getenv("FRX_RESIDENT_STAMP_ROUND"); rl.stamp_round = want_prof && sr ? std::max(0, std::atoi(sr)) : 0; }
     rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;

@@ -38,9 +38,7 @@ namespace frx {
 // command for a round the leader started on a prediction.  The read crosses PCIe (1-2.5 us with 32 leaders polling): it is issued only AFTER thread 0's wave has consumed its
 // first batch of loads - vmcnt completes in order, so issued in front of them it held up the wave's whole chain by the PCIe round trip (measured: adjoint 6.5 us with one
 // candidate on the chip, 7.5 us with 32).
-// `early_ctr` (resident round kernel, optional): every wave of the adjoint adds one to this word of device memory once ITS stores of the gradient (ResidentOps::gpub)
-// have been acknowledged - the cluster's history workgroups start on the new gradient when the count reaches 4 x the evaluation number, before the leader's phase word.
-struct LineSearchTap { const double *d; const int *flags; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; double *lds_out = nullptr; const unsigned long long *early_cmd = nullptr; unsigned *early_ctr = nullptr; };
+struct LineSearchTap { const double *d; const int *flags; DvResult *res; unsigned *arrive; volatile unsigned *flag; unsigned round; double *lds_out = nullptr; const unsigned long long *early_cmd = nullptr; };
 
 
 
@@ -1289,7 +1287,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     // of every younger store as well - measured as 1.2 us at the end of the adjoint with four clusters on an XCD, time the leader otherwise
     // spends on the line search before its next publication drains them anyway.  The time gradient's copy for the cluster (`gpub`) is
     // therefore stored by wave 1 from the LDS copy, behind the last barrier.
-    const bool defer_time_gpub = gs != nullptr && gpub != nullptr && tap.early_cmd != nullptr && tap.early_ctr == nullptr;   // (with early_ctr every wave waits for its stores at the very end anyway: the older they are by then, the better)
+    const bool defer_time_gpub = gs != nullptr && gpub != nullptr && tap.early_cmd != nullptr;
     const bool tapped = tap.d != nullptr;
     const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
     double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
@@ -1568,10 +1566,6 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the result above is visible before the count moves
             if (atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
         }
-    }
-    if (tap.early_ctr) {                                                 // (see LineSearchTap: this wave's share of the gradient has left the CU)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((k & 63) == 0) __hip_atomic_fetch_add(tap.early_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     FRX_STAMP(24);
 }

@@ -59,7 +59,7 @@ static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 
 // LDS layout (doubles), shared by the kernel and the host-side size computation
 struct RoundLds {
-    int ctl, sC, yC, gC, xpC, gpC, xnC, oS, oY, pair, role, total;    // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
+    int ctl, sC, yC, gC, xpC, gpC, pair, role, total;    // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
     int Rf, vd, va, vb, vc, ve, vw, vv, mv;              // dense state: Rf = R^-1 as [128][129] (row stride 129: conflict-free by row AND by column)
 };
 enum { RK_RS = 129 };                                    // row stride of Rf
@@ -71,7 +71,7 @@ __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) 
     RoundLds L;
     int o = 0;
     L.ctl = o; o += 48;                                   // 16 unsigned | 8 doubles | 16 profile accumulators
-    L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT; L.xpC = o; o += CHT; L.gpC = o; o += CHT; L.xnC = o; o += CHT; L.oS = o; o += CHT; L.oY = o; o += CHT;
+    L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT; L.xpC = o; o += CHT; L.gpC = o; o += CHT;
     L.pair = o; o += 2 * 4 * 128;
     o = (o + 1) & ~1;
     L.role = o;
@@ -104,8 +104,7 @@ struct RoundArgs {
     int ls_max_linesearch, speculate;
     int cmd_stride;                                                   // commands are cmd_stride x 16 bytes apart in h_cmd
     int fast_control;                                                 // bit 0 (default on): barrier-free confirmation and the first-trial shortcut of the prediction (off: the long forms, for A/B
-                                                                      // measurements); bit 1: PROF experiment, one extra timed read of the command mailbox per round (stamps 19 .. 21);
-                                                                      // bit 2 (default on): pass A of the history workgroups starts on the adjoint's completion count, ahead of the phase word
+                                                                      // measurements); bit 1: PROF experiment, one extra timed read of the command mailbox per round (stamps 19 .. 21)
     int stamp_round;                                                  // PROF: the stamps of cluster 0's evaluation number stamp_round are kept in dp.stamps[32 .. 63]
     int poll_sleep;                                                   // 0..3: s_sleep 1 / 2 / 4 / 8 between polls of phase words and counters, 4: none (FRX_RESIDENT_POLL)
     int maxN19;                                                       // 19 maxN: size of the leader's (C, T) copy
@@ -253,7 +252,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     // host actually sent before the next result is posted.  The host keeps every decision: if it stopped instead (convergence,
     // iteration limit) the leader restores the accepted point and leaves; any other disagreement ends the launch with
     // RK_ERR_SPECULATION and the plan is re-run on the per-stage path.
-    bool unconfirmed = false, spec_ready = false, have_cmd = false, ls_ok = false, adv_sent = false;
+    bool unconfirmed = false, spec_ready = false, have_cmd = false, ls_ok = false;
     unsigned n_pred_adv = 0, n_pred_trial = 0, n_redone = 0;                // counters of a.spec, written once at the end
     int pred_kind = 0, run_kind = 0;                                        // 1 = ADVANCE predicted, 2 = another trial of the running search predicted (kind of the NEXT / of the RUNNING round)
     double pred_step = 1.0;
@@ -276,6 +275,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 f_acc = ctlD[0];
                 last_slot = jnew; last_bound = bound;
                 accept_step();                                              // same as the DV_ADVANCE branch below
+                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
                 kind = PH_ADV;
             } else step = pred_step;                                        // another trial of the running search: straight to x = xp + step d
             lstage = 1;
@@ -338,7 +338,8 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
                 f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
                 accept_step();
-                kind = PH_ADV; lstage = 1;                                  // (the step's slot and pair count ride in the phase word)
+                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
+                kind = PH_ADV; lstage = 1;
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
                     f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
@@ -371,16 +372,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         }
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
         RK_PROF(RK_P_DENSE_IN);                                             // (leader: command decoded / accepted step taken over)
-        if (adv_sent) { adv_sent = false; __syncthreads(); }                // this step's phase word went out right behind the prediction (below): the cluster is at work already
-        else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
         RK_PROF(RK_P_SOLVE);                                                // (leader: drain of this phase's publications)
         pseq++;
-        // (one 8-byte store: the phase word and, for ADV, the step's slot and pair count - nobody needs a trip to `pub` for them)
-        if (t == 0) __hip_atomic_store((rk_u64 *)(a.phase + k * RK_WSTRIDE), (rk_u64)((pseq << 4) | (unsigned)kind) | ((rk_u64)(((unsigned)bound << 8) | (unsigned)jnew) << 32), FRX_RLX_AGENT);
-        }
+        if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
         if (seq_pending != 0) {
             // The result of the round whose acceptance the leader predicted goes to the host only NOW, behind the phase word of the step it
@@ -449,7 +446,6 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
             if (dg_pending) { if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]); dg_pending = false; }   // gp . d of this round's ADVANCE (read behind the adjoint's barrier)
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
-            if (a.fast_control & 4) tap.early_ctr = a.phase + k * RK_WSTRIDE + 2;   // "this evaluation's gradient is in `pub`": the history workgroups start on pass A (see rk_member_loop)
             if (unconfirmed) tap.early_cmd = &a.h_cmd[k * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
             backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
@@ -564,15 +560,6 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     }
                 }
             }
-            if (pred_kind == 1 && (a.fast_control & 4)) {
-                // The accepted step's phase word goes out NOW: what the cluster needs is in `pub` already (the trial point since the forward map,
-                // the gradient acknowledged wave by wave at the end of the adjoint - LineSearchTap::early_ctr), slot and pair count ride in the
-                // word.  The leader's own bookkeeping for the step (previous point, result post) follows while the cluster works.
-                pseq++;
-                const unsigned ns_ = (unsigned)((pred_word >> 8) & 0xFFFu), nb_ = (unsigned)((pred_word >> 20) & 0xFFFu);
-                if (t == 0) __hip_atomic_store((rk_u64 *)(a.phase + k * RK_WSTRIDE), (rk_u64)((pseq << 4) | (unsigned)PH_ADV) | ((rk_u64)((nb_ << 8) | ns_) << 32), FRX_RLX_AGENT);
-                adv_sent = true;
-            }
             RK_PROF(RK_P_WAIT_PART);                                        // (leader: the line search's next command)
             if (spec_ready) seq_pending = hseq;                             // nobody waits for the host's answer to this one: posted behind the next phase word (above)
             else if (t == 0) {
@@ -617,42 +604,25 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
 #pragma unroll
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
     unsigned pseq = 0, nadv = 0;
-    int jnew = -1, bound = 0;
-    // Pass A ahead of the phase word.  Everything pass A needs is in `pub` the moment the adjoint has stored the gradient - ~2 us before the
-    // leader, which still has to confirm its command, predict the next one and take the step over, publishes PH_ADV.  The leader's four waves
-    // each count up a word next to the phase word when their gradient stores have been acknowledged (LineSearchTap::early_ctr); a history
-    // workgroup that sees evaluation number `nct` complete loads its chunks and forms s, y and the four dot products for the slot the NEXT
-    // accepted step will take.  The new pair goes into that slot's registers at once (the dot products of the slot's own thread are the new
-    // pair's), the pair it displaces is kept in LDS (oS, oY); everything else stays in temporaries (sC, yC, gC, xnC, `pair`).  If PH_ADV follows
-    // with that slot and pair count, the previous-point chunk is moved on and the partial sums are published at once; anything else (the trial
-    // was rejected, the plan ended) puts the displaced pair back.  Same operands, same operations as without the head start: bit-identical plans.
-    unsigned nct = 0, spec_eval = ~0u;                                      // evaluations seen (CT phases); the evaluation whose pass A sits in the temporaries
-    int sj = -1, sb = 0;                                                    // ... computed for this slot and pair count
-    double *xnC = sm + L.xnC, *oS = sm + L.oS, *oY = sm + L.oY;
-    bool spec_live = false;                                                 // slot sj's registers hold a pair that has not been accepted yet
-    const bool early_on = (a.fast_control & 4) != 0;
+    int jnew = 0, bound = 0;
     for (;;) {
         if (t == 0) {
             const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-            rk_u64 w = 0;
+            unsigned w = 0;
             bool ok = true;
-            unsigned spec_now = 0u;
             for (unsigned spins = 0;; spins++) {
-                w = __hip_atomic_load((const rk_u64 *)(a.phase + k * RK_WSTRIDE), FRX_RLX_AGENT);
-                if ((((unsigned)w) >> 4) == pseq + 1) break;
-                if (early_on && nct > 0 && spec_eval != nct && __hip_atomic_load(a.phase + k * RK_WSTRIDE + 2, FRX_RLX_AGENT) == 4u * nct) { spec_now = 1u; break; }
+                w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
+                if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
-            ctlU[0] = spec_now ? 0u : ((unsigned)w & 15u);
-            ctlU[1] = (unsigned)(w >> 32) & 0xFFu; ctlU[2] = (unsigned)(w >> 40) & 0xFFFu;      // slot and pair count of an ADV
+            ctlU[0] = w & 15u;
         }
         __syncthreads();
         const int kind = (int)ctlU[0];
-        const int pj = __builtin_amdgcn_readfirstlane((int)ctlU[1]), pb = __builtin_amdgcn_readfirstlane((int)ctlU[2]);
+        pseq++;
         __syncthreads();
-        if (kind != 0) pseq++;
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
         if (kind == PH_NEXT) {                                              // work queue: the cluster takes another candidate - the penalty share follows it
@@ -664,38 +634,30 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
         if (kind == PH_INIT) {                                              // this workgroup's chunk of the start point and its gradient: the first pair's "previous point"
             const int e0 = hg * CHT;
             for (int i = t; i < CHT; i += 256) { xpC[i] = ldg<true>(pub + e0 + i); gpC[i] = ldg<true>(pub + a.NXP + e0 + i); }
-            jnew = -1; bound = 0; spec_eval = ~0u;                           // a new plan: its first step takes slot 0
-        }
-        if (kind == PH_CT) nct++;
-        if (spec_live && !(kind == PH_ADV && spec_eval == nct && sj == pj && sb == pb)) {   // the step pass A was computed for did not come: the displaced pair returns
-            if (slot == sj) {
-#pragma unroll
-                for (int e = 0; e < E; e++) { Sreg[e] = oS[half * E + e]; Yreg[e] = oY[half * E + e]; }
-            }
-            spec_live = false; spec_eval = ~0u;
         }
 
         // ------------------------------------------------------------------------------------------------------------------
         // PHASE ADV: new pair into the history, 4 m dot products, dense step, linear combination
         // ------------------------------------------------------------------------------------------------------------------
-        // slot and pair count pass A works for: the announced ones (ADV) or the ones the next accepted step will carry (lbfgs.hpp:1364-1372)
-        const int cj = kind == PH_ADV ? pj : (jnew < 0 ? 0 : (jnew + 1 == m ? 0 : jnew + 1)), cb = kind == PH_ADV ? pb : min(m, bound + 1);
-        if (kind == 0 || (kind == PH_ADV && !(spec_eval == nct && sj == cj && sb == cb))) {
-            // -- 1. this workgroup's chunk of the point and its gradient; s = x - xp, y = g - gp against the chunk kept from the previous step --
+        if (kind == PH_ADV) {
+            nadv++;
+            // -- 1. this workgroup's chunk of the accepted point and its gradient; s = x - xp, y = g - gp against the chunk kept from the previous step --
             const int e0 = hg * CHT;
             for (int i = t; i < CHT; i += 256) {
                 const double xv = ldg<true>(pub + e0 + i), gv = ldg<true>(pub + a.NXP + e0 + i);
-                sC[i] = xv - xpC[i]; yC[i] = gv - gpC[i]; gC[i] = gv; xnC[i] = xv;
+                sC[i] = xv - xpC[i]; yC[i] = gv - gpC[i]; gC[i] = gv; xpC[i] = xv; gpC[i] = gv;
             }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 2 * a.NXP + 1); }
             __syncthreads();
-            // -- 2. the new pair replaces slot cj (the displaced one is kept until the step is announced) --
-            if (slot == cj) {
+            jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]); bound = __builtin_amdgcn_readfirstlane((int)ctlU[2]);   // wave-uniform by construction
+            // -- 2. the new pair replaces slot jnew --
+            if (slot == jnew) {
 #pragma unroll
-                for (int e = 0; e < E; e++) { oS[half * E + e] = Sreg[e]; oY[half * E + e] = Yreg[e]; Sreg[e] = sC[half * E + e]; Yreg[e] = yC[half * E + e]; }
+                for (int e = 0; e < E; e++) { Sreg[e] = sC[half * E + e]; Yreg[e] = yC[half * E + e]; }
             }
             // -- 3. pass A: s_j.g, y_j.g, s_j.y_new, y_j.y_new over this thread's elements --
-            int age = cj - slot; if (age < 0) age += m;
-            const bool valid = slot < m && age < cb;
+            int age = jnew - slot; if (age < 0) age += m;
+            const bool valid = slot < m && age < bound;
             {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 if (valid) {
@@ -708,17 +670,6 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
 #pragma unroll
                 for (int q = 0; q < 4; q++) pair[(half * 4 + q) * 128 + slot] = acc[q];
             }
-            sj = cj; sb = cb; spec_eval = nct; spec_live = true;
-            if (kind == 0) { __syncthreads(); RK_PROF(RK_P_PASS_A); continue; }                // ahead of the phase word: back to the poll
-        }
-        if (kind == PH_ADV) {
-            nadv++;
-            jnew = cj; bound = cb;
-            // -- the step is announced: the pair in slot jnew stays, its point and gradient become the previous ones --
-            for (int i = t; i < CHT; i += 256) { xpC[i] = xnC[i]; gpC[i] = gC[i]; }
-            spec_live = false; spec_eval = ~0u;
-            int age = jnew - slot; if (age < 0) age += m;
-            const bool valid = slot < m && age < bound;
             __syncthreads();
             for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)hg * 512 + o, pair[o] + pair[512 + o], wt);
             rk_drain_and_meet();
@@ -804,22 +755,18 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             const rk_u64 dl = wall_clock64() + a.timeout_ticks;
             unsigned w = 0;
             bool ok = true;
-            rk_u64 w64 = 0;
             for (unsigned spins = 0;; spins++) {
-                w64 = __hip_atomic_load((const rk_u64 *)(a.phase + k * RK_WSTRIDE), FRX_RLX_AGENT);
-                w = (unsigned)w64;
+                w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
             ctlU[0] = w & 15u;
-            ctlU[1] = (unsigned)(w64 >> 32) & 0xFFu;                         // slot of an ADV (rides in the phase word)
         }
         __syncthreads();
         const int kind = (int)ctlU[0];
         pseq++;
-        const int jnew_w = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
         __syncthreads();
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
@@ -831,9 +778,9 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
         }
         if (kind == PH_ADV) {
             nadv++;
-            if (t == 0) { const bool ok = rk_wait_eq(a.cntA + k * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
+            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); const bool ok = rk_wait_eq(a.cntA + k * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
             __syncthreads();
-            const int jnew = jnew_w;
+            const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
             RK_PROF(RK_P_WAIT_PART);
             {   // partial sums of the history workgroups, summed in workgroup order (deterministic); all loads of a batch in flight together
                 double pv[2][8];

@@ -143,15 +143,15 @@ def test_resident_plans_end_like_per_stage_plans(frx, sc):
 
 
 def test_shortcuts_of_the_round_kernel_do_not_change_a_plan(frx, sc, monkeypatch):
-    """The leader's barrier-free confirmation and first-trial shortcut (FRX_RESIDENT_FAST_CONTROL), the history workgroups' head start on pass A
-    (FRX_RESIDENT_EARLY_PASS) and the prediction levels (FRX_RESIDENT_SPECULATE) are ways to the SAME commands and the same arithmetic: with any
-    of them switched off the plan is bit for bit the default one."""
+    """The leader's barrier-free confirmation and first-trial shortcut (FRX_RESIDENT_FAST_CONTROL) and the prediction levels
+    (FRX_RESIDENT_SPECULATE) are ways to the SAME commands and the same arithmetic: with any of them switched off the plan is bit for bit the
+    default one."""
     cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(4)]
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
     tol = sc.ZHANGJIAJIE["opt_rel_tol"]
     ref = _plan(prob, tol, True, max_iterations=600)
     assert ref["resident"] >= 3 and ref["device_status"] == 0
-    for var, val in (("FRX_RESIDENT_FAST_CONTROL", "0"), ("FRX_RESIDENT_EARLY_PASS", "0"), ("FRX_RESIDENT_SPECULATE", "0"), ("FRX_RESIDENT_SPECULATE", "1")):
+    for var, val in (("FRX_RESIDENT_FAST_CONTROL", "0"), ("FRX_RESIDENT_SPECULATE", "0"), ("FRX_RESIDENT_SPECULATE", "1")):
         monkeypatch.setenv(var, val)
         r = _plan(prob, tol, True, max_iterations=600)
         monkeypatch.delenv(var)
