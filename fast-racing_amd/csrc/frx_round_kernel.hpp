@@ -661,10 +661,28 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 if (valid) {
+                    // The chunk values come from LDS (broadcast reads), the pair from registers.  Left to itself the compiler read two elements,
+                    // waited, multiplied, read the next two (28 exposed LDS latencies, ~1.8 us of this pass, ISA); here the reads of a block of
+                    // CH elements are in flight while the previous block is multiplied - same products, same order of additions.
+                    constexpr int CH = (E % 8 == 0) ? 8 : 4;
+                    static_assert(E % CH == 0, "history elements per thread: a multiple of the block");
+                    double gb[2][CH], yb[2][CH];
 #pragma unroll
-                    for (int e = 0; e < E; e++) {
-                        const double gg = gC[half * E + e], yn = yC[half * E + e];
-                        acc[0] += Sreg[e] * gg; acc[1] += Yreg[e] * gg; acc[2] += Sreg[e] * yn; acc[3] += Yreg[e] * yn;
+                    for (int j = 0; j < CH; j++) { gb[0][j] = gC[half * E + j]; yb[0][j] = yC[half * E + j]; }
+#pragma unroll
+                    for (int e0 = 0; e0 < E; e0 += CH) {
+                        const int cur = (e0 / CH) & 1, nxt = cur ^ 1;
+                        if (e0 + CH < E) {
+#pragma unroll
+                            for (int j = 0; j < CH; j++) { gb[nxt][j] = gC[half * E + e0 + CH + j]; yb[nxt][j] = yC[half * E + e0 + CH + j]; }
+                        }
+                        RK_CHUNK();
+#pragma unroll
+                        for (int j = 0; j < CH; j++) {
+                            const double gg = gb[cur][j], yn = yb[cur][j];
+                            acc[0] += Sreg[e0 + j] * gg; acc[1] += Yreg[e0 + j] * gg; acc[2] += Sreg[e0 + j] * yn; acc[3] += Yreg[e0 + j] * yn;
+                        }
+                        RK_CHUNK();
                     }
                 }
 #pragma unroll
@@ -700,8 +718,16 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
                     const int grp = t / E, e = t - grp * E;                // grp = half * 2 + part: slots [64 part, 64 part + 64) of that half
                     const double *col = xt + (size_t)(grp * 64) * XS + e;
                     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 4
-                    for (int i = 0; i < 64; i += 4) { s0 += col[i * XS]; s1 += col[(i + 1) * XS]; s2 += col[(i + 2) * XS]; s3 += col[(i + 3) * XS]; }
+#pragma unroll
+                    for (int i0 = 0; i0 < 64; i0 += 16) {                  // sixteen reads in flight per block (four at a time measured one LDS latency per four additions); same four sums
+                        double cb[16];
+#pragma unroll
+                        for (int j = 0; j < 16; j++) cb[j] = col[(i0 + j) * XS];
+                        RK_CHUNK();
+#pragma unroll
+                        for (int j = 0; j < 16; j += 4) { s0 += cb[j]; s1 += cb[j + 1]; s2 += cb[j + 2]; s3 += cb[j + 3]; }
+                        RK_CHUNK();
+                    }
                     wsum[grp * E + e] = (s0 + s1) + (s2 + s3);
                 }
                 __syncthreads();

@@ -1,5 +1,5 @@
 """A/B of two BUILDS on one box: alternating subprocesses, each loads the package (and its libfrx.so) from its own root.
-   python ab_libs.py ROOT_A ROOT_B [reps] [B]   -> us per round of the full plan, per process"""
+   python ab_libs.py ROOT_A ROOT_B [ROOT_C ...] [reps] [B]   -> us per round of the full plan, per process"""
 import json, os, subprocess, sys
 child = r'''
 import os, sys, json
@@ -19,12 +19,14 @@ for i in range(3):
     v.append(round(1e3 * r["ms_total"] / r["rounds"], 3))
 print(json.dumps({"us_per_round": v, "rounds": int(r["rounds"]), "objective_min": float(r["objective"].min())}))
 '''
-ra, rb = os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-B = sys.argv[4] if len(sys.argv) > 4 else "32"
-out = {ra: [], rb: []}
+args = sys.argv[1:]
+roots = [os.path.abspath(a) for a in args if not a.isdigit()]
+nums = [a for a in args if a.isdigit()]
+reps = int(nums[0]) if nums else 2
+B = nums[1] if len(nums) > 1 else "32"
+out = {r: [] for r in roots}
 for i in range(reps):
-    for root in (ra, rb):
+    for root in roots:
         p = subprocess.run([sys.executable, "-c", child, root, B], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
         out[root].append(json.loads(p.stdout.strip().splitlines()[-1]))
 print(json.dumps(out))
