@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X back-end (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU; bench.py starts the ranks ITSELF under torch.distributed.run when no
+                                                         launcher did, and refuses to run when fewer than N devices are visible or the launcher's
+                                                         WORLD_SIZE is not N;  --multi lib: one process, frx_multi_* drives the N devices)
 
 A "step" is ONE batched cost/gradient evaluation x -> (f, grad f) of the headline workload
 (BASELINE.json configs[2]: 32 candidate trajectories x 64 pieces x 16 quadrature intervals,
@@ -73,13 +75,23 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     with ThreadPoolExecutor(max_workers=workers) as ex:
         rs = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"], max_iterations=CPU_PLAN_ITERATION_CAP), batch))
     plan_batch_ms = (time.perf_counter() - t0) * 1e3
+    # the same plans once more with the OTHER form of the sample abscissa (s1 += step, CPU.hpp:400, against step * j, cc.cu:152: one rounding
+    # apart per sample): what the reference's optimiser does to a last-bit difference - the CPU-vs-CPU spread printed next to device-vs-CPU
+    for o in batch: o.set_abscissa_mode(True)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        rs2 = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"], max_iterations=CPU_PLAN_ITERATION_CAP), batch))
+    for o in batch: o.set_abscissa_mode(False)
+    cpu_baseline.plans = rs; cpu_baseline.plans_other_rounding = rs2          # for main(): coefficient spread against the device's plans of the SAME candidates
+    nb = len(batch)
     return {
         "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "node_cores": cores, "threads": workers, "kind": "port",
         "sample": f"{done} objective evaluations (x->f,grad) of {len(cands)} candidates of the workload at the bench state, "
                   f"{workers} threads on a node with {cores} logical cores, oracle built -O3 -march=x86-64-v3 -ffp-contract=off",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
         "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
-        "plan_ms_batch": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_candidates": len(batch), "plan_iteration_cap": CPU_PLAN_ITERATION_CAP, "plan_batch_objective_min": float(min(x["objective"] for x in rs)),
+        # (the CPU leg plans at most 32 candidates, one per thread, whatever the GPU batch is: the field says how many, and the rate is per candidate)
+        f"plan_ms_batch_of_{nb}": plan_batch_ms, "plan_batch_threads": workers, "plan_batch_candidates": nb, "plans_per_s": nb / (plan_batch_ms * 1e-3),
+        "plan_iteration_cap": CPU_PLAN_ITERATION_CAP, f"plan_objective_min_of_the_first_{nb}": float(min(x["objective"] for x in rs)),
     }
 
 
@@ -93,17 +105,45 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plan", action="store_true")
     ap.add_argument("--large-batch", type=int, default=1024, help="candidates of the extra large-batch k_penalty measurement (0 = skip)")
+    ap.add_argument("--multi", choices=("ranks", "lib"), default="ranks",
+                    help="N > 1 front end (DESIGN.md 5): 'ranks' = one process per GPU over torch.distributed/RCCL (self-launched when no launcher did it); "
+                         "'lib' = ONE process driving frx_multi_* (one host thread + handle per device, ncclCommInitAll inside the library)")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, meet at a barrier, print the job's shape and leave (no GPU work: the CPU test of the self-launch path)")
     args = ap.parse_args()
+
+    from frx_import import frx
+    from fast_racing_amd import dist as frxdist
+    # --gpus N decides the job, not the environment: without a launcher this process starts the N ranks itself (the reference is pinned to device 0,
+    # cuda_computer.cu:414); a launcher that started another number of ranks, or fewer visible devices than ranks, is an error - never a silent 1-rank run
+    n_dev = int(frx.lib().frx_device_count())
+    if args.multi == "lib":
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--multi lib is ONE process for all devices: do not start it under a multi-rank launcher")
+        if args.gpus > 1 and not os.environ.get("FRX_BENCH_DEVICE") and n_dev < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} --multi lib needs {args.gpus} HIP devices, {n_dev} visible")
+    else:
+        n_launch = frxdist.ranks_to_launch(args.gpus, os.environ, n_dev if not args.launch_check else max(n_dev, args.gpus))
+        if n_launch:
+            sys.exit(frxdist.self_launch(n_launch, os.path.abspath(__file__), sys.argv[1:]))
 
     import numpy as np
     import torch
-    from frx_import import frx
-    from fast_racing_amd import scenario as sc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    lib_mode = args.multi == "lib" and args.gpus > 1
+    world = args.gpus if lib_mode else int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available() or frx.lib().frx_device_count() < 1:
+    if args.launch_check:
+        import torch.distributed as dist
+        if world > 1 and not lib_mode:
+            dist.init_process_group(backend="gloo"); dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "front_end": args.multi, "self_launched": os.environ.get("TORCHELASTIC_RUN_ID") is not None or world == 1}), flush=True)
+        if world > 1 and not lib_mode:
+            dist.barrier(); dist.destroy_process_group()
+        return
+    from fast_racing_amd import scenario as sc
+    if not torch.cuda.is_available() or n_dev < 1:
         raise SystemExit("bench.py needs a HIP device (libfrx has no CPU fallback)")
     # test knobs (not used by the driver): FRX_BENCH_DEVICE pins every rank to one device and FRX_BENCH_BACKEND=gloo replaces RCCL,
     # so that the N > 1 control flow can be exercised on a 1-GPU box
@@ -111,7 +151,7 @@ def main():
         local_rank = int(os.environ["FRX_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 and not lib_mode:
         import torch.distributed as dist
         backend = os.environ.get("FRX_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -131,6 +171,12 @@ def main():
         cands = [sc.make_candidate(0, N, gates, perturb_id=rank * B + b) for b in range(B)]
     prob = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa)
     stream = torch.cuda.current_stream().cuda_stream
+    # --multi lib: this one process owns every shard.  Shard r (its own 32 candidates, like rank r of the other front end) lives on device r
+    # (or all of them on FRX_BENCH_DEVICE: control-flow test on a 1-GPU box); the evaluation step launches on every device before it waits for any
+    lib_devs = [int(os.environ["FRX_BENCH_DEVICE"]) if os.environ.get("FRX_BENCH_DEVICE") else r for r in range(world)] if lib_mode else []
+    lib_cands = [list(cands)] + [[sc.make_candidate(r * B + b, N, gates) if args.config == "montecarlo4096" else sc.make_candidate(0, N, gates, perturb_id=r * B + b)
+                                  for b in range(B)] for r in range(1, world)] if lib_mode else []
+    lib_shards = []
 
     # bench state: the iterate after 60 L-BFGS iterations from the reference's initial guess (untimed)
     x0 = prob.initial_guess()
@@ -140,20 +186,33 @@ def main():
     f_dev = torch.zeros(prob.B, dtype=torch.float64, device="cuda")
     g_dev = torch.zeros(prob.NX, dtype=torch.float64, device="cuda")
 
+    for r in range(1, world if lib_mode else 1):
+        pr = frx.Problem(lib_cands[r], params, device=lib_devs[r], qd_intervals=kappa)
+        xr = pr.optimize(params["opt_rel_tol"], max_iterations=60)["x"]
+        with torch.cuda.device(lib_devs[r]):
+            st_r = torch.cuda.Stream(device=lib_devs[r])
+            lib_shards.append((pr, torch.from_numpy(xr).cuda(), torch.zeros(pr.B, dtype=torch.float64, device="cuda"), torch.zeros(pr.NX, dtype=torch.float64, device="cuda"), st_r))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        for d in set(lib_devs): torch.cuda.synchronize(d)
+
     def step():
         prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), stream)
+        for pr, xd, fd, gd, st_r in lib_shards:
+            pr.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), st_r.cuda_stream)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync_all()
     if dist: dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync_all()
     if dist: dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     dt = time.perf_counter() - t0
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -281,9 +340,26 @@ def main():
                 prob.set_resident(2)
                 r_q = prob.optimize(params["opt_rel_tol"], x0=x0)
                 prob.set_resident(True)
-            p1 = frx.Problem(cands[:1], params, device=local_rank, qd_intervals=kappa)
-            r_b1 = p1.optimize(params["opt_rel_tol"])
+            # the reference's real use is ONE candidate: SE3GCOPTER::setup + optimize of MinCoPlan_CPU.cpp:113-126, its timer around both
+            t_s = time.perf_counter()
+            p1 = frx.Problem(cands[:1], params, device=local_rank, qd_intervals=kappa, enumerate_v=True)
+            t_setup1 = (time.perf_counter() - t_s) * 1e3
+            t_s = time.perf_counter()
+            x01 = p1.initial_guess()
+            t_guess1 = (time.perf_counter() - t_s) * 1e3
+            r_b1 = p1.optimize(params["opt_rel_tol"], x0=x01)
             p1.close()
+        r_lib = None
+        if lib_mode:
+            # the whole job through the library's own multi-device front end: one host thread + handle per device, winner over RCCL (ncclCommInitAll)
+            mp_ = frx.MultiProblem([c for sh in lib_cands for c in sh], params, devices=lib_devs, qd_intervals=kappa)
+            xm = mp_.initial_guess()
+            mp_.optimize(params["opt_rel_tol"], x0=xm, max_iterations=30)           # warm: communicator, resident kernels
+            t_s = time.perf_counter()
+            r_lib = mp_.optimize(params["opt_rel_tol"], x0=xm)
+            r_lib["ms_wall"] = (time.perf_counter() - t_s) * 1e3
+            r_lib["n_shards"], r_lib["uses_rccl"] = mp_.n_shards, mp_.uses_rccl
+            mp_.close()
         if dist:                                                         # the job's plan time is the slowest rank's
             tm = torch.tensor([r["ms_total"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -299,12 +375,21 @@ def main():
         if rank == 0:
             plan.update({"plan_ms_per_stage_path": r_ps["ms_total"], "plan_rounds_per_stage_path": r_ps["rounds"],
                          "plan_ms_one_candidate": r_b1["ms_total"], "plan_rounds_one_candidate": r_b1["rounds"],
+                         "plan_us_per_round_one_candidate": 1e3 * r_b1["ms_total"] / max(r_b1["rounds"], 1),
+                         "plan_setup_ms_one_candidate": t_setup1, "plan_initial_guess_ms_one_candidate": t_guess1,
+                         "plan_ms_with_setup_one_candidate": r_b1["ms_total"] + t_setup1 + t_guess1,
                          "plan_path_one_candidate": "resident" if r_b1["resident"] else "per-stage",
                          "plans_per_s_per_stage_path": B / (r_ps["ms_total"] * 1e-3)})
             if r_q is not None:
                 plan.update({"plan_ms_work_queue": r_q["ms_total"], "plan_clusters_work_queue": int(r_q["clusters"]), "plans_per_s_work_queue": B / (r_q["ms_total"] * 1e-3),
                              "plan_commands_of_the_busiest_cluster": r_q["rounds"], "plan_evals_mean": float(r_q["evals"].mean()),
                              "work_queue_equals_default_path_status": bool(np.array_equal(r_q["status"], r["status"]))})
+        if r_lib is not None:
+            plan.update({"plan_front_end": "frx_multi_* (one process, one host thread + handle per device)", "plan_ms_whole_job": r_lib["ms_wall"],
+                         "plan_shards": int(r_lib["n_shards"]), "plan_winner_exchange": r_lib["exchange"],
+                         "plan_status_ok_whole_job": int(np.sum(r_lib["status"] >= 0)), "lib_winner_id": r_lib["winner_id"], "lib_winner_objective": r_lib["winner_objective"]})
+            r["ms_total"] = r_lib["ms_wall"]                                 # the job's plan time: all shards, planned concurrently by the library
+            plan["plan_ms"] = r_lib["ms_wall"]
         # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
         from fast_racing_amd.dist import select_winner
         ids = np.arange(rank * B, rank * B + B)
@@ -318,6 +403,52 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cands, params, kappa, x_state, prob.x_off)
 
+    if rank == 0 and cpu is not None and plan:
+        # The 1e-6 contract on optimised coefficients, where the number is: the device's plans against the CPU oracle's plans of
+        # the same candidates, next to the CPU oracle against itself with one rounding moved (the sample abscissa's other form) - independent runs of the
+        # reference's stop rule end this far apart; the lock-step form (tests/test_gpu_parity.py) is where 1e-9 ... 1e-13 holds
+        def spread(pa, pb):
+            worst_c, worst_f = 0.0, 0.0
+            for b, (qa, qb) in enumerate(zip(pa, pb)):
+                worst_c = max(worst_c, float(np.abs(qa["C"] - qb["C"]).max() / np.abs(qb["C"]).max()))
+                worst_f = max(worst_f, abs(float(qa["objective"]) - float(qb["objective"])) / abs(float(qb["objective"])))
+            return worst_c, worst_f
+        nb = len(cpu_baseline.plans)
+        dev_plans = [{"C": r["C"][6 * prob.piece_off[b]:6 * prob.piece_off[b + 1]], "objective": r["objective"][b]} for b in range(nb)]
+        sc_dev, sf_dev = spread(dev_plans, cpu_baseline.plans)
+        sc_cpu, sf_cpu = spread(cpu_baseline.plans_other_rounding, cpu_baseline.plans)
+        plan.update({"plan_coeff_spread_vs_cpu": sc_dev, "plan_objective_spread_vs_cpu": sf_dev, "plan_coeff_spread_cpu_vs_cpu": sc_cpu, "plan_objective_spread_cpu_vs_cpu": sf_cpu,
+                     "plan_spread_definition": f"max over the first {nb} candidates of max|C_a - C_b| / max|C_b| (and |f_a - f_b| / |f_b|) between INDEPENDENT optimiser runs at the stock "
+                                               "tolerance; cpu_vs_cpu = the CPU oracle against itself with the sample abscissa accumulated (CPU.hpp:400) instead of multiplied (cc.cu:152)"})
+
+    # The kernel that actually runs a plan (VERDICT r3 missing 3): k_round, priced per ROUND = one evaluation + one L-BFGS update of every candidate.
+    # Bytes: SURVEY.md 8d's full-evaluation bytes (the history never touches HBM); FP64 work: the penalty integrator's counted flops plus the direction
+    # (pass A 4 m n FMAs, dense 3 m^2, pass B 2 m n per accepted step).  Idle fractions from the committed round budget (instrumented instantiation).
+    round_obj = None
+    if rank == 0 and plan and fp64:
+        m_hist = 128
+        us_round = plan["plan_us_per_round"]
+        dir_flops = float(np.sum(2.0 * (6 * m_hist * nx + 3 * m_hist * m_hist)))
+        pen_flops = fp64["flops_per_sample"] * samples_per_step
+        round_obj = {"kernel": "frx::k_round (resident: one launch per plan)", "us_per_round": us_round, "bytes_per_round": eval_bytes,
+                     "achieved": eval_bytes / (us_round * 1e-6) / 1e9, "unit": "GB/s", "frac": eval_bytes / (us_round * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "fp64_flops_per_round": pen_flops + dir_flops, "fp64_flops_penalty": pen_flops, "fp64_flops_direction": dir_flops,
+                     "fp64_frac": (pen_flops + dir_flops) / (us_round * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
+                     "bound": "latency: per candidate a round is ONE dependent chain (direction -> forward map -> penalty -> adjoint) on 8 of the chip's 256 CUs"}
+        for name in ("r04_round_budget_B32.json", "r03_round_budget_B32.json"):
+            bp = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(bp) and args.config == "headline":
+                try:
+                    bj = json.loads(open(bp).read().split("\n{\"per_stage")[0])
+                    tot = bj["leader"]["total"]
+                    round_obj["budget"] = {"from_profile": True, "source": "profiles/" + name, "instrumented_us_per_round": bj["us_per_round_wall"],
+                                           "leader_us": bj["leader"], "leader_idle_frac": (bj["leader"].get("wait_arrive", 0.0) + bj["leader"].get("wait_host", 0.0)) / tot,
+                                           "member_idle_frac": (bj["member1"].get("wait_phase", 0.0) + bj["member1"].get("wait_u", 0.0)) / bj["member1"]["total"],
+                                           "dense_idle_frac": (bj["dense"].get("wait_phase", 0.0) + bj["dense"].get("wait_part", 0.0)) / bj["dense"]["total"]}
+                except Exception as e:                                   # a malformed profile must not cost the bench line
+                    round_obj["budget"] = {"error": repr(e), "source": "profiles/" + name}
+                break
+
     if rank == 0:
         out = {
             "metric": "constraint-samples/s", "value": world * samples_per_step * args.steps / dt, "unit": "samples/s",
@@ -327,7 +458,8 @@ def main():
                                    f"({samples_per_step} constraint samples/step/GPU), 16-gate Zhangjiajie-like corridor, K_i=8",
                        "step": "one batched objective evaluation x->(f,grad): k_forward + k_penalty + k_backward, inputs resident in HBM",
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
-                       "parallelism": f"candidates sharded {B}/GPU, no data-path collective"},
+                       "parallelism": f"candidates sharded {B}/GPU, no data-path collective",
+                       "front_end": ("frx_multi_* in one process" if lib_mode else "one process per GPU (torch.distributed)") if world > 1 else "one process, one device"},
             "roofline": {"bound": "hbm", "kernel": pen_kernel, "selected_by": "the kernel SURVEY.md 8d prices: the penalty integrator (CPU.hpp:188-408 = cuda_computer::compute)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,
@@ -346,12 +478,13 @@ def main():
                                               "implementation_traffic_frac_of_hbm_peak": stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                               "traffic_range": knot_traffic.get(k), "traffic_from_profile": knot_traffic.get(k) is not None,
                                               "bound": "latency: one workgroup per candidate, a dependent FP64 chain (DESIGN.md 3.1, 3.3)"} for k in ("forward", "adjoint")},
-                         "hbm_bound_kernel": hbm_kernel, "states": states},
+                         "round": round_obj, "hbm_bound_kernel": hbm_kernel, "states": states},
             "cpu_baseline": cpu,
         }
         out.update(plan)
         print(json.dumps(out), flush=True)
     prob.close()
+    for sh in lib_shards: sh[0].close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -62,3 +62,48 @@ def select_winner(dist, device, local_objective: np.ndarray, local_ids: np.ndarr
     coeffs = buf[1:1 + 18 * n].reshape(6 * n, 3).copy()
     T = buf[1 + 18 * n_pieces_max:1 + 18 * n_pieces_max + n].copy()
     return gid, obj, owner, coeffs, T
+
+
+# ---- self-launch of the one-process-per-GPU front end (bench.py --gpus N without an external launcher) ----
+def _free_port() -> int:
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def self_launch_command(n_ranks: int, script: str, argv, port: int = 0):
+    """The command that starts `script argv` as n_ranks ranks of one node - what the driver runs for N > 1
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script ...`)."""
+    import sys
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), script] + list(argv)
+
+
+def ranks_to_launch(n_gpus: int, env, visible_devices: int) -> int:
+    """How many ranks THIS process has to start: 0 when it already is a rank of a launched job (WORLD_SIZE set) or when one rank was asked for.
+    Fails loudly - never degrades - when the job the flags describe cannot be what runs:
+      * a launcher started a world whose size is not --gpus;
+      * fewer devices are visible than ranks asked for (unless FRX_BENCH_DEVICE pins every rank to one device: the 1-GPU-box test knob)."""
+    n_gpus = int(n_gpus)
+    if n_gpus < 1:
+        raise SystemExit(f"--gpus {n_gpus}: at least one rank")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a {world}-rank run as {n_gpus} GPUs")
+        need = 0
+    else:
+        need = n_gpus if n_gpus > 1 else 0
+    if n_gpus > 1 and not env.get("FRX_BENCH_DEVICE") and visible_devices < n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} needs {n_gpus} HIP devices, {visible_devices} visible (FRX_BENCH_DEVICE=<d> puts every rank on one device: a control-flow test, not a measurement)")
+    return need
+
+
+def self_launch(n_ranks: int, script: str, argv, env=None) -> int:
+    """Run `script argv` as n_ranks ranks (one process per GPU) and return the job's exit code; rank 0's stdout is this process's stdout."""
+    import os
+    import subprocess
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on these hosts
+    e.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(self_launch_command(n_ranks, script, argv), env=e)

@@ -66,3 +66,48 @@ def test_single_rank_winner(frx):
     cost = np.array([3.0, 1.0, 2.0]); ids = np.array([10, 11, 12])
     gid, obj, owner, wc, wT = select_winner(None, torch.device("cpu"), cost, ids, lambda i: np.full((12, 3), float(i)), lambda i: np.full(2, 0.5), 2)
     assert (gid, obj, owner) == (11, 1.0, 0) and np.all(wc == 1.0) and wT.sum() == 1.0
+
+
+# ---- bench.py --gpus N starts its own ranks: the launch path, on CPU ----
+def _bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FRX_BENCH_DEVICE")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself(frx):
+    import json
+    p = _bench(["--gpus", "2", "--launch-check"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["launch_check"] is True and line["n_gpus"] == 2 and line["self_launched"] is True
+    # one rank: no launcher involved at all
+    p = _bench(["--gpus", "1", "--launch-check"])
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_to_degrade(frx):
+    # fewer devices than ranks (this container has none, a 1-GPU box has one): an error that says so, not a 1-rank run labelled N GPUs
+    if frx.lib().frx_device_count() < 2:
+        p = _bench(["--gpus", "2", "--no-plan", "--no-cpu-baseline"])
+        assert p.returncode != 0 and "needs 2 HIP devices" in p.stderr
+        p = _bench(["--gpus", "2", "--multi", "lib", "--no-plan", "--no-cpu-baseline"])
+        assert p.returncode != 0 and "needs 2 HIP devices" in p.stderr
+    # a launcher whose world is not --gpus
+    p = _bench(["--gpus", "2", "--launch-check"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+
+
+def test_self_launch_command_is_the_drivers(frx):
+    from fast_racing_amd.dist import self_launch_command, ranks_to_launch
+    cmd = self_launch_command(4, "/x/bench.py", ["--gpus", "4", "--steps", "5"], port=29400)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29400"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "5"]
+    assert ranks_to_launch(1, {}, 1) == 0 and ranks_to_launch(8, {}, 8) == 8 and ranks_to_launch(8, {"WORLD_SIZE": "8"}, 8) == 0
+    assert ranks_to_launch(2, {"FRX_BENCH_DEVICE": "0"}, 1) == 2          # the 1-GPU-box knob: every rank on one device
+    with pytest.raises(SystemExit):
+        ranks_to_launch(2, {}, 1)
