@@ -27,6 +27,8 @@
 #include "frx_device.hpp"
 #include "frx_internal.hpp"
 #include "frx_lbfgs.hpp"
+#include "frx_host_pool.hpp"
+#include "frx_host_setup.hpp"
 
 namespace {
 
@@ -49,103 +51,6 @@ struct HipEventPair {
 
 using clk = std::chrono::steady_clock;
 inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
-
-// ---- a tiny spinning thread pool (one evaluation round is ~100 us: no condvars) ----
-// Work is STATICALLY partitioned: item i always runs on worker i % n, and every worker is pinned to its
-// own CPU.  Each candidate's L-BFGS state (1.5 MB of (s, y) history at mem_size 128) is allocated, first
-// touched and then always updated by the same core, so it stays in that core's cache hierarchy.
-class SpinPool {
-public:
-    explicit SpinPool(int nthreads) : n_(std::max(1, nthreads)) {
-        cpu_set_t allowed;
-        CPU_ZERO(&allowed);
-        std::vector<int> cpus;
-        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
-            for (int c = 0; c < CPU_SETSIZE; c++)
-                if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
-        // Every live pool of the process pins its workers onto its OWN range of the allowed CPUs: pool k (the lowest free index, taken at
-        // construction, returned at destruction) uses CPUs [k n, (k + 1) n) of the list - several host threads driving separate handles
-        // (frx_multi: one per device) neither share cores nor depend on which pool was created first.  A pool whose range does not fit
-        // the allowed set runs unpinned.  The CALLER's thread is never pinned: its affinity is the caller's business.  FRX_PIN=0 disables
-        // pinning altogether; FRX_PIN_OFFSET / FRX_PIN_STRIDE choose which allowed CPUs the ranges are cut from.
-        const char *pe = std::getenv("FRX_PIN"), *po = std::getenv("FRX_PIN_OFFSET"), *ps = std::getenv("FRX_PIN_STRIDE");
-        const int off = po ? std::atoi(po) : 0, stride = std::max(1, ps ? std::atoi(ps) : 1);
-        live_pools().fetch_add(1, std::memory_order_acq_rel);
-        {
-            std::lock_guard<std::mutex> g(slot_lock());
-            std::vector<char> &used = slots();
-            size_t k = 0;
-            while (k < used.size() && used[k]) k++;
-            if (k == used.size()) used.push_back(0);
-            used[k] = 1; slot_ = (int)k;
-        }
-        const long first = (long)off + (long)slot_ * n_ * stride, last = first + (long)(n_ - 1) * stride;
-        const bool do_pin = !(pe && pe[0] == '0') && n_ > 1 && last < (long)cpus.size();
-        for (int t = 1; t < n_; t++) {
-            workers_.emplace_back([this, t] { loop(t); });
-            if (do_pin) pin(workers_.back().native_handle(), cpus[first + (long)t * stride]);
-        }
-    }
-    ~SpinPool() {
-        stop_.store(true, std::memory_order_release);
-        for (auto &w : workers_) w.join();
-        live_pools().fetch_sub(1, std::memory_order_acq_rel);
-        std::lock_guard<std::mutex> g(slot_lock());
-        if (slot_ >= 0 && slot_ < (int)slots().size()) slots()[slot_] = 0;
-    }
-    int size() const { return n_; }
-    // fn(i) for i in [0, count): worker t takes i = t, t + n, t + 2n, ...
-    template <class F> void run(int count, F &&fn) {
-        if (count <= 0) return;
-        if (n_ == 1) { for (int i = 0; i < count; i++) fn(i); return; }
-        fn_ = [&fn](int i) { fn(i); };
-        count_ = count;
-        pending_.store(n_ - 1, std::memory_order_relaxed);
-        epoch_.fetch_add(1, std::memory_order_release);
-        for (int i = 0; i < count; i += n_) fn_(i);
-        while (pending_.load(std::memory_order_acquire) > 0) cpu_relax();
-    }
-private:
-    static void cpu_relax() { __builtin_ia32_pause(); }
-    static void pin(pthread_t th, int cpu) {
-        cpu_set_t m;
-        CPU_ZERO(&m);
-        CPU_SET(cpu, &m);
-        pthread_setaffinity_np(th, sizeof(m), &m);
-    }
-    void loop(int t) {
-        unsigned seen = 0;
-        int idle = 0;
-        while (!stop_.load(std::memory_order_acquire)) {
-            unsigned e = epoch_.load(std::memory_order_acquire);
-            if (e != seen) {
-                seen = e;
-                for (int i = t; i < count_; i += n_) fn_(i);
-                pending_.fetch_sub(1, std::memory_order_release);
-                idle = 0;
-            } else if (++idle > (live_pools().load(std::memory_order_relaxed) > 1 ? 2000 : 200000)) { std::this_thread::yield(); idle = 0; }
-            else cpu_relax();
-        }
-    }
-    int n_, slot_ = -1;
-    static std::mutex &slot_lock() { static std::mutex m; return m; }
-    static std::vector<char> &slots() { static std::vector<char> v; return v; }
-    std::vector<std::thread> workers_;
-    std::function<void(int)> fn_;
-    int count_ = 0;
-    std::atomic<int> pending_{0};
-    std::atomic<unsigned> epoch_{0};
-    std::atomic<bool> stop_{false};
-    static std::atomic<int> &live_pools() { static std::atomic<int> n{0}; return n; }
-};
-
-// ---- per-candidate host description (what setup() keeps for the initial guess) ----
-struct HostCand {
-    int coarseN = 0, fineN = 0, dimT = 0, dimP = 0;
-    double iState[9], fState[9];                 // clipped copies (CPU.hpp:1166-1170)
-    std::vector<std::vector<double>> cfgVs;      // [v0, v_r - v0] (CPU.hpp:1049)
-    std::vector<int> intervals, idxVs;
-};
 
 template <class T> struct DevBuf {
     T *p = nullptr;
@@ -185,7 +90,7 @@ struct frx_problem {
     frx_config cfg;
     int device = 0, B = 0, P = 0, Pc = 0, NX = 0, Kmax = 0, maxN = 0, maxCN = 0, sumKfine = 0;
     bool softT = true;
-    std::vector<HostCand> cand;
+    std::vector<frx::HostCand> cand;
     std::vector<int> poff, coff, xoff, boff, dimT;
     frx::DevProblem dp;
     hipStream_t stream = nullptr;
@@ -237,98 +142,6 @@ struct frx_problem {
 
 namespace {
 
-// objectiveNLS (CPU.hpp:749-774): squared distance between a target point and the image of the
-// sphere parameterisation of one V-polytope; pobs = [target, v0, edges...]
-double nls_objective(const double *pobs, const double *x, double *grad, int n, std::vector<double> &r, std::vector<double> &gdr) {
-    double qn = 0.0;
-    for (int a = 0; a < n; a++) qn += x[a] * x[a];
-    const double qp1 = qn + 1.0, qp1sq = qp1 * qp1, sc = 2.0 / qp1;
-    r.resize(n); gdr.resize(n);
-    for (int a = 0; a < n; a++) r[a] = sc * x[a];
-    double delta[3];
-    for (int q = 0; q < 3; q++) {
-        double s = 0.0;
-        for (int a = 0; a < n; a++) s += pobs[3 * (a + 2) + q] * (r[a] * r[a]);
-        delta[q] = s + pobs[3 + q] - pobs[q];
-    }
-    const double cost = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2];
-    const double g3[3] = {2 * delta[0], 2 * delta[1], 2 * delta[2]};
-    for (int a = 0; a < n; a++)
-        gdr[a] = (pobs[3 * (a + 2)] * g3[0] + pobs[3 * (a + 2) + 1] * g3[1] + pobs[3 * (a + 2) + 2] * g3[2]) * r[a] * 2.0;
-    double gq = 0.0;
-    for (int a = 0; a < n; a++) gq += gdr[a] * x[a];
-    for (int a = 0; a < n; a++) grad[a] = gdr[a] * 2.0 / qp1 - x[a] * 4.0 * gq / qp1sq;
-    return cost;
-}
-
-void poly_centre(const std::vector<double> &V, double *c) {     // CPU.hpp:1018-1019 / 1206-1207
-    const int k = (int)(V.size() / 3) - 1;
-    for (int r = 0; r < 3; r++) {
-        double s = 0.0;
-        for (int a = 0; a < k; a++) s += V[3 * (a + 1) + r];
-        c[r] = s / (1.0 + k) + V[r];
-    }
-}
-double dist3(const double *a, const double *b) {
-    return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
-}
-
-// setInitial + backwardT + backwardP for one candidate (CPU.hpp:1188-1228, 679-726, 777-813)
-void initial_guess_one(const frx_problem &P, const HostCand &hc, double *x) {
-    const double vAlloc = std::min(P.cfg.vel_max, 10.0);                 // maxSpeedForAllocatiion, CPU.hpp:1193
-    const int M = hc.coarseN;
-    std::vector<double> vecT(M), inP(3 * (size_t)std::max(hc.fineN - 1, 0));
-    double lastP[3], curP[3] = {hc.iState[0], hc.iState[1], hc.iState[2]}, delta[3];
-    int offset = 0;
-    for (int i = 0; i < M; i++) {
-        std::memcpy(lastP, curP, sizeof(curP));
-        const int interv = hc.intervals[i];
-        if (i < M - 1) poly_centre(hc.cfgVs[2 * i + 1], curP);
-        else { curP[0] = hc.fState[0]; curP[1] = hc.fState[1]; curP[2] = hc.fState[2]; }
-        for (int r = 0; r < 3; r++) delta[r] = curP[r] - lastP[r];
-        vecT[i] = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]) / vAlloc;
-        for (int r = 0; r < 3; r++) delta[r] /= interv;
-        const int cnt = (i < M - 1) ? interv : interv - 1;
-        for (int j = 0; j < cnt; j++) {
-            for (int r = 0; r < 3; r++) inP[offset * 3 + r] = (j + 1) * delta[r] + lastP[r];
-            offset++;
-        }
-    }
-    // backwardT
-    const bool c2 = P.cfg.c2_diffeo != 0;
-    if (P.softT) {
-        for (int i = 0; i < M; i++)
-            x[i] = c2 ? (vecT[i] > 1.0 ? (std::sqrt(2.0 * vecT[i] - 1.0) - 1.0) : (1.0 - std::sqrt(2.0 / vecT[i] - 1.0)))
-                      : std::log(vecT[i]);
-    } else {
-        for (int i = 0; i < M - 1; i++) {
-            const double r = vecT[i] / vecT[M - 1];
-            x[i] = c2 ? (r > 1.0 ? (std::sqrt(2.0 * r - 1.0) - 1.0) : (1.0 - std::sqrt(2.0 / r - 1.0))) : std::log(r);
-        }
-    }
-    // backwardP: one tiny L-BFGS per waypoint (default parameters, g_epsilon = FLT_EPSILON, 128 iterations)
-    frx_lbfgs_params nls;
-    frx::lbfgs_defaults(nls);
-    nls.g_epsilon = FLT_EPSILON;
-    nls.max_iterations = 128;
-    double *p = x + hc.dimT;
-    int j = 0;
-    std::vector<double> pobs, grad, r, gdr;
-    for (int i = 0; i < hc.fineN - 1; i++) {
-        const std::vector<double> &V = hc.cfgVs[hc.idxVs[i]];
-        const int k = (int)(V.size() / 3) - 1;
-        for (int a = 0; a < k; a++) p[j + a] = 1.0 / (std::sqrt(k + 1.0) + 1.0);
-        pobs.resize(3 * (size_t)(k + 2));
-        for (int q = 0; q < 3; q++) pobs[q] = inP[i * 3 + q];
-        std::memcpy(&pobs[3], V.data(), sizeof(double) * 3 * (k + 1));
-        grad.assign(k, 0.0);
-        frx::Solver s;
-        s.start(k, p + j, grad.data(), nls);
-        while (!s.done()) s.feed(nls_objective(pobs.data(), p + j, grad.data(), k, r, gdr));
-        j += k;
-    }
-}
-
 int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *st, bool backward) {
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
@@ -367,6 +180,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     if (device < 0 || device >= ndev) return fail(FRX_ERR_INVALID_ARG, "device ordinal out of range");
     if (hipSetDevice(device) != hipSuccess) return fail(FRX_ERR_NO_DEVICE, "hipSetDevice failed");
 
+    const auto t_create0 = clk::now();
     frx_problem *p = new (std::nothrow) frx_problem();
     if (!p) return fail(FRX_ERR_ALLOC, "out of host memory");
     p->cfg = *cfg;
@@ -381,42 +195,15 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     std::vector<double> hrec, horg, vrec, head(ini_state, ini_state + 9 * (size_t)B), tail(fin_state, fin_state + 9 * (size_t)B);
     int hpoly = 0, vpoly = 0;                     // running polytope indices into h_off / v_off
     for (int b = 0; b < B; b++) {
-        HostCand &hc = p->cand[b];
+        frx::HostCand &hc = p->cand[b];
         const int cN = coarse_n[b];
         if (cN < 1) { delete p; return fail(FRX_ERR_INVALID_ARG, "coarse_n[b] < 1"); }
-        hc.coarseN = cN;
-        std::memcpy(hc.iState, ini_state + 9 * (size_t)b, sizeof(hc.iState));
-        std::memcpy(hc.fState, fin_state + 9 * (size_t)b, sizeof(hc.fState));
-        // V-polytopes: [v0, v_r - v0]
-        hc.cfgVs.resize(2 * cN - 1);
-        for (int m = 0; m < 2 * cN - 1; m++) {
-            const int beg = v_off[vpoly + m], nv = v_off[vpoly + m + 1] - beg;
-            if (nv < 1) { delete p; return fail(FRX_ERR_EMPTY_POLYTOPE, "a corridor polytope has no vertices"); }
-            hc.cfgVs[m].resize(3 * (size_t)nv);
-            const double *v = v_rec + 3 * (size_t)beg;
-            for (int r = 0; r < 3; r++) hc.cfgVs[m][r] = v[r];
-            for (int a = 1; a < nv; a++)
-                for (int r = 0; r < 3; r++) hc.cfgVs[m][3 * a + r] = v[3 * a + r] - v[r];
+        // host description: V-polytopes as [v0, v_r - v0], gridMesh, waypoint index map, clipped boundary speeds (frx_host_setup.hpp)
+        if (frx::host_cand_init(hc, *cfg, p->softT, cN, ini_state + 9 * (size_t)b, fin_state + 9 * (size_t)b, v_off + vpoly, v_rec) != FRX_OK) {
+            delete p; return fail(FRX_ERR_EMPTY_POLYTOPE, "a corridor polytope has no vertices");
         }
         cvoff[b] = (int)(vrec.size() / 3);
-        // gridMesh (CPU.hpp:1003-1029)
-        hc.intervals.assign(cN, 1);
-        {
-            double lastP[3], curP[3] = {hc.iState[0], hc.iState[1], hc.iState[2]};
-            for (int i = 0; i < cN; i++) {
-                std::memcpy(lastP, curP, sizeof(curP));
-                if (i < cN - 1) poly_centre(hc.cfgVs[2 * i + 1], curP);
-                else { curP[0] = hc.fState[0]; curP[1] = hc.fState[1]; curP[2] = hc.fState[2]; }
-                const int cur = (int)std::ceil(dist3(curP, lastP) / cfg->grid_res);
-                hc.intervals[i] = cur > 0 ? cur : 1;
-            }
-        }
-        hc.fineN = 0;
-        for (int i = 0; i < cN; i++) hc.fineN += hc.intervals[i];
-        hc.dimT = p->softT ? cN : cN - 1;                               // CPU.hpp:1131
         // index maps (CPU.hpp:1129-1152), expanded into per-piece / per-waypoint device descriptors
-        hc.idxVs.assign(std::max(hc.fineN - 1, 0), 0);
-        hc.dimP = 0;
         const int gp0 = p->poff[b], gc0 = p->coff[b];
         int offset = 0;
         int xcur = p->xoff[b] + hc.dimT;
@@ -442,9 +229,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
                 if (j < hc.intervals[i] - 1) vm = 2 * i;
                 else if (i < cN - 1) vm = 2 * i + 1;
                 if (vm >= 0) {
-                    hc.idxVs[offset] = vm;
                     const int nv = (int)(hc.cfgVs[vm].size() / 3);
-                    hc.dimP += nv - 1;
                     wp_vbeg.push_back((int)(vrec.size() / 3)); wp_nv.push_back(nv); wp_xbeg.push_back(xcur);
                     vrec.insert(vrec.end(), hc.cfgVs[vm].begin(), hc.cfgVs[vm].end());   // waypoint order, contiguous per candidate
                     xcur += nv - 1;
@@ -453,12 +238,6 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
                 p->sumKfine += K;
                 offset++;
             }
-        }
-        // legal boundary speed on the copies only (CPU.hpp:1166-1170)
-        for (double *st : {hc.iState, hc.fState}) {
-            const double tn = std::sqrt(st[3] * st[3] + st[4] * st[4] + st[5] * st[5]);
-            const double sc = tn > cfg->vel_max ? (cfg->vel_max / tn) : 1.0;
-            for (int r = 0; r < 3; r++) st[3 + r] *= sc;
         }
         hpoly += cN;
         vpoly += 2 * cN - 1;
@@ -539,6 +318,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
             return fail(e_ == hipErrorOutOfMemory ? FRX_ERR_ALLOC : FRX_ERR_HIP, m_);                   \
         }                                                                                               \
     } while (0)
+    const double ms_host_build = ms_since(t_create0);
     CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     CR((hipError_t)frx::launch_set_limits(p->geo));
     CR(p->d_cvoff.upload(cvoff)); CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
@@ -583,6 +363,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
     d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
     d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.wq_glob = p->d_wq.p; d.stamps = nullptr; d.cand_active = nullptr; d.piece_active = nullptr;
+    if (std::getenv("FRX_SETUP_TIMING")) fprintf(stderr, "[frx setup] frx_problem_create: B = %d, host descriptors %.3f ms, device allocations + uploads %.3f ms\n", B, ms_host_build, ms_since(t_create0) - ms_host_build);
     *out = p;
     return FRX_OK;
 }
@@ -764,9 +545,7 @@ int frx_problem_layout(const frx_problem *p, int *piece_off, int *coarse_off, in
 
 int frx_initial_guess(frx_problem *p, double *x0) {
     if (!p || !x0) return fail(FRX_ERR_INVALID_ARG, "null argument");
-    const int nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)p->B));
-    SpinPool pool(nt);
-    pool.run(p->B, [&](int b) { initial_guess_one(*p, p->cand[b], x0 + p->xoff[b]); });
+    frx::initial_guess_batch(p->cfg, p->softT, p->cand, p->xoff.data(), x0);     // one flat task list over (candidate, waypoint)
     return FRX_OK;
 }
 
@@ -868,7 +647,7 @@ template <class EvalAll>
 static int drive_batch(int count, const int *x_off, double *x, double *g, double *f, const frx_lbfgs_params &pm, int n_threads,
                        int *status, int *iters, int *evals, double *f_out, double *stats, EvalAll &&eval_all) {
     std::vector<frx::Solver> sv(count);
-    SpinPool pool(std::min(n_threads, count));
+    frx::SpinPool pool(std::min(n_threads, count));
     // allocation + first touch of each solver's history by its owning (pinned) worker
     pool.run(count, [&](int i) { sv[i].start(x_off[i + 1] - x_off[i], x + x_off[i], g + x_off[i], pm); });
     std::vector<int> active;

@@ -15,6 +15,8 @@
 // every vertex order); here vertices are sorted lexicographically so that the order is a function of the polytope alone.
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -23,6 +25,7 @@
 
 #include "../../include/frx.h"
 #include "frx_internal.hpp"
+#include "frx_host_pool.hpp"
 
 namespace {
 
@@ -399,29 +402,37 @@ int frx_enumerate_vertices(int K, const double *h_rec, double *v_out, int cap, i
 int frx_problem_create_from_h(const frx_config *cfg, int device, int B, const int *coarse_n, const double *ini_state,
                               const double *fin_state, const int *h_off, const double *h_rec, frx_problem **out) {
     if (!cfg || !coarse_n || !h_off || !h_rec || !out || B <= 0) return frx::set_error(FRX_ERR_INVALID_ARG, "frx_problem_create_from_h: null argument or B <= 0");
-    std::vector<int> v_off{0};
-    int verdict = POLY_OK;
-    std::vector<double> v_rec;
-    std::vector<std::array<double, 3>> vs;
-    std::vector<double> both;
+    // extractVs (se3gcopter_cpu.hpp:1031-1074) enumerates every cell and every overlap of consecutive cells, one after the other, inside the
+    // reference's plan timer.  The 2 cN - 1 polytopes of every candidate are independent: one flat task list for the thread pool, results
+    // concatenated in polytope order afterwards (the output does not depend on the number of threads).
+    struct Task { int hb, K, K2, poly; };                                // K2 > 0: overlap of cell `poly` with the next one
+    std::vector<Task> tasks;
     int poly = 0;
     for (int b = 0; b < B; b++) {
         for (int i = 0; i < coarse_n[b]; i++) {
             const int hb = h_off[poly + i], K = h_off[poly + i + 1] - hb;
-            enumerate(K, h_rec + 6 * (size_t)hb, vs, &verdict);
-            if (verdict != POLY_OK) return polytope_error(verdict, "corridor cell", poly + i);
-            v_off.push_back(v_off.back() + (int)vs.size());
-            for (const auto &v : vs) v_rec.insert(v_rec.end(), v.begin(), v.end());
-            if (i + 1 < coarse_n[b]) {                               // overlap of consecutive cells (se3gcopter_cpu.hpp:1052-1054)
-                const int K2 = h_off[poly + i + 2] - h_off[poly + i + 1];
-                both.assign(h_rec + 6 * (size_t)hb, h_rec + 6 * (size_t)(hb + K + K2));
-                enumerate(K + K2, both.data(), vs, &verdict);
-                if (verdict != POLY_OK) return polytope_error(verdict, "overlap of corridor cells", poly + i);
-                v_off.push_back(v_off.back() + (int)vs.size());
-                for (const auto &v : vs) v_rec.insert(v_rec.end(), v.begin(), v.end());
-            }
+            tasks.push_back({hb, K, 0, poly + i});
+            if (i + 1 < coarse_n[b]) tasks.push_back({hb, K, h_off[poly + i + 2] - h_off[poly + i + 1], poly + i});
         }
         poly += coarse_n[b];
+    }
+    const int NT = (int)tasks.size();
+    std::vector<std::vector<std::array<double, 3>>> res(NT);
+    std::vector<int> verdicts(NT, POLY_OK);
+    auto work = [&](int t) {
+        const Task &k = tasks[t];
+        enumerate(k.K + k.K2, h_rec + 6 * (size_t)k.hb, res[t], &verdicts[t]);    // (an overlap's records are the two cells' records, contiguous in h_rec)
+    };
+    const auto tdbg0 = std::chrono::steady_clock::now();
+    const int nthr = frx::setup_threads(NT, 4.0);                                                // ~4 us per polytope (8 ... 16 planes)
+    frx::TaskPool::get().run(NT, nthr, [&](int t, int) { work(t); });
+    if (std::getenv("FRX_SETUP_TIMING")) fprintf(stderr, "[frx setup] H->V enumeration: %d polytopes on %d threads, %.3f ms\n", NT, nthr, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tdbg0).count());
+    std::vector<int> v_off{0};
+    std::vector<double> v_rec;
+    for (int t = 0; t < NT; t++) {                                          // first failing polytope in order, as the serial walk reported it
+        if (verdicts[t] != POLY_OK) return polytope_error(verdicts[t], tasks[t].K2 ? "overlap of corridor cells" : "corridor cell", tasks[t].poly);
+        v_off.push_back(v_off.back() + (int)res[t].size());
+        for (const auto &v : res[t]) v_rec.insert(v_rec.end(), v.begin(), v.end());
     }
     return frx_problem_create(cfg, device, B, coarse_n, ini_state, fin_state, h_off, h_rec, v_off.data(), v_rec.data(), out);
 }

@@ -232,3 +232,24 @@ extern "C" int hostcheck_first_trial(double ftol, double gtol, double min_step, 
     if (fast) *fast = a; if (full) *full = b;
     return a == b;
 }
+
+// ---- host side of setup() and the reference's initial guess (fast-racing_amd/csrc/frx_host_setup.hpp), without a device ----
+// The library builds the same HostCand records inside frx_problem_create and calls the same initial_guess_batch from frx_initial_guess;
+// here they run alone so that the initial guess (incl. the nested NLS solves of backwardP) is checked against the oracle on a CPU-only box.
+#include "../../fast-racing_amd/csrc/frx_host_setup.hpp"
+
+extern "C" int hostcheck_initial_guess(const frx_config *cfg, int B, const int *coarse_n, const double *ini_state, const double *fin_state,
+                                       const int *v_off, const double *v_rec, int *x_off /* B + 1 */, double *x0, int cap) {
+    const bool softT = cfg->rho > 0;
+    std::vector<frx::HostCand> cand(B);
+    int vpoly = 0;
+    x_off[0] = 0;
+    for (int b = 0; b < B; b++) {
+        if (frx::host_cand_init(cand[b], *cfg, softT, coarse_n[b], ini_state + 9 * (size_t)b, fin_state + 9 * (size_t)b, v_off + vpoly, v_rec) != FRX_OK) return -1;
+        vpoly += 2 * coarse_n[b] - 1;
+        x_off[b + 1] = x_off[b] + cand[b].dimT + cand[b].dimP;
+    }
+    if (x_off[B] > cap) return -2;
+    frx::initial_guess_batch(*cfg, softT, cand, x_off, x0);
+    return x_off[B];
+}

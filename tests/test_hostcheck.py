@@ -43,3 +43,39 @@ def test_reverse_mode_penalty_matches_oracle(hc, sc, ob, obst, kappa):
             assert abs(out[:, 0].sum() - cost) <= 1e-11 * max(abs(cost), 1e-300)
             assert np.abs(out[:, 1] - gdT).max() <= 1e-10 * max(np.abs(gdT).max(), 1e-300)
             assert np.abs(out[:, 2:].reshape(-1, 3) - gdC).max() <= 1e-10 * max(np.abs(gdC).max(), 1e-300)
+
+
+# ---- host side of setup() + the reference's initial guess (frx_host_setup.hpp), the code frx_initial_guess runs, on a CPU-only box ----
+def _host_guess(hc, frx, cands, params, kappa, threads=None):
+    cfg = frx.FrxConfig.from_params(params, qd_intervals=kappa)
+    coarse_n, ini, fin, h_off, h_rec, v_off, v_rec = frx.pack_batch(cands)
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"); ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    hc.hostcheck_initial_guess.restype = C.c_int
+    hc.hostcheck_initial_guess.argtypes = [C.POINTER(frx.FrxConfig), C.c_int, ip, dp, dp, ip, dp, ip, dp, C.c_int]
+    x_off = np.zeros(len(cands) + 1, np.int32); x0 = np.zeros(4096 * len(cands))
+    old = os.environ.get("FRX_SETUP_THREADS")
+    if threads is not None: os.environ["FRX_SETUP_THREADS"] = str(threads)
+    try:
+        n = hc.hostcheck_initial_guess(C.byref(cfg), len(cands), coarse_n, ini, fin, v_off, v_rec, x_off, x0, x0.size)
+    finally:
+        if threads is not None:
+            if old is None: del os.environ["FRX_SETUP_THREADS"]
+            else: os.environ["FRX_SETUP_THREADS"] = old
+    assert n > 0
+    return x_off, x0[:n].copy()
+
+
+def test_initial_guess_of_the_host_code_matches_the_oracle_whatever_the_thread_count(hc, frx, sc, ob):
+    """setInitial / backwardT / backwardP (CPU.hpp:1188-1228, 679-726, 777-813) as the library runs them - a flat task list over (candidate,
+    waypoint) - against the oracle's restatement (itself pinned to the compiled reference at 1e-13, tests/test_reference_pin.py)."""
+    P = sc.ZHANGJIAJIE
+    cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(6)] + [sc.make_candidate(7, 12, 3, obstacles=True), sc.make_candidate(9, 1, 0)]
+    x_off, x_ser = _host_guess(hc, frx, cands, P, 16, threads=1)
+    for b, c in enumerate(cands):
+        o = ob.Oracle(c, P, qd_intervals=16)
+        ref = o.initial_guess()
+        assert x_off[b + 1] - x_off[b] == ref.size
+        assert np.abs(x_ser[x_off[b]:x_off[b + 1]] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    for nt in (2, 5, 8):                                           # the same solves in the same arithmetic: bit-identical for every partition
+        _, x_par = _host_guess(hc, frx, cands, P, 16, threads=nt)
+        assert np.array_equal(x_par, x_ser)
