@@ -277,6 +277,10 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) simds = 4 * prop.multiProcessorCount; }
         if ((p->P + ge.ppw - 1) / ge.ppw <= simds) best_w = 1;
         if (const char *pw = std::getenv("FRX_PENALTY_WAVES")) { const int w = std::atoi(pw); if (w >= 1 && w <= 4) best_w = w; }
+        //  W is chosen for lane utilisation, but the workgroup's LDS grows with it (ppg corridor blocks of Kmax + 1 records): step W down
+        // until the block fits the CU - a corridor with many half-spaces runs on fewer waves instead of failing create
+        auto pen_lds = [&](int w) { const int ppg = (64 * w) / ge.lpp; return sizeof(double) * ((size_t)ppg * 19 + (size_t)ppg * (p->Kmax + 1) * 4 + (size_t)64 * w * 21); };
+        while (best_w > 1 && pen_lds(best_w) > (size_t)160 * 1024) best_w--;
         ge.pen_w = best_w; ge.ppg = (64 * best_w) / ge.lpp;
     }
     ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
@@ -1073,7 +1077,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     if (std::getenv("FRX_RESIDENT_HOST_STATS")) {                                     // diagnostic: how often a service thread looks at each of its mailboxes
         const double wall_us = 1e3 * ms_since(t0);
-        for (int tid = 0; tid < nsrv; tid++) std::fprintf(stderr, "[frx] mailbox thread %d: %ld scans of %d mailboxes in %.0f us = %.3f us per scan, busy %.1f ms\n", tid, scans[tid], (int)((long)B * (tid + 1) / nsrv) - (int)((long)B * tid / nsrv), wall_us, wall_us / std::max(1L, scans[tid]), t_host_thr[tid]);
+        for (int tid = 0; tid < nsrv; tid++) std::fprintf(stderr, "[frx] mailbox thread %d: %ld scans of %d mailboxes in %.0f us = %.3f us per scan, busy %.1f ms\n", tid, scans[tid], (int)((long)S * (tid + 1) / nsrv) - (int)((long)S * tid / nsrv), wall_us, wall_us / std::max(1L, scans[tid]), t_host_thr[tid]);
     }
     int rc = FRX_OK;
     double t_host = 0.0;
@@ -1177,6 +1181,7 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
         // chip (one workgroup per CU, B x G of them), with the per-stage path as fallback when it does not or when the device gives up
         const char *rs_env = std::getenv("FRX_RESIDENT");
         p->resident_used = 0; p->resident_retried = 0;
+        p->resident_failed = 0; p->resident_clusters = 0; for (auto &q : p->spec_counts) q = 0;      //  diagnostics of THIS plan, whichever path it takes
         if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0) {
             const std::vector<double> x_start(x, x + p->NX);
             rc_dv = optimize_resident(p, *params, x, status, iters, evals, objective);
@@ -1185,15 +1190,24 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
             else {
                 // A candidate that ends with an L-BFGS error on the resident kernel keeps that verdict, as it would in the reference
                 // (lbfgs_optimize returns the code, SE3GCOPTER::optimize ignores it, CPU.hpp:1249): on the Monte-Carlo and perturbation
-                // shares the resident kernel fails on no more candidates than the CPU oracle does (tests/test_gpu_configs.py).  Round 2
-                // re-ran such candidates on the per-stage rounds - a second chance the reference does not take, 2-3x the plan time for the
-                // batch that contains one; that re-run is now a diagnostic (frx_debug_set_resident_retry / FRX_RESIDENT_RETRY=1).
+                // shares the resident kernel fails on no more candidates than the CPU oracle does (tests/test_gpu_configs.py) - with ONE
+                // exception.  The resident kernel forms d = -H g in the compact representation (R^-1 maintained incrementally), the
+                // reference by the two-loop recursion; in exact arithmetic H is positive definite in both and d is a descent direction.  A
+                // search that starts with g.d >= 0 (LBFGSERR_INCREASEGRADIENT, lbfgs.hpp:766) can therefore only be the work of rounding in
+                // the direction itself - an ill-conditioned R - and says nothing about the candidate: such candidates, and only those, are
+                // planned again on the per-stage rounds, whose direction kernel IS the two-loop recursion.  Line searches that give up
+                // (-1005, -1007: infeasible corridors, the CPU oracle's verdict as well) are final.  frx_debug_set_resident_retry(p, 1) /
+                // FRX_RESIDENT_RETRY=1 re-run every failed candidate (diagnostic), FRX_RESIDENT_RETRY=0 none.
                 const char *rt_env = std::getenv("FRX_RESIDENT_RETRY");
-                const bool retry = rt_env ? rt_env[0] != '0' : p->resident_retry != 0;
-                if (retry && p->resident_failed > 0) {
+                const int retry_mode = rt_env ? (rt_env[0] == '0' ? 0 : rt_env[0] == 't' ? 2 : 1) : (p->resident_retry != 0 ? 1 : 2);   // 2 = targeted (default)
+                auto wants_retry = [&](int st) { return st < 0 && st != frx::LBERR_MAXIMUMITERATION && (retry_mode == 1 || (retry_mode == 2 && st == frx::LBERR_INCREASEGRADIENT)); };
+                int n_retry = 0;
+                for (int b = 0; b < p->B; b++) n_retry += wants_retry(status[b]) ? 1 : 0;
+                const bool retry = n_retry > 0;
+                if (retry) {
                     std::vector<char> again(p->B, 0);
                     int n_again = 0;
-                    for (int b = 0; b < p->B; b++) if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
+                    for (int b = 0; b < p->B; b++) if (wants_retry(status[b])) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
                     const int used = p->resident_used;
                     const double t_res = p->stats[0];
                     const int rc2 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);

@@ -34,7 +34,8 @@ namespace frx {
 // the one that brings it to B * round writes `round` into a word of mapped host memory, on which the host spins instead of
 // polling the stream through the driver (the reference's cuda_computer signals completion the same way, cc.cu:384-405, 537-547).
 // `lds_out` (persistent round kernel): the four values go to this LDS array {f, g.d, x.x, g.g} instead of `res`, whatever the flags.
-// `early_cmd` (resident round kernel, optional): a word of mapped HOST memory that thread 0 reads while the adjoint runs and leaves in lds_out[7] (bit pattern) - the host's
+// `early_cmd` (resident round kernel, optional): a command {word, step} in mapped HOST memory that thread 0 reads while the adjoint runs and leaves in lds_out[7], lds_out[6] (bit
+// patterns; word first: the host writes the step first and the word last, so a word with the expected sequence number comes with its step) - the host's
 // command for a round the leader started on a prediction.  The read crosses PCIe (1-2.5 us with 32 leaders polling): it is issued only AFTER thread 0's wave has consumed its
 // first batch of loads - vmcnt completes in order, so issued in front of them it held up the wave's whole chain by the PCIe round trip (measured: adjoint 6.5 us with one
 // candidate on the chip, 7.5 us with 32).
@@ -1348,7 +1349,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     }
     FRX_STAMP(17);
     double costAcc = 0.0, gTl = 0.0;
-    unsigned long long early_word = 0;
+    unsigned long long early_word = 0, early_step = 0;
     if (wave == 0) {
         // ---- jerk energy + its duration gradient (CPU.hpp:507-520, 65-75) on top of the penalty partials ----
         if (piece) {
@@ -1365,7 +1366,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         // (s_waitcnt vmcnt(0) in front of the loop in the ISA, even with the values passed through an in/out asm).  The table entry
         // therefore travels through LDS: lane kk parks it in gCo[kk], which the same lane overwrites with its result.
         if (kk < cN) gCo[kk] = (double)(r_iv + (r_fb << 10));
-        if (tap.early_cmd && k == 0) early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // behind the wave's first loads (see LineSearchTap)
+        if (tap.early_cmd && k == 0) { early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); early_step = __hip_atomic_load(tap.early_cmd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // behind the wave's first loads (see LineSearchTap)
     } else {
         const int ax = wave - 1;
         const bool act = kk >= 1 && kk <= N - 1;
@@ -1559,7 +1560,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             const double fval = red[0];
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
-            if (tap.lds_out) { tap.lds_out[0] = fval; tap.lds_out[1] = a0; tap.lds_out[2] = a1; tap.lds_out[3] = a2; if (tap.early_cmd) tap.lds_out[7] = __longlong_as_double((long long)early_word); }
+            if (tap.lds_out) { tap.lds_out[0] = fval; tap.lds_out[1] = a0; tap.lds_out[2] = a1; tap.lds_out[3] = a2; if (tap.early_cmd) { tap.lds_out[7] = __longlong_as_double((long long)early_word); tap.lds_out[6] = __longlong_as_double((long long)early_step); } }
             else { DvResult *r = tap.res + b; r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2; }
         }
         if (k == 0 && tap.arrive) {
@@ -1673,8 +1674,8 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         for (int ax = 0; ax < 3; ax++) { KN(KP, ax, k) = c[ax]; KN(KV, ax, k) = c[3 + ax]; KN(KA, ax, k) = 2.0 * c[6 + ax]; }
     }
     if (k < 3) { KN(KP, k, N) = r_tl[0]; KN(KV, k, N) = r_tl[1]; KN(KA, k, N) = r_tl[2]; }
-    unsigned long long early_word = 0;
-    if (tap.early_cmd && k == 0) early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // behind the first loads (see LineSearchTap)
+    unsigned long long early_word = 0, early_step = 0;
+    if (tap.early_cmd && k == 0) { early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); early_step = __hip_atomic_load(tap.early_cmd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // behind the first loads (see LineSearchTap)
     __syncthreads();
 
     FRX_STAMP(18);
@@ -1863,7 +1864,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
         if (k == 0 && ((tap_flags & DV_EVAL) || tap.lds_out)) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
-            if (tap.lds_out) { tap.lds_out[0] = fval; tap.lds_out[1] = a0; tap.lds_out[2] = a1; tap.lds_out[3] = a2; if (tap.early_cmd) tap.lds_out[7] = __longlong_as_double((long long)early_word); }
+            if (tap.lds_out) { tap.lds_out[0] = fval; tap.lds_out[1] = a0; tap.lds_out[2] = a1; tap.lds_out[3] = a2; if (tap.early_cmd) { tap.lds_out[7] = __longlong_as_double((long long)early_word); tap.lds_out[6] = __longlong_as_double((long long)early_step); } }
             else { DvResult *r = tap.res + b; r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2; }
         }
         if (k == 0 && tap.arrive) {

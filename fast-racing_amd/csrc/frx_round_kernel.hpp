@@ -461,16 +461,19 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             if (unconfirmed) {
                 // Common case first, without a barrier: the word thread 0 read while the adjoint ran (ctlD[7], in LDS behind the adjoint's last
                 // barrier) is this round's command and equals the predicted one - every thread sees the same word and decides alike.
-                const rk_u64 we = (rk_u64)__double_as_longlong(ctlD[7]);
-                if ((a.fast_control & 1) && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word) unconfirmed = false;
+                // A predicted TRIAL step is confirmed on the step's own 64 bits, read with the word (the word carries only a 24-bit fold of them).
+                const rk_u64 we = (rk_u64)__double_as_longlong(ctlD[7]), se = (rk_u64)__double_as_longlong(ctlD[6]);
+                const bool step_ok = run_kind != 2 || se == (rk_u64)__double_as_longlong(step);
+                if ((a.fast_control & 1) && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word && step_ok) unconfirmed = false;
             }
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
                     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                    rk_u64 w = (rk_u64)__double_as_longlong(ctlD[7]);
+                    rk_u64 w = 0, stp_now = 0;                                  // word and step in ONE 16-byte read: they belong together
                     bool ok = true;
-                    for (unsigned spins = 0; (w >> 32) != hseq; spins++) {
-                        w = __hip_atomic_load(&a.h_cmd[k * a.cmd_stride].word, FRX_RLX_SYS);
+                    for (unsigned spins = 0;; spins++) {
+                        rk_load_cmd(a.h_cmd + k * a.cmd_stride, w, stp_now);
+                        if ((w >> 32) == hseq) break;
                         if ((spins & 15u) == 15u && rk_expired(a, dl)) { ok = false; break; }
                     }
                     // 0 confirmed; 1 the host stopped (QUIT): the accepted point is the result; 2 a disagreement that cannot be undone (the history has
@@ -479,17 +482,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     // host's command executed (xp, gp, d are untouched by a trial)
                     unsigned verdict = 0u;
                     if (!ok) { rk_fail(a, RK_ERR_HOST); verdict = 2u; }
-                    else if ((unsigned)w != (unsigned)pred_word) {
+                    else if ((unsigned)w != (unsigned)pred_word || (run_kind == 2 && stp_now != (rk_u64)__double_as_longlong(step))) {
                         if ((unsigned)w & (unsigned)(DV_QUIT | DV_NEXT)) { verdict = 1u; ctlU[2] = (unsigned)w; }
                         else verdict = (run_kind == 2 && !((unsigned)w & (unsigned)(DV_ADVANCE | DV_INIT))) ? 3u : 2u;
                     }
                     if (verdict == 2u) { rk_fail(a, RK_ERR_SPECULATION); __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); }
-                    if (verdict == 3u) {                                     // the whole command, word and step in one 16-byte read
-                        rk_u64 w2 = 0, stp = 0;
-                        rk_load_cmd(a.h_cmd + k * a.cmd_stride, w2, stp);
-                        ctlU[2] = (unsigned)w2; ctlD[5] = __longlong_as_double((long long)stp);
-                        n_redone++;
-                    }
+                    if (verdict == 3u) { ctlU[2] = (unsigned)w; ctlD[5] = __longlong_as_double((long long)stp_now); n_redone++; }   // the whole command came with the read above
                     ctlU[1] = verdict;
                 }
                 __syncthreads();

@@ -32,10 +32,11 @@ int frx_resident_profile(const frx_problem *p, unsigned long long *out, int cap_
  * (*row_doubles = 4 nxp + 2 doubles, vectors zero-padded from n to nxp); *rows = records written (<= cap_steps); out may be NULL. */
 int frx_debug_direction_log(frx_problem *p, int cap_steps, int n_cands);
 int frx_debug_direction_log_read(const frx_problem *p, int cand, double *out, int cap_rows, int *rows, int *row_doubles);
-/* Round 2 re-ran, on the per-stage rounds, every candidate that ended with an L-BFGS error on the resident kernel; the default now keeps
- * the resident kernel's verdict like the reference keeps lbfgs_optimize's.  enable = 1 restores the re-run on this handle (environment:
- * FRX_RESIDENT_RETRY=0|1 overrides).  frx_debug_resident_counts: candidates of the last resident plan that ended with an L-BFGS error
- * other than the iteration limit, and how many of them were re-run. */
+/* A candidate that ends with an L-BFGS error on the resident kernel keeps that verdict, like the reference keeps lbfgs_optimize's - except
+ * LBFGSERR_INCREASEGRADIENT (a search that starts uphill: only rounding in the compact-form direction can produce it, the two-loop recursion of
+ * the per-stage rounds would not), which is planned again on the per-stage rounds by default.  enable = 1: re-run EVERY failed candidate (round 2's
+ * behaviour, diagnostic); environment FRX_RESIDENT_RETRY=0|1|t(argeted) overrides.  frx_debug_resident_counts: candidates of the last plan that
+ * ended with an L-BFGS error other than the iteration limit on the resident kernel, and how many were re-run. */
 int frx_debug_set_resident_retry(frx_problem *p, int enable);
 int frx_debug_resident_counts(const frx_problem *p, int *failed, int *retried);
 /* Clusters of the last resident plan: = batch size when the batch fitted the chip, fewer when the candidates went through the work queue. */
