@@ -25,6 +25,10 @@ CASES = {
     "n16_k16_obst": (22, 1, 16, 4, 16, True, {}),
     "n12_k48_stock": (23, 0, 12, 3, 48, False, {}),
     "n10_fixedT_exp": (24, 2, 10, 2, 8, False, dict(rho=0.0, total_t=6.0, c2_diffeo=0)),
+    # the size every number of the bench line is quoted on (BASELINE.json configs[2]: 64 pieces x kappa 16): candidate 0 of the bench batch
+    # (K_i = 8) and a perturbed candidate of the same scenario with obstacle planes (K_i = 8 ... 14)
+    "headline_n64_k16": (0, 0, 64, 16, 16, False, {}),
+    "n64_k16_obst": (0, 3, 64, 16, 16, True, {}),
 }
 
 
@@ -57,6 +61,30 @@ def build(name):
     return out
 
 
+def build_refvs(sid=25, N=16, gates=4, kappa=8):
+    """The `Candidate` overload of INTEGRATION.md 2: the caller keeps geoutils::enumerateVs on the reference side and hands the vertices over.
+    The V-polytopes here are the REFERENCE's own (its Seidel LP + quickhull order, geoutils.hpp:43-149 - NOT the lexicographic order of
+    frx_enumerate_vertices), so x lives in the reference's xi parameterisation; ref_* are the reference's outputs in that parameterisation."""
+    cand = sc.make_candidate(sid, N, gates, obstacles=True)
+    R = ob.Reference(cand, sc.ZHANGJIAJIE, override_vs=False, qd_intervals=kappa)          # its own enumerateVs
+    vs = [R.vpoly(m) for m in range(2 * N - 1)]
+    cand_r = sc.Candidate(cand.ini_state, cand.fin_state, cand.h_polys, vs, cand.gates)
+    o = ob.Oracle(cand_r, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x0 = R.initial_guess()
+    xs = [x0, o.optimize(1e-6, max_iterations=10, x0=x0)["x"], o.optimize(1e-6, max_iterations=120, x0=x0)["x"]]
+    rf, rg, rT, rC = [], [], [], []
+    for x in xs:
+        f, g = R.objective(x); rf.append(f); rg.append(g)
+        T, Cf = R.forward(x); rT.append(T); rC.append(Cf)
+    ro = o.optimize(1e-6, x0=x0)
+    v_off = np.cumsum([0] + [v.shape[1] for v in vs]).astype(np.int32)
+    differs = sum(int(v.shape != w.shape or np.abs(v - w).max() > 1e-6) for v, w in zip(vs, cand.v_polys))
+    return dict(case=np.array([sid, 0, N, gates, kappa, 1]), v_off=v_off, v_rec=np.concatenate([v.T.reshape(-1) for v in vs]), x=np.array(xs),
+                ref_x0=x0, ref_f=np.array(rf), ref_g=np.array(rg), ref_T=np.array(rT), ref_C=np.array(rC),
+                opt_obj=np.array(ro["objective"]), opt_status=np.array(ro["status"]), opt_iters=np.array(ro["iters"]),
+                polytopes_in_another_order_than_the_library=np.array(differs))
+
+
 def build_corridor(seed):
     """Corridor fixture: cells by the REFERENCE's decomp_util (oracle/_ref/libref_decomp.so) inside the oracle's restatement
     of the corridor loop of MavGlobalPlanner::plan, on a synthetic front-end path and point cloud."""
@@ -86,6 +114,10 @@ if __name__ == "__main__":
         print("corridor_seed5:", len(d["h_off"]) - 1, "cells,", int(d["h_off"][-1]), "half-spaces")
     if "--corridor-only" in sys.argv:
         sys.exit(0)
+    if ob.ref_gcopter() is not None:
+        d = build_refvs()
+        np.savez_compressed(os.path.join(os.path.dirname(__file__), "refvs_n16_k8_obst.npz"), **d)
+        print("refvs_n16_k8_obst: f =", d["ref_f"], "polytopes whose vertex order differs from frx_enumerate_vertices:", int(d["polytopes_in_another_order_than_the_library"]), "of", len(d["v_off"]) - 1)
     for name in CASES:
         d = build(name)
         np.savez_compressed(os.path.join(os.path.dirname(__file__), name + ".npz"), **d)

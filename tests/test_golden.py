@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 sys_path = os.path.join(ROOT, "tests", "golden")
-FILES = sorted(f for f in glob.glob(os.path.join(sys_path, "*.npz")) if not os.path.basename(f).startswith("corridor_"))   # corridor fixtures: test_next_rows.py
+FILES = sorted(f for f in glob.glob(os.path.join(sys_path, "*.npz")) if not os.path.basename(f).startswith(("corridor_", "refvs_")))   # corridor fixtures: test_next_rows.py
 
 
 def load_case(path, sc):
@@ -85,4 +85,47 @@ def test_device_reproduces_golden(path, frx, sc):
         # optimised coefficients: device map at the golden minimiser (the 1e-6 contract, lock-step form)
         T, Cf = prob.forward(d["opt_x"])
         assert rel(Cf, d["opt_C"]) < 1e-6 and rel(T, d["opt_T"]) < 1e-12
+    prob.close()
+
+
+# ---- the `Candidate` overload with the REFERENCE's vertices: a problem in the reference's own xi parameterisation ----
+def _refvs_case(sc):
+    d = np.load(os.path.join(sys_path, "refvs_n16_k8_obst.npz"))
+    sid, pid, N, gates, kappa, obst = (int(v) for v in d["case"])
+    cand = sc.make_candidate(sid, N, gates, perturb_id=pid, obstacles=bool(obst))
+    vs = [d["v_rec"][3 * d["v_off"][m]:3 * d["v_off"][m + 1]].reshape(-1, 3).T.copy() for m in range(2 * N - 1)]
+    assert int(d["polytopes_in_another_order_than_the_library"]) > 0             # the fixture is about a DIFFERENT vertex order (geoutils.hpp:43-149 + sdlp.hpp:689-708)
+    return d, sc.Candidate(cand.ini_state, cand.fin_state, cand.h_polys, vs, cand.gates), kappa
+
+
+def test_oracle_and_host_setup_in_the_references_vertex_order(sc, ob, frx):
+    d, cand, kappa = _refvs_case(sc)
+    o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    assert rel(o.initial_guess(), d["ref_x0"]) < 1e-12
+    for s, x in enumerate(d["x"]):
+        f, g = o.objective(x)
+        assert abs(f - d["ref_f"][s]) <= 1e-12 * abs(d["ref_f"][s]) and rel(g, d["ref_g"][s], abs(f)) < 1e-9
+    # the library's own host code (frx_host_setup.hpp, the code behind frx_initial_guess) on the same vertices
+    from test_hostcheck import _host_guess, _load_hostcheck
+    _, x0 = _host_guess(_load_hostcheck(), frx, [cand], sc.ZHANGJIAJIE, kappa, threads=1)
+    assert rel(x0, d["ref_x0"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_plans_in_the_references_vertex_order(frx, sc):
+    """frx_problem_create with the vertices geoutils::enumerateVs produced (fixture): initial guess, objective, gradient and coefficients equal the
+    REFERENCE's own numbers in its parameterisation; a plan from there ends with the oracle's verdict at the oracle's objective level."""
+    d, cand, kappa = _refvs_case(sc)
+    prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x0 = prob.initial_guess()
+    assert rel(x0, d["ref_x0"]) < 1e-12
+    for s, x in enumerate(d["x"]):
+        f, g = prob.objective(x)
+        assert abs(f[0] - d["ref_f"][s]) <= 1e-9 * abs(d["ref_f"][s])
+        assert rel(g, d["ref_g"][s], abs(d["ref_f"][s])) < 1e-9
+        T, Cf = prob.forward(x)
+        assert rel(T, d["ref_T"][s]) < 1e-13 and rel(Cf, d["ref_C"][s]) < 1e-7
+    r = prob.optimize(1e-6, x0=x0)
+    assert (r["status"][0] >= 0) == (int(d["opt_status"]) >= 0)
+    assert abs(r["objective"][0] - float(d["opt_obj"])) <= 2e-2 * float(d["opt_obj"])       # independent runs of the reference's stop rule: DESIGN.md 4
     prob.close()

@@ -11,14 +11,18 @@ import pytest
 from conftest import ROOT
 
 
-@pytest.fixture(scope="module")
-def hc():
+def _load_hostcheck():
     d = os.path.join(ROOT, "tests", "hostcheck")
     subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
     H = C.CDLL(os.path.join(d, "libhostcheck.so"))
     dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"); ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     H.hostcheck_penalty.argtypes = [C.c_int, C.c_int, dp, dp, ip, dp, dp, C.c_int, dp]
     return H
+
+
+@pytest.fixture(scope="module")
+def hc():
+    return _load_hostcheck()
 
 
 @pytest.mark.parametrize("obst,kappa", [(False, 8), (True, 16)])

@@ -20,7 +20,8 @@ def have_ref(ob):
 
 
 CASES = [(0, 16, 4, 8, False, {}), (3, 32, 8, 16, True, {}), (5, 12, 3, 48, False, {}), (7, 10, 2, 8, True, dict(rho=0.0, total_t=7.0, c2_diffeo=0)),
-         (8, 10, 2, 8, False, dict(rho=0.0, total_t=7.0, c2_diffeo=1)), (9, 6, 1, 8, False, dict(c2_diffeo=0))]
+         (8, 10, 2, 8, False, dict(rho=0.0, total_t=7.0, c2_diffeo=1)), (9, 6, 1, 8, False, dict(c2_diffeo=0)),
+         (0, 64, 16, 16, False, {}), (2, 64, 16, 16, True, {})]          # the headline geometry (BASELINE.json configs[2]): K_i = 8, and K_i = 8 ... 14
 
 
 @pytest.mark.parametrize("sid,N,gates,kappa,obst,over", CASES)
