@@ -72,6 +72,8 @@ def test_device_reproduces_golden(path, frx, sc):
             assert rel(g, d["g"][s], abs(d["f"][s])) < 1e-9
             T, Cf = prob.forward(x)
             assert rel(T, d["T"][s]) < 1e-13 and rel(Cf, d["C"][s]) < 1e-7
+            hk = (np.repeat(d["T"][s], 6) ** np.tile(np.arange(6), len(d["T"][s])))[:, None]       # duration-normalised coefficients c_k h^k (what a coefficient
+            assert rel(Cf * hk, d["C"][s] * hk) < 1e-11                                             # does to the trajectory): tests/test_gpu_parity.py, knot form
             cost, gdT, gdC = prob.penalty(d["T"][s], d["C"][s])
             assert abs(cost[0] - d["pen_cost"][s]) <= 1e-9 * max(abs(d["pen_cost"][s]), 1e-300)
             assert rel(gdT, d["pen_gdT"][s]) < 1e-9 and rel(gdC, d["pen_gdC"][s]) < 1e-9
