@@ -111,11 +111,13 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, meet at a barrier, print the job's shape and leave (no GPU work: the CPU test of the self-launch path)")
     args = ap.parse_args()
 
+    import torch                                   # (before libfrx touches the HIP runtime: torch brings its own copy, and the first one loaded wins)
+    n_dev_torch = torch.cuda.device_count() if torch.cuda.is_available() else 0
     from frx_import import frx
     from fast_racing_amd import dist as frxdist
     # --gpus N decides the job, not the environment: without a launcher this process starts the N ranks itself (the reference is pinned to device 0,
     # cuda_computer.cu:414); a launcher that started another number of ranks, or fewer visible devices than ranks, is an error - never a silent 1-rank run
-    n_dev = int(frx.lib().frx_device_count())
+    n_dev = min(int(frx.lib().frx_device_count()), n_dev_torch)
     if args.multi == "lib":
         if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
             raise SystemExit("--multi lib is ONE process for all devices: do not start it under a multi-rank launcher")
@@ -127,7 +129,6 @@ def main():
             sys.exit(frxdist.self_launch(n_launch, os.path.abspath(__file__), sys.argv[1:]))
 
     import numpy as np
-    import torch
 
     lib_mode = args.multi == "lib" and args.gpus > 1
     world = args.gpus if lib_mode else int(os.environ.get("WORLD_SIZE", "1"))
