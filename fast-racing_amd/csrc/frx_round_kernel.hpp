@@ -175,9 +175,14 @@ struct RoundView {                       // per-workgroup constants; c, n, xbase
 // penalty share of workgroup `pw` (0..G-2) in a CT phase
 template <bool PROF>
 __device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const RoundView &v, double *ev, int pw) {
+    // Wave-tasks go to the history workgroups (pw = 1 .. G-2) first and to the leader (pw = 0) last: at the headline geometry 22 tasks meet 24
+    // member waves and the leader takes none - its wave 0 is the one whose thread 0 waits for the PCIe acknowledgements of a deferred result post
+    // (~1.5 us on three rounds out of four) and then had its own three pieces still to do, which made it the last wave of the cluster to finish.
     const int npw = a.G - 1, ntasks = (v.N + a.ppw - 1) / a.ppw, per_pass = npw * 4;
+    const int rank = (pw == 0 ? npw - 1 : pw - 1);                         // order in which the workgroups take tasks
     for (int base = 0; base < ntasks; base += per_pass) {
-        const int task = base + pw * 4 + v.wave;
+        if (base + rank * 4 >= ntasks) break;                               // nothing for this workgroup in this pass (workgroup-uniform: no barrier is skipped by a part of it)
+        const int task = base + rank * 4 + v.wave;
         const int np = task < ntasks ? min(a.ppw, v.N - task * a.ppw) : 0;
         penalty_body<true, true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, v.p0 + task * a.ppw, np, ev + (size_t)v.wave * a.pen_lds, v.lane, v.wt);   // latency form: a wave has its SIMD to itself
         __syncthreads();
@@ -227,6 +232,10 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     // their drain (1.5-2 us) between the end of the adjoint and the phase word of every accepted step.
     unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
     bool trial_done = false, dg_pending = false;
+    // The cluster needs nothing of the leader's own bookkeeping of an accepted step (xp = x, gp = g in its LDS) to start on the new direction -
+    // the point and its gradient are in `pub` already - so the phase word leaves first and the copies run while the members work (round 4:
+    // the copies sat between the prediction and the phase word, ~1 us of every accepted round in front of the whole direction phase).
+    bool accept_pending = false;
     auto accept_step = [&]() {
         double *row = nullptr;                                              // direction log (tests): the pair and the gradient the direction is built from
         if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * (4 * (size_t)a.NXP + 2);
@@ -274,9 +283,8 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 step = 1.0;
                 f_acc = ctlD[0];
                 last_slot = jnew; last_bound = bound;
-                accept_step();                                              // same as the DV_ADVANCE branch below
                 if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
-                kind = PH_ADV;
+                kind = PH_ADV; accept_pending = true;                       // xp = x, gp = g: behind the phase word (same as the DV_ADVANCE branch below)
             } else step = pred_step;                                        // another trial of the running search: straight to x = xp + step d
             lstage = 1;
         } else if (lstage == 0) {
@@ -337,9 +345,8 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 continue;
             } else if (flags & DV_ADVANCE) {                                // lbfgs.hpp:1354-1360: s = x - xp, y = g - gp; the point becomes the base
                 f_acc = ctlD[0]; last_slot = jnew; last_bound = bound;
-                accept_step();
                 if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }   // the step's slot and pair count ride along
-                kind = PH_ADV; lstage = 1;
+                kind = PH_ADV; lstage = 1; accept_pending = true;
             } else {
                 if (flags & DV_INIT) {                                      // d = -g, xp = x, gp = g (lbfgs.hpp:1220, 1262-1263)
                     f_acc = ctlD[0]; gg0 = ctlD[3]; last_slot = -1; last_bound = 0;
@@ -397,6 +404,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             }
             seq_pending = 0;
         }
+        if (accept_pending) { accept_step(); accept_pending = false; }      // (the gather below reads gp behind the arrival barrier)
         RK_PROF(RK_P_PUBLISH);
         if (kind == PH_QUIT) break;
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
