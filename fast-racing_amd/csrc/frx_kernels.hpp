@@ -261,7 +261,7 @@ struct LdsView {
 // The samples of ONE lane (sample jl, jl + lpp, ... of the piece whose coefficients are at cS and corridor block at hS, duration Tp): their 20 partials
 // {cost, d/dT, d/dc[6][3]} accumulated into the lane's LDS slot `mine`.
 template <bool LAT>
-__device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const double *cS, const double *hS, double Tp, int jl, int lpp, double *mine) {
+__device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const double *cS, const double *hS, double Tp, int jl, int lpp, int Kmax, double *mine) {
     LdsView c(cS), hb(hS);
     const int K = (int)hb[3];
     const int kappa = dp.kappa;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const
         const double s1 = step * j;                           // sample abscissa as cc.cu:152
         const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
         double adj[12], Ps, gTa;
-        penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, adj, Ps, gTa);
+        penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, Kmax, adj, Ps, gTa);
         if (!LAT) { c.fence(); FRX_PHASE(); }
         // the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates
         double o[20];
@@ -302,8 +302,20 @@ __device__ __forceinline__ void penalty_reduce(const double *red, int npieces, i
         const int p2 = idx / 20, v = idx - p2 * 20;
         const double *src = red + (p2 * lpp) * 21 + v;
         double s = 0.0;
+        int l = 0;
+        // the additions are one dependent chain in sample order (determinism); the LDS reads are not - sixteen in flight per block
+        // (four at a time cost an LDS latency per four additions: five of them for the 17 samples of kappa = 16)
+        for (; l + 16 <= lpp; l += 16) {
+            double b[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) b[j] = src[(l + j) * 21];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; j++) s += b[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll 4
-        for (int l = 0; l < lpp; l++) s += src[l * 21];
+        for (; l < lpp; l++) s += src[l * 21];
         stg<SH>(out + idx, s, wt);
     }
 }
@@ -360,7 +372,7 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     __syncthreads();
 
     const bool active = pl < npieces && (pfl & DV_EVAL);
-    if (active) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, red + lane * 21);
+    if (active) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, Kmax, red + lane * 21);
     __syncthreads();
     penalty_reduce<SH>(red, npieces, lpp, out20 + (size_t)gp0 * 20, lane, nthr, wt);
 }

@@ -32,8 +32,14 @@
 // being interleaved for ILP, which costs occupancy on a kernel that is FP64-issue bound anyway
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FRX_PHASE() __builtin_amdgcn_sched_barrier(0)
+#define FRX_LDS_READS_STAY_ABOVE() __builtin_amdgcn_sched_barrier(0x1)   // arithmetic may cross, memory operations may not: LDS reads issued above stay in flight together
 #else
 #define FRX_PHASE() ((void)0)
+#define FRX_LDS_READS_STAY_ABOVE() ((void)0)
+#endif
+
+#ifndef FRX_HS_CHUNK
+#define FRX_HS_CHUNK 4         // half-spaces whose sign tests run interleaved (penalty_sample); 8 needs 64 registers for the records alone and spills
 #endif
 
 namespace frx {
@@ -116,13 +122,14 @@ struct PtrView {
 //           and c = n.(p_k - org) - safeMargin, so that  n.(pos - p_k) + safeMargin = n.(pos - org) - c.
 //           The origin (the point of the polytope's first half-space) is subtracted once per sample and keeps the magnitudes at
 //           corridor scale (metres), as pos - p_k does in CPU.hpp:325.
+//   K, Kub = the piece's number of half-spaces and a wave-uniform bound on it (records k < Kub are readable: the block is zero-padded)
 //   adj   = out: a0,a1,a2,a3 (12 doubles), already weighted by ws
 //   Psum  = out: sum of chi*viol^3 (not weighted)
 //   gTalpha = out: a0.v + a1.a + a2.j + a3.s  (to be multiplied by alpha = j/kappa)
 //   LAT   = latency form: no phase boundaries and no forgetting - the scheduler may interleave the corridor loop with the limits (which
 //           do not depend on it) at the price of registers; for launches that cannot fill the chip anyway (one wave's latency IS the launch)
 template <bool LAT, class CV, class HV>
-FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, HV hb, int K, double *adj, double &Psum, double &gTalpha) {
+FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, HV hb, int K, int Kub, double *adj, double &Psum, double &gTalpha) {
     // ---- phase A: position and attitude only (CPU.hpp:260-279); everything else is evaluated after the loop ----
     double pl[3], zB[3], yB[3], xB[3], invF, invM;
     {
@@ -145,36 +152,73 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
     bool needReverse = false;
 
     // ---- corridor half-spaces (CPU.hpp:310-345); the sign test avoids the sqrt unless violated ----
+    // Two passes over chunks of FRX_HS_CHUNK half-spaces (round 4).  Pass 1 runs the sign test of the whole chunk WITHOUT a branch: independent
+    // chains of ~18 FP64 instructions that the scheduler interleaves, their records read from LDS in one go - the one-loop form tested, branched
+    // and read half-space by half-space, so a lone wave paid an LDS latency plus a dependent chain per half-space (ISA: ds_read2 / s_waitcnt /
+    // 18 VALU / s_cbranch, eight times: ~1.8 k of a sample's ~5 k cycles).  Pass 2 revisits, in the same order, only the half-spaces pass 1
+    // flagged (none for a sample inside its corridor) and does what the branch did.  Same expressions, same order of accumulation.
+    // Kub: wave-uniform bound on K (the corridor block is zero-padded to it); lanes with fewer half-spaces mask the surplus.
     {
         const double e0 = pc.ell[0], e1 = pc.ell[1], e2 = pc.ell[2];
         double Pcorr = 0.0;
-#if defined(FRX_COUNT_BUILD)                                     // scripts/count_fp64.py: one copy of the loop body, so that static counts are per iteration
+        constexpr int CH = FRX_HS_CHUNK;
+        for (int k0 = 0; k0 < Kub; k0 += CH) {
+            unsigned need = 0u;
+            double rec[CH][4];
+            FRX_PHASE();                                                   // between this fence and the next: the chunk's LDS reads and nothing else
+#if defined(FRX_COUNT_BUILD)                                     // scripts/count_fp64.py: one copy of the test, so that static counts are per half-space
 #pragma unroll 1
-#endif
-        for (int k = 0; k < K; k++) {
-            const int r = 4 + 4 * k;
-            const double n[3] = {hb[r], hb[r + 1], hb[r + 2]};
-            // (R^T n) .* ellipsoid
-            const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
-            const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
-            const double d0 = dot3(n, pl) - hb[r + 3];                 // n.(pos - p_k) + safeMargin
-            if (d0 >= 0.0 || eN2 > d0 * d0) {
-                const double ir = rsqrt_fast(eN2), eNorm = eN2 * ir;
-                const double sd = d0 + eNorm;                          // CPU.hpp:325,328
-                if (sd > 0.0) {
-                    const double sd2 = sd * sd;
-                    const double cw = ws * pc.chi[0] * 3.0 * sd2;
-                    const double ie = cw * ir;
-                    const double cg0 = w0 * ie * e0, cg1 = w1 * ie * e1, cg2 = w2 * ie * e2;   // cw * eNormGd, CPU.hpp:324,326
+#else
 #pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        a0[d] += cw * n[d];
-                        U0[d] += cg0 * n[d];
-                        U1[d] += cg1 * n[d];
-                        U2[d] += cg2 * n[d];
+#endif
+            for (int j = 0; j < CH; j++) {                                 // the chunk's records first, all reads in flight together ...
+#if defined(__HIP_DEVICE_COMPILE__)
+                const int r = 4 + 4 * (k0 + j);                            // device: up to CH - 1 records past the piece's block are still the wave's own LDS (the next
+#else                                                                      // block or the reduction slots behind them); what is read there is masked by k < K below
+                const int k = k0 + j, r = 4 + 4 * (k < Kub ? k : Kub - 1);
+#endif
+                rec[j][0] = hb[r]; rec[j][1] = hb[r + 1]; rec[j][2] = hb[r + 2]; rec[j][3] = hb[r + 3];
+            }
+            FRX_PHASE();                                                   // (... not re-sunk next to their uses: the scheduler minimises registers, not latency)
+#if defined(FRX_COUNT_BUILD)
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+            for (int j = 0; j < CH; j++) {
+                const double *n = rec[j];
+                // (R^T n) .* ellipsoid
+                const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
+                const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
+                const double d0 = dot3(n, pl) - n[3];                      // n.(pos - p_k) + safeMargin
+                need |= (k0 + j < K && (d0 >= 0.0 || eN2 > d0 * d0)) ? (1u << j) : 0u;
+            }
+            if (need != 0u) {
+#pragma unroll 1
+                for (int j = 0; j < CH; j++) {
+                    if (!(need & (1u << j))) continue;
+                    const int r = 4 + 4 * (k0 + j);
+                    const double n[3] = {hb[r], hb[r + 1], hb[r + 2]};
+                    const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
+                    const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
+                    const double d0 = dot3(n, pl) - hb[r + 3];
+                    const double ir = rsqrt_fast(eN2), eNorm = eN2 * ir;
+                    const double sd = d0 + eNorm;                          // CPU.hpp:325,328
+                    if (sd > 0.0) {
+                        const double sd2 = sd * sd;
+                        const double cw = ws * pc.chi[0] * 3.0 * sd2;
+                        const double ie = cw * ir;
+                        const double cg0 = w0 * ie * e0, cg1 = w1 * ie * e1, cg2 = w2 * ie * e2;   // cw * eNormGd, CPU.hpp:324,326
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            a0[d] += cw * n[d];
+                            U0[d] += cg0 * n[d];
+                            U1[d] += cg1 * n[d];
+                            U2[d] += cg2 * n[d];
+                        }
+                        Pcorr += sd * sd2;
+                        needReverse = true;
                     }
-                    Pcorr += sd * sd2;
-                    needReverse = true;
                 }
             }
         }
@@ -271,7 +315,7 @@ FRX_HD void penalty_sample(const double *c, const double *, double s1, double ws
         const double *org, *hs;
         FRX_HD double operator[](int i) const { return i < 4 ? org[i < 3 ? i : 0] : hs[i - 4]; }
     };
-    penalty_sample<false>(PtrView{c}, s1, ws, pc, Blk{org, hs}, K, adj, Psum, gTalpha);
+    penalty_sample<false>(PtrView{c}, s1, ws, pc, Blk{org, hs}, K, K, adj, Psum, gTalpha);
 }
 
 // C2 / exponential time diffeomorphism, forward and derivative (CPU.hpp:639-641, 826-839)
