@@ -941,6 +941,21 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.S = S; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;
+    // FRX_RESIDENT_TRACE="lo,hi[,file]" (with FRX_RESIDENT_PROF): timeline of cluster 0 for the phases lo <= n < hi - every workgroup's thread 0 logs
+    // (segment id, phase, 100 MHz wall clock) - written as text to `file` (default frx_round_trace.txt) after the plan (scripts/r04/round_timeline.py)
+    DevBuf<unsigned long long> d_trace;
+    const int trace_cap = 2048;
+    const char *tr_env = want_prof ? std::getenv("FRX_RESIDENT_TRACE") : nullptr;
+    std::string trace_file = "frx_round_trace.txt";
+    if (tr_env) {
+        unsigned lo = 0, hi = 0; char fbuf[512] = {0};
+        const int nf = std::sscanf(tr_env, "%u,%u,%511s", &lo, &hi, fbuf);
+        if (nf >= 2 && hi > lo && d_trace.alloc((size_t)G * trace_cap) == hipSuccess) {
+            HIP_TRY(hipMemsetAsync(d_trace.p, 0, sizeof(unsigned long long) * (size_t)G * trace_cap, p->stream));
+            rl.trace = d_trace.p; rl.trace_cap = trace_cap; rl.trace_lo = lo; rl.trace_hi = hi;
+            if (nf == 3) trace_file = fbuf;
+        }
+    }
     { const char *fc = std::getenv("FRX_RESIDENT_FAST_CONTROL"); rl.fast_control = fc && fc[0] == '0' ? 0 : 1; }
     { const char *tr = std::getenv("FRX_RESIDENT_TIMED_READ"); if (tr && tr[0] == '1') rl.fast_control |= 2; }
     { const char *sr = std::getenv("FRX_RESIDENT_STAMP_ROUND"); rl.stamp_round = want_prof && sr ? std::max(0, std::atoi(sr)) : 0; }
@@ -1111,10 +1126,13 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         std::string line;
         for (int k = 0; k < S; k++) {
             bool same = true;
-            for (int w = 1; w < G; w++) same = same && xc[(size_t)k * G + w] == xc[(size_t)k * G];
+            for (int w = 1; w < G; w++) same = same && (xc[(size_t)k * G + w] & 0xFFu) == (xc[(size_t)k * G] & 0xFFu);
             one_xcd += same ? 1 : 0;
             line += " [";
-            for (int w = 0; w < G; w++) line += std::to_string((int)xc[(size_t)k * G + w] - 1);
+            for (int w = 0; w < G; w++) {                                // XCD : shader engine . shader array . CU of every workgroup (leader first, dense last)
+                const unsigned e = xc[(size_t)k * G + w];
+                line += std::to_string((int)(e & 0xFFu) - 1) + ":" + std::to_string((e >> 13) & 7u) + "." + std::to_string((e >> 12) & 1u) + "." + std::to_string((e >> 8) & 15u) + (w + 1 < G ? " " : "");
+            }
             line += "]";
         }
         std::fprintf(stderr, "[frx] clusters on one XCD: %d of %d;%s\n", one_xcd, S, line.c_str());
@@ -1129,6 +1147,20 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     for (int k = 0; k < S; k++) rounds = std::max(rounds, slot_[k].ncmd);                 // commands of the busiest cluster (S < B: over all the candidates it took)
     p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
+    if (rl.trace) {
+        std::vector<unsigned long long> tr((size_t)G * trace_cap);
+        HIP_TRY(hipMemcpy(tr.data(), d_trace.p, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(trace_file.c_str(), "w")) {
+            std::fprintf(f, "# workgroup segment phase ticks(100MHz, 40 bits)   G=%d\n", G);
+            for (int w = 0; w < G; w++)
+                for (int i = 0; i < trace_cap; i++) {
+                    const unsigned long long e = tr[(size_t)w * trace_cap + i];
+                    if (!e) break;
+                    std::fprintf(f, "%d %llu %llu %llu\n", w, e >> 56, (e >> 40) & 0xFFFFull, e & 0xFFFFFFFFFFull);
+                }
+            std::fclose(f);
+        }
+    }
     if (want_prof) {
         p->rprof.resize((size_t)S * (G + 1) * 16 + 32);                                // [S][G][16] segment sums, [S][16] host-wait histogram; the last 32 words: the bodies' cycle stamps
         HIP_TRY(hipMemcpy(p->rprof.data(), p->d_rprof.p, sizeof(unsigned long long) * (size_t)S * (G + 1) * 16, hipMemcpyDeviceToHost));

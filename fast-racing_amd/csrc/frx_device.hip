@@ -117,11 +117,16 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.B = r.B; a.S = r.S; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g); a.maxN19 = g.maxN * 19;
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;
-    const void *fn = r.prof ? (const void *)k_round<ROUND_E, true> : (const void *)k_round<ROUND_E, false>;
+    a.trace = r.prof ? (rk_u64 *)r.trace : nullptr; a.trace_cap = r.trace_cap; a.trace_lo = r.trace_lo; a.trace_hi = r.trace_hi;
+    // four instantiations: with / without the profile, and for <= 64 pieces per candidate (the class-specific bodies only) or any geometry
+    const bool n64 = g.knot_threads == 64 && !([] { const char *e = std::getenv("FRX_RESIDENT_NR"); return e && e[0] == '0'; }());   // FRX_RESIDENT_NR=0: the generic instantiation (A/B)
+    const void *fn = r.prof ? (n64 ? (const void *)k_round<ROUND_E, true, 64> : (const void *)k_round<ROUND_E, true, 0>)
+                            : (n64 ? (const void *)k_round<ROUND_E, false, 64> : (const void *)k_round<ROUND_E, false, 0>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    if (r.prof) hipLaunchKernelGGL((k_round<ROUND_E, true>), dim3(8 * r.G * ((r.S + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_round<ROUND_E, false>), dim3(8 * r.G * ((r.S + 7) / 8)), dim3(256), lds, (hipStream_t)stream, a);
+    const dim3 grid(8 * r.G * ((r.S + 7) / 8)), block(256);
+    if (r.prof) { if (n64) hipLaunchKernelGGL((k_round<ROUND_E, true, 64>), grid, block, lds, (hipStream_t)stream, a); else hipLaunchKernelGGL((k_round<ROUND_E, true, 0>), grid, block, lds, (hipStream_t)stream, a); }
+    else { if (n64) hipLaunchKernelGGL((k_round<ROUND_E, false, 64>), grid, block, lds, (hipStream_t)stream, a); else hipLaunchKernelGGL((k_round<ROUND_E, false, 0>), grid, block, lds, (hipStream_t)stream, a); }
     return (int)hipGetLastError();
 }
 

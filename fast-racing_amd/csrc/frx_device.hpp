@@ -89,6 +89,7 @@ struct RoundLaunch {
     void *h_cmd, *h_res;                                           // mapped host mailboxes, [S] x 16 B (x cmd_stride) and [S] x 64 B
     unsigned long long timeout_ticks;
     unsigned long long *prof = nullptr;                            // optional [B][G][16]: per-segment ticks (profiling instantiation)
+    unsigned long long *trace = nullptr; int trace_cap = 0; unsigned trace_lo = 0, trace_hi = 0;   // optional timeline of cluster 0 (profiling instantiation): [G][trace_cap] events of the phases [trace_lo, trace_hi)
     int B, S, G, m, E, NXP;                                         // B candidates on S <= B clusters of G workgroups (S < B: the host hands candidates S .. B-1 to clusters that finish, DV_NEXT)
     int dbg_cap = 0, dbg_cands = 0;                                 // direction log (dbg): [B] counts + dbg_cands x dbg_cap records of 4 NXP + 2 doubles
     double ls_ftol = 1e-4, ls_gtol = 0.9, ls_min_step = 1e-20, ls_max_step = 1e20, ls_xtol = 1e-16;   // frx_lbfgs_params of the plan (leader's prediction of the host's verdict)

@@ -951,11 +951,15 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
 #undef RS
 
 // SH: T and C are consumed by OTHER workgroups of the same launch (see ldg / stg above).
-template <bool SH>
+// NR > 0: the caller KNOWS the geometry class at compile time (nrow = NR rows, 256 threads: the resident round kernel's instantiation for <= 64 pieces):
+// the forms for the other classes are not compiled into it - k_round carried all three (146 KB of code against a 64 KB instruction cache that two
+// CUs share; the leader walks through forward map, adjoint and control code once per round, each time from L2).
+template <bool SH, int NR = 0>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr) {
+                               int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr) {
     // ct_lds (optional, LDS, 19 doubles per piece: 18 coefficients + duration): a copy for the backward pass of the same workgroup
-    const int k = threadIdx.x, nthr = blockDim.x;
+    const int nrow = NR > 0 ? NR : nrow_rt;
+    const int k = threadIdx.x, nthr = NR > 0 ? 256 : (int)blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
@@ -1584,16 +1588,18 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
 }
 
 // SH: out20 (and T, C) were written by workgroups of the same launch.
-template <bool SH>
+template <bool SH, int NR = 0>
 __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
-                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow_rt, const double *__restrict__ pcrw, int nsteps,
                                 const LineSearchTap &tap, int b, double *sm, const double *ct_lds = nullptr, const ResidentOps *ro = nullptr) {
-    if (nrow == 64 && blockDim.x == 256) {              // <= 64 pieces: one wave per axis
+    const int nrow = NR > 0 ? NR : nrow_rt;
+    if (NR == 64 || (NR == 0 && nrow == 64 && blockDim.x == 256)) {              // <= 64 pieces: one wave per axis
         backward_knot_wsp64<SH>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);
         return;
     }
-    const int k = threadIdx.x, nthr = blockDim.x;
+    if (NR == 64) return;
+    const int k = threadIdx.x, nthr = NR > 0 ? 256 : (int)blockDim.x;
     const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];

@@ -111,12 +111,17 @@ struct RoundArgs {
     int B, S, G, m, NXP, eval_doubles, ct_doubles;                    // B candidates, S <= B clusters (S < B: work queue, DV_NEXT);                       // NXP = (G - 2) 2 E: padded vector length (history workgroups x chunk);                       // ct_doubles: leader's LDS copies ((C, T), then x, polytopes, direction, multipliers) at the head of its role region, before the eval scratch
     double *dbg;                             // optional direction log (frx_debug.h, frx_debug_direction_log): [B] record counts, then per candidate c < dbg_cands
     int dbg_cap, dbg_cands;                  // dbg_cap records of 4 NXP + 2 doubles: s, y, g (the pair and the gradient the direction was built from), d, slot, pair count
+    rk_u64 *trace; int trace_cap; unsigned trace_lo, trace_hi;      // PROF instantiation only: timeline of cluster 0 - every workgroup's thread 0 appends (segment id << 56 | wall clock) for the
+                                                                    // phases trace_lo <= phase number < trace_hi, trace_cap events per workgroup ([G][trace_cap]; FRX_RESIDENT_TRACE)
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*; then [B][16]: histogram of the leaders' waits for a host command
 };
 // profile segments (thread 0 of every workgroup accumulates the time since its previous checkpoint into one of these)
 enum { RK_P_WAIT_HOST = 0, RK_P_VECTORS = 1, RK_P_FORWARD = 2, RK_P_WAIT_PHASE = 3, RK_P_PASS_A = 4, RK_P_WAIT_PART = 5, RK_P_DENSE_IN = 6, RK_P_SOLVE = 7,
        RK_P_WAIT_U = 8, RK_P_PASS_B = 9, RK_P_PENALTY = 10, RK_P_WAIT_ARRIVE = 11, RK_P_GATHER = 12, RK_P_BACKWARD = 13, RK_P_POST = 14, RK_P_PUBLISH = 15 };
 
+// extra timeline events (no segment sum): ids >= 32
+#define RK_TR(id) do { if (PROF && threadIdx.x == 0 && a.trace && v.k == 0 && pseq >= a.trace_lo && pseq < a.trace_hi && tr_n < (unsigned)a.trace_cap) \
+                         a.trace[(size_t)v.wg * a.trace_cap + tr_n++] = ((rk_u64)(id) << 56) | ((rk_u64)pseq << 40) | ((rk_u64)wall_clock64() & 0xFFFFFFFFFFull); } while (0)
 // value of lane `l` (wave-uniform index) of a double, as a wave-uniform scalar: the broadcast of a vector element to all lanes without an
 // LDS access - the dense workgroup's mat-vecs are bound by LDS bandwidth, and two of the three LDS reads per row element were broadcasts
 __device__ __forceinline__ double rk_bcast(double v, int l) {
@@ -170,7 +175,8 @@ struct RoundView {                       // per-workgroup constants; c, n, xbase
     bool wt;
     double *pub, *part, *upub, *dpub;
 };
-#define RK_PROF(seg) do { if (PROF && threadIdx.x == 0) { const rk_u64 now_ = wall_clock64(); ((rk_u64 *)(sm + L.ctl + 16))[seg] += now_ - prof_last; prof_last = now_; } } while (0)
+#define RK_PROF(seg) do { if (PROF && threadIdx.x == 0) { const rk_u64 now_ = wall_clock64(); ((rk_u64 *)(sm + L.ctl + 16))[seg] += now_ - prof_last; prof_last = now_; \
+                            if (a.trace && v.k == 0 && pseq >= a.trace_lo && pseq < a.trace_hi && tr_n < (unsigned)a.trace_cap) a.trace[(size_t)v.wg * a.trace_cap + tr_n++] = ((rk_u64)(seg) << 56) | ((rk_u64)pseq << 40) | (now_ & 0xFFFFFFFFFFull); } } while (0)
 
 // penalty share of workgroup `pw` (0..G-2) in a CT phase
 template <bool PROF>
@@ -192,7 +198,7 @@ __device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const Round
 // ============================================================================================================================
 // LEADER (workgroup 0 of a cluster)
 // ============================================================================================================================
-template <bool PROF>
+template <bool PROF, int NR>
 __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, const RoundLds &L, double *sm) {
     const int k = v.k, t = v.t, lane = v.lane, wave = v.wave;
     int c = v.c, n = v.n;                                                   // the candidate this cluster works on (changes with DV_NEXT)
@@ -250,6 +256,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         for (int i = t; i < n; i += 256) { xglob[i] = xsrc[i]; gglob[i] = gsrc[i]; }
     };
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
+    unsigned tr_n = 0; (void)tr_n;
     unsigned pseq = 0, nphase = 0;
     rk_u64 hseq = 0;
     int lstage = 0, flags = 0, jnew = 0, bound = 0;
@@ -273,6 +280,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     int last_slot = -1, last_bound = 0;
     for (;;) {
         int kind = 0;
+        RK_TR(40);                                                          // loop top
         if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
             spec_ready = false; unconfirmed = true; run_kind = pred_kind;
             hseq++;
@@ -365,9 +373,10 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             }
             trial_done = false;
             if (flags & DV_EVAL) {
+                RK_TR(41);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // x is complete in LDS (no vmcnt: the trial point's stores to `pub` drain behind the forward map)
                 RK_PROF(RK_P_VECTORS);
-                forward_knot_body<true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt, &ro);
+                forward_knot_body<true, NR>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt, &ro);
                 kind = PH_CT; lstage = 2;
                 RK_PROF(RK_P_FORWARD);
             } else {
@@ -411,6 +420,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         // ---- the phase is complete when every workgroup of the cluster has reported ----
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+        RK_TR(37);
         nphase++;
         if (t == 0) { const bool ok = rk_wait_eq(a.cntL + k * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
         __syncthreads();
@@ -433,10 +443,19 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             // carries TRIAL): the element a thread gathers is the element it moves, so no barrier lies between the two
             double acc = 0.0;
             const bool with_trial = (flags & DV_TRIAL) != 0;
-            for (int i = t; i < n; i += 256) {
-                const double di = ldg<true>(dpub + i);
-                dv[i] = di; acc += gp[i] * di;
-                if (with_trial) { const double xv = xp[i] + step * di; x[i] = xv; stg<true>(pub + i, xv, wt); }
+            for (int i0 = t; i0 < n; i0 += 3 * 256) {                       // three elements per thread and trip, their loads in flight together (the plain loop
+                double dl[3];                                               // compiled to load / s_waitcnt vmcnt(0) / use per element: three L2 round trips in a row)
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int i = i0 + 256 * u; dl[u] = ldg<true>(dpub + (i < n ? i : n - 1)); }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int i = i0 + 256 * u;
+                    if (i < n) {
+                        const double di = dl[u];
+                        dv[i] = di; acc += gp[i] * di;
+                        if (with_trial) { const double xv = xp[i] + step * di; x[i] = xv; stg<true>(pub + i, xv, wt); }
+                    }
+                }
             }
             trial_done = with_trial;
             if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what came back for the pair logged by accept_step
@@ -455,7 +474,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             if (dg_pending) { if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]); dg_pending = false; }   // gp . d of this round's ADVANCE (read behind the adjoint's barrier)
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
             if (unconfirmed) tap.early_cmd = &a.h_cmd[k * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
-            backward_knot_body<true>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
+            backward_knot_body<true, NR>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
             if (PROF && a.dp.stamps && k == 0 && t == 0) a.dp.stamps[18] = (long long)__builtin_readcyclecounter();   // (18 .. 21: the leader's work behind the adjoint)
@@ -606,6 +625,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
     double *pub = v.pub, *part = v.part, *upub = v.upub, *dpub = v.dpub;
     const int slot = t & 127, half = t >> 7;
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
+    unsigned tr_n = 0; (void)tr_n;
     double Sreg[E], Yreg[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
@@ -649,12 +669,17 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             nadv++;
             // -- 1. this workgroup's chunk of the accepted point and its gradient; s = x - xp, y = g - gp against the chunk kept from the previous step --
             const int e0 = hg * CHT;
-            for (int i = t; i < CHT; i += 256) {
-                const double xv = ldg<true>(pub + e0 + i), gv = ldg<true>(pub + a.NXP + e0 + i);
-                sC[i] = xv - xpC[i]; yC[i] = gv - gpC[i]; gC[i] = gv; xpC[i] = xv; gpC[i] = gv;
+            {   // (thread 0's two control loads used to follow its chunk loads one by one, each behind a wait: three L2 round trips in front of the barrier)
+                static_assert(CHT <= 256, "one chunk element per thread");
+                const int ic = t < CHT ? t : CHT - 1;
+                const double xv = ldg<true>(pub + e0 + ic), gv = ldg<true>(pub + a.NXP + e0 + ic);
+                double c1 = 0.0, c2 = 0.0;
+                if (t == 0) { c1 = ldg<true>(pub + 2 * a.NXP); c2 = ldg<true>(pub + 2 * a.NXP + 1); }
+                if (t < CHT) { sC[t] = xv - xpC[t]; yC[t] = gv - gpC[t]; gC[t] = gv; xpC[t] = xv; gpC[t] = gv; }
+                if (t == 0) { ctlU[1] = (unsigned)c1; ctlU[2] = (unsigned)c2; }
             }
-            if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); ctlU[2] = (unsigned)ldg<true>(pub + 2 * a.NXP + 1); }
             __syncthreads();
+            RK_TR(32);                                                          // chunk and control words arrived
             jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]); bound = __builtin_amdgcn_readfirstlane((int)ctlU[2]);   // wave-uniform by construction
             // -- 2. the new pair replaces slot jnew --
             if (slot == jnew) {
@@ -695,6 +720,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
                 for (int q = 0; q < 4; q++) pair[(half * 4 + q) * 128 + slot] = acc[q];
             }
             __syncthreads();
+            RK_TR(33);                                                          // dot products done
             for (int o = t; o < 512; o += 256) stg<true>(part + (size_t)hg * 512 + o, pair[o] + pair[512 + o], wt);
             rk_drain_and_meet();
             if (t == 0) __hip_atomic_fetch_add(a.cntA + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
@@ -704,8 +730,9 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             __syncthreads();
             RK_PROF(RK_P_WAIT_U);
             {
-                const double coefS = ldg<true>(upub + slot), coefY = ldg<true>(upub + 128 + slot);
+                double coefS = ldg<true>(upub + slot), coefY = ldg<true>(upub + 128 + slot);
                 if (t == 0) ctlD[6] = ldg<true>(upub + 256);
+                if (!valid) { coefS = 0.0; coefY = 0.0; }                   // a slot without a pair holds zeros or a finished plan's (finite) pair: 0 s + 0 y = 0, no select per element
                 // Element i of the chunk is a sum over the 128 SLOTS of this thread's products - a reduction ACROSS threads for each of the
                 // 2 E elements.  Round 2 did it with 14 packed four-value wave reductions per wave (~460 dependent DPP / crossbar
                 // instructions, ~1.6 us on a lone wave); now every thread drops its E products into an LDS square [256][E + 1] (the penalty
@@ -716,9 +743,10 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
                 {
                     double *mine = xt + t * XS;
 #pragma unroll
-                    for (int e = 0; e < E; e++) mine[e] = valid ? (coefS * Sreg[e] + coefY * Yreg[e]) : 0.0;
+                    for (int e = 0; e < E; e++) mine[e] = coefS * Sreg[e] + coefY * Yreg[e];
                 }
                 __syncthreads();
+                RK_TR(34);                                                      // products in the LDS square
                 double *wsum = pair;                                       // [2 halves][2 parts][E]
                 if (t < 4 * E) {
                     const int grp = t / E, e = t - grp * E;                // grp = half * 2 + part: slots [64 part, 64 part + 64) of that half
@@ -737,6 +765,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
                     wsum[grp * E + e] = (s0 + s1) + (s2 + s3);
                 }
                 __syncthreads();
+                RK_TR(35);                                                      // column sums done
                 const double gamma = ctlD[6];
                 for (int i = t; i < CHT; i += 256) {
                     const int hh = i / E, e = i - hh * E;
@@ -750,6 +779,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
         // ---- report the end of this workgroup's part of the phase to the leader ----
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+        RK_TR(36);
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)k * a.G + wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }
@@ -776,6 +806,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
     double *ctlD = sm + L.ctl + 8;
     const int pp = t & 127, hq = t >> 7, q0 = 64 * hq;
     rk_u64 prof_last = PROF ? wall_clock64() : 0;
+    unsigned tr_n = 0; (void)tr_n;
     double Ya[32], Yb[32];                                                  // (Y^T Y)[pp][q0 .. q0 + 31], [q0 + 32 .. q0 + 63]: two arrays the compiler keeps in registers
 #pragma unroll
     for (int u = 0; u < 32; u++) { Ya[u] = 0.0; Yb[u] = 0.0; }
@@ -931,7 +962,8 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
     if (PROF && a.prof && t < 16) a.prof[((size_t)k * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
 }
 
-template <int E, bool PROF>
+// NR: 64 = every candidate has <= 64 pieces (the wave-specialised bodies, nothing else compiled in), 0 = the geometry class is a run-time value
+template <int E, bool PROF, int NR>
 __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int CHT = 2 * E;
@@ -956,7 +988,9 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
         unsigned my_xcc = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
         my_xcc = (my_xcc & 15u) + 1u;
-        __hip_atomic_store(a.xcc + v.k * a.G + v.wg, my_xcc, FRX_RLX_AGENT);
+        unsigned hw_id = 0;                                                 // where this workgroup runs (diagnostic: bits 8.. of the word; CU_ID 11:8, SH_ID 12, SE_ID 15:13 of HW_ID)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        __hip_atomic_store(a.xcc + v.k * a.G + v.wg, my_xcc | ((hw_id & 0xFF00u) << 0), FRX_RLX_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(a.census, 1u, FRX_RLX_AGENT);
         bool ok;
@@ -975,7 +1009,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             if (v.wg == 0) __hip_atomic_store(&a.h_res[v.k].seq, ~(rk_u64)0, FRX_RLX_SYS);
         }
         bool same = ok;
-        for (int k = 0; k < a.G; k++) same = same && __hip_atomic_load(a.xcc + v.k * a.G + k, FRX_RLX_AGENT) == my_xcc;
+        for (int k = 0; k < a.G; k++) same = same && (__hip_atomic_load(a.xcc + v.k * a.G + k, FRX_RLX_AGENT) & 0xFFu) == my_xcc;
         ctlU[0] = ok ? 1u : 0u;
         ctlU[3] = same ? 1u : 0u;
     }
@@ -984,10 +1018,11 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     v.wt = ctlU[3] == 0u;                                                 // write-through payload stores unless the cluster shares an XCD
     if (PROF && v.t < 16) ((rk_u64 *)(sm + L.ctl + 16))[v.t] = 0;
     __syncthreads();
-    if (v.wg == 0) rk_leader_loop<PROF>(a, v, L, sm);
+    if (v.wg == 0) rk_leader_loop<PROF, NR>(a, v, L, sm);
     else if (v.wg == a.G - 1) rk_dense_loop<PROF>(a, v, L, sm);
     else rk_member_loop<E, PROF>(a, v, L, sm);
 }
 #undef RK_PROF
+#undef RK_TR
 
 } // namespace frx
