@@ -242,6 +242,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     // the point and its gradient are in `pub` already - so the phase word leaves first and the copies run while the members work (round 4:
     // the copies sat between the prediction and the phase word, ~1 us of every accepted round in front of the whole direction phase).
     bool accept_pending = false;
+    bool adv_published = false;                                             // the ADVANCE phase word of the predicted command went out right behind the prediction (below)
     auto accept_step = [&]() {
         double *row = nullptr;                                              // direction log (tests): the pair and the gradient the direction is built from
         if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * (4 * (size_t)a.NXP + 2);
@@ -291,7 +292,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 step = 1.0;
                 f_acc = ctlD[0];
                 last_slot = jnew; last_bound = bound;
-                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
+                if (!adv_published && t == 0) { stg<true>(pub + 2 * a.NXP, (double)jnew, wt); stg<true>(pub + 2 * a.NXP + 1, (double)bound, wt); }
                 kind = PH_ADV; accept_pending = true;                       // xp = x, gp = g: behind the phase word (same as the DV_ADVANCE branch below)
             } else step = pred_step;                                        // another trial of the running search: straight to x = xp + step d
             lstage = 1;
@@ -366,6 +367,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 lstage = 1;
             }
         }
+        // One iteration = one COMMAND: its own phase (ADVANCE / INIT / NEXT / QUIT), then - pass 1 - its evaluation, as straight-line code (the two
+        // passes are unrolled).  Until round 4 every PHASE was a trip of the outer loop: measured with the timeline (scripts/r04/round_timeline.py),
+        // the trip back to the loop top cost 0.6-0.9 us each time - register shuffles and reloads of spilled scalars at the latch - twice per round on the critical path.
+        bool leave = false;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
         if (lstage == 1 && kind == 0) {
             if ((flags & DV_TRIAL) && !trial_done) {                        // x = xp + step * d (lbfgs.hpp:825-826); after an ADVANCE the gather above has done it
                 __syncthreads();
@@ -383,11 +390,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 rk_drain_and_meet();
                 if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[k].seq, hseq, FRX_RLX_SYS); }
                 lstage = 0;
-                continue;
+                break;
             }
         }
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[13] = (long long)__builtin_readcyclecounter();
         RK_PROF(RK_P_DENSE_IN);                                             // (leader: command decoded / accepted step taken over)
+        if (adv_published && kind == PH_ADV) adv_published = false;         // this phase word is out already (behind the prediction, below)
+        else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[14] = (long long)__builtin_readcyclecounter();
         rk_drain_and_meet();                                                // everything published so far has left this CU
@@ -395,6 +404,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         pseq++;
         if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)kind, FRX_RLX_AGENT);
         if (PROF && a.dp.stamps && k == 0 && t == 0 && kind == PH_CT) a.dp.stamps[15] = (long long)__builtin_readcyclecounter();
+        }
         if (seq_pending != 0) {
             // The result of the round whose acceptance the leader predicted goes to the host only NOW, behind the phase word of the step it
             // started: posted right after the adjoint (round 2), its five stores to host memory sat in front of this publication's drain -
@@ -415,7 +425,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         }
         if (accept_pending) { accept_step(); accept_pending = false; }      // (the gather below reads gp behind the arrival barrier)
         RK_PROF(RK_P_PUBLISH);
-        if (kind == PH_QUIT) break;
+        if (kind == PH_QUIT) { leave = true; break; }
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
         // ---- the phase is complete when every workgroup of the cluster has reported ----
         rk_drain_and_meet();
@@ -431,12 +441,12 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             flush(x, g);
             pseq++;
             if (t == 0) { __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
-            break;
+            leave = true; break;
         }
         if (kind == PH_NEXT) {                                              // every workgroup of the cluster is on the new candidate: tell the host, whose next command starts its plan
             if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[k].seq, hseq, FRX_RLX_SYS); }
             lstage = 0;
-            continue;
+            break;
         }
         if (kind == PH_ADV) {                                               // gather the direction; dginit = gp . d (lbfgs.hpp:756)
             // ... and, in the same sweep, the first trial point of the new search x = xp + step d (lbfgs.hpp:825-826; every ADVANCE command
@@ -525,21 +535,21 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     if (t == 0) ctlU[1] = ctlU[2];                          // where the command decoder looks
                     have_cmd = true; ls_ok = false; lstage = 0;             // no more predictions in this search: the device's copy of the line search has left the host's
                     __syncthreads();
-                    continue;
+                    break;
                 }
                 if (verdict == 1u && (ctlU[2] & (unsigned)DV_NEXT)) {           // the host stopped this plan and hands over the next candidate: the accepted
                     for (int i = t; i < n; i += 256) { x[i] = xp[i]; g[i] = gp[i]; }   // point is the result (the command decoder flushes x, g)
                     if (t == 0) ctlU[1] = ctlU[2];
                     have_cmd = true; ls_ok = false; lstage = 0;
                     __syncthreads();
-                    continue;
+                    break;
                 }
                 if (verdict != 0u) {
                     if (verdict == 1u) flush(xp, gp); else flush(x, g);                     // host stopped: the accepted point is the result
                     rk_drain_and_meet();
                     pseq++;
                     if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT);
-                    break;
+                    leave = true; break;
                 }
             }
             RK_PROF(RK_P_PASS_A);                                           // (leader: confirmation of the command this round ran on)
@@ -598,14 +608,28 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
             }
             lstage = 0;
-            __syncthreads();
+            if (spec_ready && pred_kind == 1) {
+                // The predicted ADVANCE goes to the cluster HERE, straight behind the prediction: slot and pair count, the drain of the gradient's copy,
+                // the phase word.  The members start on the direction while the leader closes the round, walks back to the top of its loop and takes
+                // the step over in its own vectors (timeline, round 4: 1.5 us lay between the prediction and the phase word).
+                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)((pred_word >> 8) & 0xFFFu), wt); stg<true>(pub + 2 * a.NXP + 1, (double)((pred_word >> 20) & 0xFFFu), wt); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                rk_drain_and_meet();
+                pseq++;
+                if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_ADV, FRX_RLX_AGENT);
+                adv_published = true;
+            } else __syncthreads();
             if (PROF && a.dp.stamps && k == 0 && a.stamp_round > 0 && hseq == (rk_u64)a.stamp_round) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (t < 32) a.dp.stamps[32 + t] = (long long)__hip_atomic_load((unsigned long long *)a.dp.stamps + t, FRX_RLX_AGENT);
             }
             RK_PROF(RK_P_POST);
+            break;                                                          // the command is done
         }
+        kind = 0;                                                           // the command's own phase is over: pass 1 is its evaluation
+        }
+        if (leave) break;
     }
     if (PROF && a.prof && t < 16) a.prof[((size_t)k * a.G + v.wg) * 16 + t] = ((rk_u64 *)(sm + L.ctl + 16))[t];
     if (t == 0 && a.spec) { a.spec[c * 4] = n_pred_adv; a.spec[c * 4 + 1] = n_pred_trial; a.spec[c * 4 + 2] = n_redone; }
