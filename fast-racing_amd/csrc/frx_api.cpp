@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -847,6 +848,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
 // device - two shards of frx_multi on one GPU, two user threads - could each get a partially resident grid, and neither census would
 // ever complete.  Launches of this process are therefore serialised per device: the second plan waits for the first one's kernel to
 // leave (another PROCESS on the same device is caught by the census bound instead: 250 ms, then the per-stage path).
+static bool device_numa_cpus(int device, cpu_set_t *out);
 static std::mutex &resident_device_lock(int device) {
     static std::mutex table_lock;
     static std::map<int, std::unique_ptr<std::mutex>> table;
@@ -958,6 +960,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     { const char *fc = std::getenv("FRX_RESIDENT_FAST_CONTROL"); rl.fast_control = fc && fc[0] == '0' ? 0 : 1; }
     { const char *tr = std::getenv("FRX_RESIDENT_TIMED_READ"); if (tr && tr[0] == '1') rl.fast_control |= 2; }
+    { const char *er = std::getenv("FRX_RESIDENT_EARLY_READ"); if (er && er[0] == '0') rl.fast_control |= 4; }
     { const char *sr = std::getenv("FRX_RESIDENT_STAMP_ROUND"); rl.stamp_round = want_prof && sr ? std::max(0, std::atoi(sr)) : 0; }
     rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;
     {   // What the leader expects of the host (frx_round_kernel.hpp): 0 nothing, it waits for every command; 1 the acceptance of a trial (ADVANCE, next
@@ -1040,7 +1043,14 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     const int scan_pause = [] { const char *e = std::getenv("FRX_RESIDENT_SCAN_PAUSE"); return e ? std::max(0, std::atoi(e)) : 0; }();   // extra pauses between two scans of a thread's mailboxes (experiments)
     std::vector<double> t_host_thr(nsrv, 0.0);
     std::vector<long> scans(nsrv, 0);
+    // the threads that talk to the device stay on the device's NUMA node for the length of the plan (FRX_NUMA=0: wherever the scheduler puts them);
+    // the caller's own affinity is put back when the plan is over
+    cpu_set_t numa_set, caller_set;
+    const bool numa_pin = !([] { const char *e = std::getenv("FRX_NUMA"); return e && e[0] == '0'; }()) && device_numa_cpus(p->device, &numa_set);
+    const bool caller_saved = numa_pin && pthread_getaffinity_np(pthread_self(), sizeof(caller_set), &caller_set) == 0;
+    if (caller_saved) (void)pthread_setaffinity_np(pthread_self(), sizeof(numa_set), &numa_set);
     auto serve = [&](int tid) {
+        if (numa_pin && tid > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(numa_set), &numa_set);
         int mine = 0;
         long nscan = 0;
         const int lo = (int)((long)S * tid / nsrv), hi = (int)((long)S * (tid + 1) / nsrv);      // this thread's clusters
@@ -1090,6 +1100,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         serve(0);
         for (auto &h : helpers) h.join();
     }
+    if (caller_saved) (void)pthread_setaffinity_np(pthread_self(), sizeof(caller_set), &caller_set);
     if (std::getenv("FRX_RESIDENT_HOST_STATS")) {                                     // diagnostic: how often a service thread looks at each of its mailboxes
         const double wall_us = 1e3 * ms_since(t0);
         for (int tid = 0; tid < nsrv; tid++) std::fprintf(stderr, "[frx] mailbox thread %d: %ld scans of %d mailboxes in %.0f us = %.3f us per scan, busy %.1f ms\n", tid, scans[tid], (int)((long)S * (tid + 1) / nsrv) - (int)((long)S * tid / nsrv), wall_us, wall_us / std::max(1L, scans[tid]), t_host_thr[tid]);
@@ -1171,6 +1182,36 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) p->resident_failed++;
     p->resident_used = G; p->resident_clusters = S;
     return FRX_OK;
+}
+
+// CPUs of the NUMA node the device hangs on (sysfs: the PCI function's numa_node, the node's cpulist), intersected with what the process may use.
+// The mailbox threads of a resident plan are kept there: with the threads on the OTHER socket of a two-socket box every command the device reads
+// and every result it writes crosses the socket interconnect and its cache-coherence traffic (measured, 32 candidates: 28.2-28.9 us per round with
+// the process on the device's node, 30.6-32.5 on the other one; waits for the host's confirmation: p90 2.3 against 6.9 us - profiles/r04_numa.txt).
+static bool device_numa_cpus(int device, cpu_set_t *out) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return false;
+    for (char *c = bdf; *c; c++) *c = (char)std::tolower(*c);
+    int node = -1;
+    { const std::string p = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node"; if (FILE *f = std::fopen(p.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); } }
+    if (node < 0) return false;
+    std::string list;
+    { const std::string p = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"; if (FILE *f = std::fopen(p.c_str(), "r")) { char buf[4096] = {0}; if (std::fgets(buf, sizeof(buf), f)) list = buf; std::fclose(f); } }
+    if (list.empty()) return false;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    for (size_t i = 0; i < list.size();) {                                   // "0-63,128-191"
+        if (!std::isdigit((unsigned char)list[i])) { i++; continue; }
+        size_t j = i; int a = 0; while (j < list.size() && std::isdigit((unsigned char)list[j])) a = 10 * a + (list[j++] - '0');
+        int b = a;
+        if (j < list.size() && list[j] == '-') { j++; b = 0; while (j < list.size() && std::isdigit((unsigned char)list[j])) b = 10 * b + (list[j++] - '0'); }
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
+        i = j;
+    }
+    if (CPU_COUNT(&want) < 2) return false;                                 // nothing (or a single CPU) of that node is ours: leave the threads where they are
+    *out = want;
+    return true;
 }
 
 // final generate (CPU.hpp:1258-1263) and the reference's return value (CPU.hpp:1267)

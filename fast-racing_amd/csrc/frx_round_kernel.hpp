@@ -483,7 +483,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         if (lstage == 2) {                                                  // after the penalty phase: adjoint, gradient, line-search scalars
             if (dg_pending) { if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]); dg_pending = false; }   // gp . d of this round's ADVANCE (read behind the adjoint's barrier)
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
-            if (unconfirmed) tap.early_cmd = &a.h_cmd[k * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7])
+            if (unconfirmed && !(a.fast_control & 4)) tap.early_cmd = &a.h_cmd[k * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7], ctlD[6])
             backward_knot_body<true, NR>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 // A predicted TRIAL step is confirmed on the step's own 64 bits, read with the word (the word carries only a 24-bit fold of them).
                 const rk_u64 we = (rk_u64)__double_as_longlong(ctlD[7]), se = (rk_u64)__double_as_longlong(ctlD[6]);
                 const bool step_ok = run_kind != 2 || se == (rk_u64)__double_as_longlong(step);
-                if ((a.fast_control & 1) && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word && step_ok) unconfirmed = false;
+                if ((a.fast_control & 1) && !(a.fast_control & 4) && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word && step_ok) unconfirmed = false;
             }
             if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
                 if (t == 0) {
@@ -837,6 +837,11 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
     for (int i = L.Rf + t; i < L.mv + 512; i += 256) sm[i] = 0.0;           // no uninitialised word is ever multiplied
     __syncthreads();
     unsigned pseq = 0, nadv = 0;
+    // (An evaluation phase is acknowledged by thread 0 alone, inside its poll loop, while the other waves stay parked at the barrier: nothing of it concerns
+    // this workgroup.  Round 4 also tried a FORWARDER here - a lane of the idle workgroup copying the host's command from the mapped mailbox into
+    // device memory for the leader, to take the PCIe read and its tail out of the adjoint: the adjoint became flat (5.4 us) but the confirmation
+    // waited more often, 0.8 us per round slower in all; what the tail really was - mailbox threads on the other socket - is cured on the host
+    // side, device_numa_cpus in frx_api.cpp: profiles/r04_numa.txt.)
     for (;;) {
         if (t == 0) {
             const rk_u64 dl = wall_clock64() + a.timeout_ticks;
@@ -844,16 +849,22 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             bool ok = true;
             for (unsigned spins = 0;; spins++) {
                 w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
-                if ((w >> 4) == pseq + 1) break;
+                if ((w >> 4) == pseq + 1) {
+                    if ((w & 15u) != (unsigned)PH_CT) break;
+                    pseq++;                                                 // an evaluation phase: nothing to do here but to report (no payload, no barrier)
+                    __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+                    spins = 0;
+                    continue;
+                }
                 if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
                 RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
-            ctlU[0] = w & 15u;
+            ctlU[0] = w & 15u; ctlU[6] = pseq + 1;
         }
         __syncthreads();
         const int kind = (int)ctlU[0];
-        pseq++;
+        pseq = ctlU[6];
         __syncthreads();
         RK_PROF(RK_P_WAIT_PHASE);
         if (kind == PH_QUIT) break;
