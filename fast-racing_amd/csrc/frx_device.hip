@@ -19,11 +19,14 @@ int launch_set_limits(const LaunchGeom &g) {
     if ((e = hipFuncSetAttribute((const void *)k_penalty_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_forward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_backward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
+    if ((e = hipFuncSetAttribute((const void *)k_forward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
+    if ((e = hipFuncSetAttribute((const void *)k_backward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
     return 0;
 }
 int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *band, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)
-        hipLaunchKernelGGL(k_forward_knot, dim3(dp.B), dim3(256), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps);
+        if (g.knot_threads == 64) hipLaunchKernelGGL(k_forward_knot64, dim3(dp.B), dim3(256), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN, g.maxXb, g.maxVb, g.pcrw, g.pcr_steps);
+        else hipLaunchKernelGGL(k_forward_knot, dim3(dp.B), dim3(256), g.lds_kfwd, (hipStream_t)stream, dp, x, T, C, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps);
     else
         hipLaunchKernelGGL(k_forward, dim3(dp.B), dim3(64), g.lds_fwd, (hipStream_t)stream, dp, x, T, C, band, g.maxN, g.maxCN);
     return (int)hipGetLastError();
@@ -41,7 +44,11 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
 int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, const double *T, const double *C,
                     const double *band, const double *out20, double *f, double *grad, void *stream, const double *tap_d, const int *tap_flags,
                     void *tap_res, unsigned *tap_arrive, volatile unsigned *tap_flag, unsigned tap_round) {
-    if (g.solver == SOLVER_KNOT_PCR)
+    if (g.solver == SOLVER_KNOT_PCR && g.knot_threads == 64)
+        hipLaunchKernelGGL(k_backward_knot64, dim3(dp.B), dim3(256), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
+                           grad, g.maxCN, g.maxXb, g.maxVb, g.pcrw, g.pcr_steps,
+                           LineSearchTap{tap_d, tap_flags, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round});
+    else if (g.solver == SOLVER_KNOT_PCR)
         hipLaunchKernelGGL(k_backward_knot, dim3(dp.B), dim3(256), g.lds_kbwd, (hipStream_t)stream, dp, x, T, C, out20, f,
                            grad, g.maxCN, g.maxXb, g.maxVb, g.knot_threads, g.pcrw, g.pcr_steps,
                            LineSearchTap{tap_d, tap_flags, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round});

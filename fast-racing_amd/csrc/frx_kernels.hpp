@@ -1261,6 +1261,13 @@ __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const doubl
     if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) return;
     forward_knot_body<false>(dp, x, Tout, Cout, maxCN, maxXb, maxVb, nrow, pcrw, nsteps, blockIdx.x, sm);
 }
+// the same for batches whose candidates all have <= 64 pieces: only the wave-specialised form is compiled in (a third of the code)
+__global__ __launch_bounds__(256) void k_forward_knot64(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
+                               int maxCN, int maxXb, int maxVb, double *__restrict__ pcrw, int nsteps) {
+    extern __shared__ double sm[];
+    if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) return;
+    forward_knot_body<false, 64>(dp, x, Tout, Cout, maxCN, maxXb, maxVb, 64, pcrw, nsteps, blockIdx.x, sm);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Adjoint for <= 64 pieces on 256 threads, round-2 form (same LDS layout as backward_knot_body, which calls it): ONE WAVE PER AXIS.
@@ -1903,6 +1910,17 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
         return;
     }
     backward_knot_body<false>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, nrow, pcrw, nsteps, tap, blockIdx.x, sm);
+}
+__global__ __launch_bounds__(256) void k_backward_knot64(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+                                const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, const double *__restrict__ pcrw, int nsteps,
+                                LineSearchTap tap) {
+    extern __shared__ double sm[];
+    if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) {           // skipped candidate: only the arrival count
+        if (threadIdx.x == 0 && tap.arrive && atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
+        return;
+    }
+    backward_knot_body<false, 64>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, 64, pcrw, nsteps, tap, blockIdx.x, sm);
 }
 #undef ROW2
 
