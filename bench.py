@@ -254,18 +254,18 @@ def main():
     eval_bytes = int(alg_bytes + np.sum(16 * nx + 24 * nvert))
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
     fp64 = None
-    fc = os.path.join(ROOT, "profiles", "r02_fp64_count_k_penalty.json")
+    fc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_fp64_count_k_penalty.json", "r02_fp64_count_k_penalty.json")) if os.path.exists(f)), "")
     if os.path.exists(fc):
         fj = json.load(open(fc))
         fl = fj["flops_per_sample_no_violation"]
-        fp64 = {"flops_per_sample": fl, "flops_per_sample_all_corridor_planes_violated": fj["flops_per_sample_all_violated"], "source": "profiles/r02_fp64_count_k_penalty.json",
+        fp64 = {"flops_per_sample": fl, "flops_per_sample_all_corridor_planes_violated": fj["flops_per_sample_all_violated"], "source": os.path.relpath(fc, ROOT),
                 "achieved_tflops": fl * samples_per_step / (pen_us * 1e-6) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                 "frac": fl * samples_per_step / (pen_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS}
     # Counter passes (rocprofv3 --pmc, one counter set per pass, scripts/r03/gpu_pmc.sh) of the gpurun call that produced the committed bench line:
     # read from profiles/, never measured inside this process - hence "from_profile".  FETCH_SIZE / WRITE_SIZE are converted to bytes with the
     # factors calibrated in the same call on a coalesced copy of known size (8-byte and 16-byte accesses per lane).
     traffic, traffic_src, valu, knot_traffic, calib = None, None, None, {}, None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_headline.json",)) if os.path.exists(f)), None)
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_headline.json", "r03_pmc_headline.json")) if os.path.exists(f)), None)
     if pmc_file and args.config == "headline":
         pj = json.load(open(pmc_file))
         traffic, traffic_src, calib = pj["traffic_bytes_per_launch"], os.path.relpath(pmc_file, ROOT), {k: v["bytes_per_counted_byte"] for k, v in pj["calibration"].items()}
@@ -312,9 +312,8 @@ def main():
         hbm_kernel = {"kernel": "frx::k_lbfgs_pre", "candidates": bl, "history_pairs": m_hist, "vector_length": n_x, "avg_kernel_us": us,
                       "bytes_per_launch": byts, "achieved": byts / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                       "check_rel_err_vs_host_recursion": err}
-        lp = os.path.join(ROOT, "profiles", "r01_pmc_lbfgs_pre.json")     # committed counter pass of the same call (scripts/gpu_pmc_lbfgs.sh)
-        if os.path.exists(lp):
-            hbm_kernel["traffic"] = json.load(open(lp))["traffic_bytes_per_launch"]; hbm_kernel["traffic_source"] = "profiles/r01_pmc_lbfgs_pre.json"
+        if pmc_file and "k_lbfgs_pre" in json.load(open(pmc_file)):         # counter pass of the same record call (scripts/r04/gpu_pmc.sh), calibrated in that call
+            hbm_kernel["traffic"] = json.load(open(pmc_file))["k_lbfgs_pre"]["traffic_bytes_per_launch"]; hbm_kernel["traffic_source"] = os.path.relpath(pmc_file, ROOT); hbm_kernel["traffic_from_profile"] = True
 
     plan = {}
     if not args.no_plan:
@@ -477,7 +476,7 @@ def main():
                                         "us_per_step": dt / args.steps * 1e6, "achieved": eval_bytes / (dt / args.steps) / 1e9, "unit": "GB/s",
                                         "frac": eval_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_kernels_us": stage_us,
-                         "knot_kernels": {k: {"kernel": {"forward": "frx::k_forward_knot", "adjoint": "frx::k_backward_knot"}[k], "avg_kernel_us": stage_us[k],
+                         "knot_kernels": {k: {"kernel": {"forward": "frx::k_forward_knot64", "adjoint": "frx::k_backward_knot64"}[k] if N <= 64 else {"forward": "frx::k_forward_knot", "adjoint": "frx::k_backward_knot"}[k], "avg_kernel_us": stage_us[k],
                                               "implementation_traffic_bytes": stage_bytes[k],
                                               "implementation_traffic_note": "x, waypoint polytopes, (T, C), out20, saved reduction multipliers, g: stage buffers between the three launches, NOT algorithmic bytes",
                                               "implementation_traffic_frac_of_hbm_peak": stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS,

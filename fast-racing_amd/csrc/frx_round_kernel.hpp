@@ -245,7 +245,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     bool adv_published = false;                                             // the ADVANCE phase word of the predicted command went out right behind the prediction (below)
     auto accept_step = [&]() {
         double *row = nullptr;                                              // direction log (tests): the pair and the gradient the direction is built from
-        if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * (4 * (size_t)a.NXP + 2);
+        if (__builtin_expect(a.dbg != nullptr, 0) && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * (4 * (size_t)a.NXP + 2);
         for (int i = t; i < n; i += 256) {
             const double xv = x[i], gv = g[i];
             if (row) { row[i] = xv - xp[i]; row[a.NXP + i] = gv - gp[i]; row[2 * a.NXP + i] = gv; }
@@ -282,7 +282,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     for (;;) {
         int kind = 0;
         RK_TR(40);                                                          // loop top
-        if (lstage == 0 && spec_ready) {                                    // the predicted command, unconfirmed for now
+        if (__builtin_expect(lstage == 0 && spec_ready, 1)) {               // the predicted command, unconfirmed for now (the common case: code laid out for it)
             spec_ready = false; unconfirmed = true; run_kind = pred_kind;
             hseq++;
             flags = (int)(pred_word & 0xFFu) & ~(int)DV_STEP_IS_ONE;
@@ -425,7 +425,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         }
         if (accept_pending) { accept_step(); accept_pending = false; }      // (the gather below reads gp behind the arrival barrier)
         RK_PROF(RK_P_PUBLISH);
-        if (kind == PH_QUIT) { leave = true; break; }
+        if (__builtin_expect(kind == PH_QUIT, 0)) { leave = true; break; }
         if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
         // ---- the phase is complete when every workgroup of the cluster has reported ----
         rk_drain_and_meet();
@@ -437,13 +437,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         const bool ok = ctlU[0] != 0u;
         __syncthreads();
         RK_PROF(RK_P_WAIT_ARRIVE);
-        if (!ok) {                                                          // tell the host and the cluster, then leave
+        if (__builtin_expect(!ok, 0)) {                                     // tell the host and the cluster, then leave
             flush(x, g);
             pseq++;
             if (t == 0) { __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
             leave = true; break;
         }
-        if (kind == PH_NEXT) {                                              // every workgroup of the cluster is on the new candidate: tell the host, whose next command starts its plan
+        if (__builtin_expect(kind == PH_NEXT, 0)) {                         // every workgroup of the cluster is on the new candidate: tell the host, whose next command starts its plan
             if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(&a.h_res[k].seq, hseq, FRX_RLX_SYS); }
             lstage = 0;
             break;
@@ -468,7 +468,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 }
             }
             trial_done = with_trial;
-            if (a.dbg && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what came back for the pair logged by accept_step
+            if (__builtin_expect(a.dbg != nullptr, 0) && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what came back for the pair logged by accept_step
                 const size_t rec = 4 * (size_t)a.NXP + 2;
                 double *row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * rec;
                 for (int i = t; i < n; i += 256) row[3 * a.NXP + i] = dv[i];
@@ -503,7 +503,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 const bool step_ok = run_kind != 2 || se == (rk_u64)__double_as_longlong(step);
                 if ((a.fast_control & 1) && !(a.fast_control & 4) && (we >> 32) == hseq && (unsigned)we == (unsigned)pred_word && step_ok) unconfirmed = false;
             }
-            if (unconfirmed) {                                              // the command this round ran on: did the host really send it?
+            if (__builtin_expect(unconfirmed, 0)) {                         // the command this round ran on: did the host really send it?
                 if (t == 0) {
                     const rk_u64 dl = wall_clock64() + a.timeout_ticks;
                     rk_u64 w = 0, stp_now = 0;                                  // word and step in ONE 16-byte read: they belong together
@@ -573,7 +573,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     accepted_first = (a.fast_control & 1) && plain && LineSearch::first_trial_accepted(lpm, step, f_acc, dgi, fv, dgv);
                     ls_ok = !accepted_first && plain && ls.mt_begin(lpm, step, f_acc, dgi) == 0;
                 }
-                if (accepted_first) {
+                if (__builtin_expect(accepted_first, 1)) {
                     const int nslot = last_slot < 0 ? 0 : (last_slot + 1 == v.m ? 0 : last_slot + 1), nbound = min(v.m, last_bound + 1);
                     pred_word = ((rk_u64)(nbound & 0xFFF) << 20) | ((rk_u64)(nslot & 0xFFF) << 8) | (rk_u64)(DV_EVAL | DV_ADVANCE | DV_TRIAL | DV_STEP_IS_ONE);
                     pred_kind = 1; spec_ready = true;
@@ -608,7 +608,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 __hip_atomic_store(&r->seq, hseq, FRX_RLX_SYS);
             }
             lstage = 0;
-            if (spec_ready && pred_kind == 1) {
+            if (__builtin_expect(spec_ready && pred_kind == 1, 1)) {
                 // The predicted ADVANCE goes to the cluster HERE, straight behind the prediction: slot and pair count, the drain of the gradient's copy,
                 // the phase word.  The members start on the direction while the leader closes the round, walks back to the top of its loop and takes
                 // the step over in its own vectors (timeline, round 4: 1.5 us lay between the prediction and the phase word).
