@@ -859,7 +859,8 @@ static std::mutex &resident_device_lock(int device) {
 }
 
 static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals, double *objective) {
-    const int B = p->B, m = pm.mem_size, E = frx::ROUND_E;
+    const int B = p->B, m = pm.mem_size;
+    int E = frx::ROUND_E;
     p->resident_used = 0; p->resident_status = 0; p->resident_failed = 0;
     if (p->geo.solver != frx::SOLVER_KNOT_PCR || m < 1 || m > 128) return 1;
     // The compact representation inverts R = S^T Y (triangular part); with fewer variables than twice the history length the pairs
@@ -870,6 +871,14 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
+    {   // Half the history elements per thread - twice the history workgroups - when the chip has room for them (up to 16 candidates at the headline
+        // size; the reference plans ONE): no history register lives in an AGPR then and both history loops are half as long (round 3 measured it
+        // on a branch, 31.1 -> 30.3 us per round with one candidate; merged in round 4).  The summation order over the history workgroups, and with
+        // it the last bits of a plan, depend on the size class of the batch.  FRX_RESIDENT_E=56 keeps the large chunks.
+        const char *ee = std::getenv("FRX_RESIDENT_E");
+        const int Es = frx::ROUND_E_SMALL, Gs = 2 + std::max(1, (p->geo.maxXb + 2 * Es - 1) / (2 * Es));
+        if (!(ee && std::atoi(ee) == frx::ROUND_E) && Gs <= 16 && (long)8 * Gs * ((B + 7) / 8) <= cus) E = Es;
+    }
     int G = 2 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each) + dense
     const int G_min = std::max(G, 3);
     {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them

@@ -101,11 +101,11 @@ static int round_eval_doubles(const LaunchGeom &g) {
     return (int)((e + 1) & ~(size_t)1) + round_ct_doubles(g);
 }
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E) {
-    if (E != ROUND_E || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
+    if ((E != ROUND_E && E != ROUND_E_SMALL) || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
     return sizeof(double) * (size_t)round_lds(m, 2 * E, round_eval_doubles(g)).total;
 }
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream) {
-    if (r.E != ROUND_E) return (int)hipErrorInvalidValue;
+    if (r.E != ROUND_E && r.E != ROUND_E_SMALL) return (int)hipErrorInvalidValue;
     RoundArgs a;
     a.dp = dp;
     a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nrow = g.knot_threads; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax;
@@ -125,16 +125,23 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     const size_t lds = round_lds_bytes(g, r.m, r.E);
     a.prof = (rk_u64 *)r.prof;
     a.trace = r.prof ? (rk_u64 *)r.trace : nullptr; a.trace_cap = r.trace_cap; a.trace_lo = r.trace_lo; a.trace_hi = r.trace_hi;
-    // four instantiations: with / without the profile, and for <= 64 pieces per candidate (the class-specific bodies only) or any geometry
+    // Instantiations: history elements per thread (56: six history workgroups at the headline size; 28: twelve, for batches that leave the chip room -
+    // no history register in an AGPR, both history loops half as long), with / without the profile, for <= 64 pieces per candidate (the
+    // class-specific bodies only) or any geometry.
     const bool n64 = g.knot_threads == 64 && !([] { const char *e = std::getenv("FRX_RESIDENT_NR"); return e && e[0] == '0'; }());   // FRX_RESIDENT_NR=0: the generic instantiation (A/B)
-    const void *fn = r.prof ? (n64 ? (const void *)k_round<ROUND_E, true, 64> : (const void *)k_round<ROUND_E, true, 0>)
-                            : (n64 ? (const void *)k_round<ROUND_E, false, 64> : (const void *)k_round<ROUND_E, false, 0>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
     const dim3 grid(8 * r.G * ((r.S + 7) / 8)), block(256);
-    if (r.prof) { if (n64) hipLaunchKernelGGL((k_round<ROUND_E, true, 64>), grid, block, lds, (hipStream_t)stream, a); else hipLaunchKernelGGL((k_round<ROUND_E, true, 0>), grid, block, lds, (hipStream_t)stream, a); }
-    else { if (n64) hipLaunchKernelGGL((k_round<ROUND_E, false, 64>), grid, block, lds, (hipStream_t)stream, a); else hipLaunchKernelGGL((k_round<ROUND_E, false, 0>), grid, block, lds, (hipStream_t)stream, a); }
-    return (int)hipGetLastError();
+    auto go = [&](auto kernel) -> int {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    };
+    if (r.E == ROUND_E) {
+        if (r.prof) return n64 ? go(k_round<ROUND_E, true, 64>) : go(k_round<ROUND_E, true, 0>);
+        return n64 ? go(k_round<ROUND_E, false, 64>) : go(k_round<ROUND_E, false, 0>);
+    }
+    if (r.prof) return n64 ? go(k_round<ROUND_E_SMALL, true, 64>) : go(k_round<ROUND_E_SMALL, true, 0>);
+    return n64 ? go(k_round<ROUND_E_SMALL, false, 64>) : go(k_round<ROUND_E_SMALL, false, 0>);
 }
 
 size_t dilate_lds_bytes(int pcap) { return sizeof(double) * ((size_t)3 * pcap + 32 + 36 + 16) + sizeof(int) * ((size_t)2 * pcap + 257 + 3); }

@@ -98,7 +98,7 @@ struct RoundLaunch {
     int fast_control = 1;                                          // see RoundArgs
     int stamp_round = 0;                                           // profiling: keep the cycle stamps of cluster 0's evaluation number stamp_round (0: of its last one)
 };
-enum { ROUND_E = 56, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
+enum { ROUND_E = 56, ROUND_E_SMALL = 28, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E);
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream);

@@ -881,18 +881,19 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
             RK_PROF(RK_P_WAIT_PART);
             {   // partial sums of the history workgroups, summed in workgroup order (deterministic); all loads of a batch in flight together
-                double pv[2][8];
+                constexpr int NB = 14;                                      // history workgroups whose loads go out as one batch (a cluster has at most 16 workgroups)
+                double pv[2][NB];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
-                    for (int w2 = 0; w2 < 8; w2++) pv[h2][w2] = ldg<true>(part + (size_t)(w2 < nh ? w2 : nh - 1) * 512 + t + 256 * h2);
+                    for (int w2 = 0; w2 < NB; w2++) pv[h2][w2] = ldg<true>(part + (size_t)(w2 < nh ? w2 : nh - 1) * 512 + t + 256 * h2);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
                     const int o = t + 256 * h2;
                     double s = 0.0;
 #pragma unroll
-                    for (int w2 = 0; w2 < 8; w2++) if (w2 < nh) s += pv[h2][w2];
-                    for (int w2 = 8; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);
+                    for (int w2 = 0; w2 < NB; w2++) if (w2 < nh) s += pv[h2][w2];
+                    for (int w2 = NB; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);
                     (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
                 }
             }

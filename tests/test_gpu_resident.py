@@ -70,21 +70,24 @@ def _two_loop(S, Y, ys, g, newest, bound, m):
     return d
 
 
-@pytest.mark.parametrize("sid,N,gates,kappa,steps", [(0, 64, 16, 16, 420), (4, 64, 16, 16, 330)])
-def test_resident_direction_equals_the_two_loop_recursion(frx, sc, sid, N, gates, kappa, steps):
+@pytest.mark.parametrize("sid,N,gates,kappa,steps,chunk", [(0, 64, 16, 16, 420, 28), (4, 64, 16, 16, 330, 56), (4, 64, 16, 16, 330, 28)])
+def test_resident_direction_equals_the_two_loop_recursion(frx, sc, monkeypatch, sid, N, gates, kappa, steps, chunk):
     """The resident kernel evaluates d = -H g in the compact (Byrd-Nocedal-Schnabel) form with an incrementally maintained R^-1
     (append a column per accepted step, drop a row and a column once the 128-pair history is full).  Contract: the reference's two-loop
     recursion (lbfgs.hpp:1381-1411).  Every accepted step of a headline-size candidate (n ~ 640 variables, m = 128) is logged on the
     device - the pair (s, y) handed to the cluster, the gradient and the direction that came back - and every direction is compared with
     a host recursion over the SAME pairs; the run is long enough for the history to wrap around at least twice."""
     m = 128
+    # both size classes of the kernel: 28 history elements per thread (twelve history workgroups: what a batch of up to 16 headline candidates gets,
+    # round 4) and 56 (six: the 32-candidate batch)
+    monkeypatch.setenv("FRX_RESIDENT_E", str(chunk))
     cand = sc.make_candidate(sid, N, gates)
     prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=kappa)
     n = int(prob.x_off[1])
     assert n >= 2 * m
     prob.direction_log(steps + 8, 1)
     r = _plan(prob, 1e-12, True, max_iterations=steps)          # tolerance far below the stock one: the run ends at the iteration limit
-    assert r["resident"] >= 3 and r["device_status"] == 0
+    assert r["resident"] == (14 if chunk == 28 else 8) and r["device_status"] == 0
     log = prob.read_direction_log(0)
     rows = len(log["slot"])
     assert rows >= 300 and rows >= 2 * m + 40, rows
@@ -110,7 +113,7 @@ def test_resident_direction_equals_the_two_loop_recursion(frx, sc, sid, N, gates
                "median_rel_err": float(np.median(errs)), "rel_err_after_first_wrap": float(errs[m:].max()), "cond_R_max": cond_max}
     print(json.dumps(summary))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"direction_pin_s{sid}.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"direction_pin_s{sid}_e{chunk}.json"), "w"), indent=1)
     assert worst <= 1e-9, summary
     prob.direction_log(0, 0)
     prob.close()
@@ -201,8 +204,10 @@ def test_work_queue_plans_do_not_depend_on_the_cluster_that_runs_them(frx, sc, m
     prob.close()
 
 
-def test_work_queue_at_the_headline_size(frx, sc):
-    """40 headline candidates = the chip's 32 clusters + 8 through the queue; the same plans as a batch of 32 and a batch of 8."""
+def test_work_queue_at_the_headline_size(frx, sc, monkeypatch):
+    """40 headline candidates = the chip's 32 clusters + 8 through the queue; the same plans as a batch of 32 and a batch of 8 (in the SAME size class
+    of the kernel: a batch of 8 alone would get twelve history workgroups per candidate - another summation order)."""
+    monkeypatch.setenv("FRX_RESIDENT_E", "56")
     B, N, gates, kappa = 40, 64, 16, 16
     cands = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)]
     tol = sc.ZHANGJIAJIE["opt_rel_tol"]
@@ -234,3 +239,20 @@ def test_resident_kernel_handles_failing_and_finishing_candidates(frx, sc, ob):
     f, _ = prob.objective(r["x"])
     assert abs(f[0] - r["objective"][0]) <= 1e-9 * abs(f[0])
     prob.close()
+
+
+def test_size_classes_of_the_kernel_agree(frx, sc, monkeypatch):
+    """A batch that leaves the chip room (<= 16 headline candidates) runs with 28 history elements per thread on twelve history workgroups, a full
+    batch with 56 on six: two summation orders of the same direction - same verdicts, objectives as close as two independent runs are."""
+    cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(4)]
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    res = {}
+    for chunk in (28, 56):
+        monkeypatch.setenv("FRX_RESIDENT_E", str(chunk))
+        prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+        res[chunk] = prob.optimize(tol)
+        prob.close()
+    a, b = res[28], res[56]
+    assert a["resident"] == 14 and b["resident"] == 8 and a["device_status"] == 0 and b["device_status"] == 0
+    assert np.array_equal(a["status"] >= 0, b["status"] >= 0)
+    assert np.abs(a["objective"] / b["objective"] - 1).max() < 5e-3
