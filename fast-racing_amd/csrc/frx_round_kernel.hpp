@@ -34,6 +34,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
 
@@ -122,15 +124,25 @@ enum { RK_P_WAIT_HOST = 0, RK_P_VECTORS = 1, RK_P_FORWARD = 2, RK_P_WAIT_PHASE =
 // extra timeline events (no segment sum): ids >= 32
 #define RK_TR(id) do { if (PROF && threadIdx.x == 0 && a.trace && v.k == 0 && pseq >= a.trace_lo && pseq < a.trace_hi && tr_n < (unsigned)a.trace_cap) \
                          a.trace[(size_t)v.wg * a.trace_cap + tr_n++] = ((rk_u64)(id) << 56) | ((rk_u64)pseq << 40) | ((rk_u64)wall_clock64() & 0xFFFFFFFFFFull); } while (0)
-// value of lane `l` (wave-uniform index) of a double, as a wave-uniform scalar: the broadcast of a vector element to all lanes without an
-// LDS access - the dense workgroup's mat-vecs are bound by LDS bandwidth, and two of the three LDS reads per row element were broadcasts
-__device__ __forceinline__ double rk_bcast(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-// keeps the scheduler from hoisting every broadcast of an unrolled loop to its top (64 scalar pairs: they would be spilled)
+// scheduling fence between the stages of the dense workgroup's passes (loads on their way | products)
 #define RK_CHUNK() __builtin_amdgcn_sched_barrier(0)
+
+// acc += e * (x of lane J of this lane's 16-lane row): the FP64 pipe takes a row broadcast as the DPP operand of a 64-bit FMA (`row_newbcast`, the one
+// DPP control it accepts), so a matrix-vector product whose vector lives one element per lane costs ONE instruction per matrix element.  Rounds 2-3
+// fetched the element with two v_readlane_b32 into a scalar pair first (rk_bcast): three instructions, the FMA waiting for the scalar write - the
+// dense passes ran at 8.5 cycles per instruction.  Every 16-lane row of `x` must hold the same sixteen vector elements.
+template <int J> __device__ __forceinline__ void rk_fma_row(double &acc, double x, double e) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(e), "n"(J));
+}
+template <int... J> __device__ __forceinline__ void rk_dot16(double &acc, double x, const double *e, std::integer_sequence<int, J...>) {
+    (rk_fma_row<J>(acc, x, e[J]), ...);
+}
+template <int... J> __device__ __forceinline__ void rk_dot16x2(double &acc0, double &acc1, double x0, double x1, const double *e, std::integer_sequence<int, J...>) {
+    ((rk_fma_row<J>(acc0, x0, e[J]), rk_fma_row<J>(acc1, x1, e[J])), ...);
+}
+typedef std::make_integer_sequence<int, 16> rk_seq16;
+// a VALU write of `x` must be two instructions old before a DPP operand reads it; the compiler does not see into the asm
+#define RK_DPP_SETTLE() asm volatile("s_nop 1" ::: "memory")
 
 // One 16-byte system-scope load of a candidate's command {word, step} from mapped host memory: the two live in one aligned 16-byte
 // granule that the host fills step first, word (with the sequence number) last, so a word that carries the expected sequence number
@@ -876,6 +888,16 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
         }
         if (kind == PH_ADV) {
             nadv++;
+            // Row pp of R^-1 as the previous step left it goes into registers NOW, while thread 0 still waits for the partial sums (round 4: pass 1 used
+            // to read it from LDS in chunks of 16 in front of their products, one exposed LDS latency plus the four waves' shared read bandwidth per
+            // chunk - 1.44 us for 0.6 us of products).  The entry of column jnew is stale then (the dropped pair's): the broadcast vectors carry a zero there.
+            double er[64];
+            {
+                const double *row = Rf + pp * RK_RS + q0;
+#pragma unroll
+                for (int j = 0; j < 64; j++) er[j] = row[j];
+            }
+            RK_CHUNK();
             if (t == 0) { ctlU[1] = (unsigned)ldg<true>(pub + 2 * a.NXP); const bool ok = rk_wait_eq(a.cntA + k * RK_WSTRIDE, (unsigned)nh * nadv, a); if (!ok) rk_fail(a, RK_ERR_DENSE); }
             __syncthreads();
             const int jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
@@ -900,25 +922,22 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             if (t < 128) { Rf[jnew * RK_RS + t] = 0.0; Rf[t * RK_RS + jnew] = 0.0; }                  // the pair that slot jnew held is gone
             __syncthreads();
             RK_PROF(RK_P_DENSE_IN);
-            const int ln = t & 63;                                          // lane ln of every wave holds element q0 + ln of a broadcast vector
+            const int ln = t & 63, l16 = t & 15;                            // every 16-lane row holds elements q0 + 16 q + l16 of a vector in register q (rk_fma_row)
             // (Y^T Y's registers take the new pair's row and column AFTER the result is published - 0.8 us off the critical path; until
             // then row / column jnew of the registers still hold the dropped pair: pass 2 masks them and adds the new ones from `ve`)
             const double rho = vc[jnew], gamma = rho / ve[jnew], wl = va[jnew] / rho;      // y.s, y.s / y.y of the newest pair (lbfgs.hpp:1403)
             // pass 1: rows of the old R^-1, two right-hand sides at once: z = R22^-1 c, tt = R22^-1 a (row and column jnew are zero)
             {
-                double sz = 0.0, st = 0.0;
-                const double *row = Rf + pp * RK_RS + q0;
-                const double vcl = vc[q0 + ln], val = va[q0 + ln];
+                double sz = 0.0, st = 0.0, xc[4], xa[4];
 #pragma unroll
-                for (int u0 = 0; u0 < 64; u0 += 16) {                      // a chunk of the row into registers, then the products: one LDS latency per chunk
-                    double e[16];
-#pragma unroll
-                    for (int j = 0; j < 16; j++) e[j] = row[u0 + j];
-                    RK_CHUNK();
-#pragma unroll
-                    for (int j = 0; j < 16; j++) { sz += e[j] * rk_bcast(vcl, u0 + j); st += e[j] * rk_bcast(val, u0 + j); }
-                    RK_CHUNK();
+                for (int q = 0; q < 4; q++) {
+                    const int el = q0 + 16 * q + l16;
+                    const bool dropped = el == jnew;                        // column jnew of the old R^-1 counts as zero
+                    xc[q] = dropped ? 0.0 : vc[el]; xa[q] = dropped ? 0.0 : va[el];
                 }
+                RK_DPP_SETTLE();
+#pragma unroll
+                for (int q = 0; q < 4; q++) rk_dot16x2(sz, st, xc[q], xa[q], er + 16 * q, rk_seq16());
                 mv[hq * 128 + pp] = sz; mz[hq * 128 + pp] = st;
             }
             __syncthreads();
@@ -932,17 +951,26 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             __syncthreads();
             // pass 2: (Y^T Y) w.  The registers hold the matrix of the PREVIOUS step; the new pair's row and column are e = Y^T y_new (ve):
             //   (YY w)[p] = sum_{q != jnew} YY_old[p][q] w[q] + e[p] w[jnew]   (p != jnew),      (YY w)[jnew] = e . w
+            double ec[64];                                                  // column pp of the NEW R^-1, rows q0 .. q0 + 63: on its way during pass 2, used by pass 3
             {
-                double sacc = 0.0;
-                const double vwl = (q0 + ln == jnew) ? 0.0 : vw[q0 + ln];
+                double sacc = 0.0, xw[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int el = q0 + 16 * q + l16; xw[q] = el == jnew ? 0.0 : vw[el]; }
+                const double vet = t < 128 ? ve[t] : 0.0, vwt = t < 128 ? vw[t] : 0.0;
+                RK_CHUNK();
+                {
+                    const double *col = Rf + q0 * RK_RS + pp;
+#pragma unroll
+                    for (int j = 0; j < 64; j++) ec[j] = col[j * RK_RS];
+                }
+                RK_CHUNK();
                 if (t < 128) {                                              // e . w on waves 0 and 1, interleaved with the products below
-                    const double ws = wave_sum_dpp(ve[t] * vw[t]);
+                    const double ws = wave_sum_dpp(vet * vwt);
                     if (ln == 0) ctlD[t >> 6] = ws;
                 }
-#pragma unroll
-                for (int u = 0; u < 32; u++) { sacc += Ya[u] * rk_bcast(vwl, u); if ((u & 15) == 15) RK_CHUNK(); }
-#pragma unroll
-                for (int u = 0; u < 32; u++) { sacc += Yb[u] * rk_bcast(vwl, 32 + u); if ((u & 15) == 15) RK_CHUNK(); }
+                RK_DPP_SETTLE();
+                rk_dot16(sacc, xw[0], Ya, rk_seq16()); rk_dot16(sacc, xw[1], Ya + 16, rk_seq16());
+                rk_dot16(sacc, xw[2], Yb, rk_seq16()); rk_dot16(sacc, xw[3], Yb + 16, rk_seq16());
                 mv[hq * 128 + pp] = sacc;
             }
             __syncthreads();
@@ -954,19 +982,12 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             __syncthreads();
             // pass 3: columns of the new R^-1: u = R^-T v
             {
-                double sacc = 0.0;
-                const double *col = Rf + q0 * RK_RS + pp;
-                const double vvl = vv[q0 + ln];
+                double sacc = 0.0, xv[4];
 #pragma unroll
-                for (int u0 = 0; u0 < 64; u0 += 16) {
-                    double e[16];
+                for (int q = 0; q < 4; q++) xv[q] = vv[q0 + 16 * q + l16];
+                RK_DPP_SETTLE();
 #pragma unroll
-                    for (int j = 0; j < 16; j++) e[j] = col[(u0 + j) * RK_RS];
-                    RK_CHUNK();
-#pragma unroll
-                    for (int j = 0; j < 16; j++) sacc += e[j] * rk_bcast(vvl, u0 + j);
-                    RK_CHUNK();
-                }
+                for (int q = 0; q < 4; q++) rk_dot16(sacc, xv[q], ec + 16 * q, rk_seq16());
                 mz[hq * 128 + pp] = sacc;
             }
             __syncthreads();
