@@ -141,6 +141,11 @@ template <int... J> __device__ __forceinline__ void rk_dot16x2(double &acc0, dou
     ((rk_fma_row<J>(acc0, x0, e[J]), rk_fma_row<J>(acc1, x1, e[J])), ...);
 }
 typedef std::make_integer_sequence<int, 16> rk_seq16;
+// the four dot products of pass A over a thread's E history elements: element I of the half's chunk sits in lane I % 16 of register I / 16
+template <int... I> __device__ __forceinline__ void rk_pass_a_dots(double (&acc)[4], const double *gq, const double *yq, const double *S, const double *Y, std::integer_sequence<int, I...>) {
+    ((rk_fma_row<I % 16>(acc[0], gq[I / 16], S[I]), rk_fma_row<I % 16>(acc[1], gq[I / 16], Y[I]),
+      rk_fma_row<I % 16>(acc[2], yq[I / 16], S[I]), rk_fma_row<I % 16>(acc[3], yq[I / 16], Y[I])), ...);
+}
 // a VALU write of `x` must be two instructions old before a DPP operand reads it; the compiler does not see into the asm
 #define RK_DPP_SETTLE() asm volatile("s_nop 1" ::: "memory")
 
@@ -727,30 +732,19 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             const bool valid = slot < m && age < bound;
             {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                if (valid) {
-                    // The chunk values come from LDS (broadcast reads), the pair from registers.  Left to itself the compiler read two elements,
-                    // waited, multiplied, read the next two (28 exposed LDS latencies, ~1.8 us of this pass, ISA); here the reads of a block of
-                    // CH elements are in flight while the previous block is multiplied - same products, same order of additions.
-                    constexpr int CH = (E % 8 == 0) ? 8 : 4;
-                    static_assert(E % CH == 0, "history elements per thread: a multiple of the block");
-                    double gb[2][CH], yb[2][CH];
+                {
+                    // The pair comes from registers, the chunk values (the same for every thread of a half) from the lanes of the thread's own 16-lane row:
+                    // register q of gq / yq holds elements 16 q + (lane & 15) of the half's chunk and the FMA takes its operand as a row broadcast
+                    // (rk_fma_row).  Rounds 3-4 read each value from LDS as a broadcast read - 2 E reads per thread next to 4 E products, pipelined in
+                    // blocks of eight since round 3; now 2 ceil(E / 16) reads.  Same products, same order of additions.  EVERY lane runs the loop (a DPP
+                    // operand needs its source lane active): a slot without a pair holds zeros or a finished plan's finite pair, its sums are dropped below.
+                    constexpr int NQ = (E + 15) / 16;
+                    double gq[NQ], yq[NQ];
 #pragma unroll
-                    for (int j = 0; j < CH; j++) { gb[0][j] = gC[half * E + j]; yb[0][j] = yC[half * E + j]; }
-#pragma unroll
-                    for (int e0 = 0; e0 < E; e0 += CH) {
-                        const int cur = (e0 / CH) & 1, nxt = cur ^ 1;
-                        if (e0 + CH < E) {
-#pragma unroll
-                            for (int j = 0; j < CH; j++) { gb[nxt][j] = gC[half * E + e0 + CH + j]; yb[nxt][j] = yC[half * E + e0 + CH + j]; }
-                        }
-                        RK_CHUNK();
-#pragma unroll
-                        for (int j = 0; j < CH; j++) {
-                            const double gg = gb[cur][j], yn = yb[cur][j];
-                            acc[0] += Sreg[e0 + j] * gg; acc[1] += Yreg[e0 + j] * gg; acc[2] += Sreg[e0 + j] * yn; acc[3] += Yreg[e0 + j] * yn;
-                        }
-                        RK_CHUNK();
-                    }
+                    for (int q = 0; q < NQ; q++) { const int el = half * E + min(16 * q + (t & 15), E - 1); gq[q] = gC[el]; yq[q] = yC[el]; }
+                    RK_DPP_SETTLE();
+                    rk_pass_a_dots(acc, gq, yq, Sreg, Yreg, std::make_integer_sequence<int, E>());
+                    if (!valid) { acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) pair[(half * 4 + q) * 128 + slot] = acc[q];
