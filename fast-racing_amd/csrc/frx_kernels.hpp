@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         double *cstage = ct_lds ? ct_lds : rowbuf;                         // where the coefficients are collected (the matrix rows are dead by the time the axis waves write here)
         if (wave == 0) {
             // durations left and right of knot kk: the left one comes from the neighbouring lane (lane = piece = knot)
-            const double hLs = __shfl_up(hMine, 1, 64);
+            const double hLs = lane_up1(hMine);
             const bool act0 = kk >= 1 && kk <= N - 1;
             pcr_matrix_wave64(rowbuf, kk, N, act0 ? hLs : 1.0, act0 ? hMine : 1.0, pwf, pws, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, progress);
             FRX_STAMP(5);
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 vK = Di[0] * r0 + Di[1] * r1; aK = Di[2] * r0 + Di[3] * r1;
             }
             if (kk == 0) { vK = vHead; aK = aHead; }
-            double vR = __shfl_down(vK, 1, 64), aR = __shfl_down(aK, 1, 64);
+            double vR = lane_down1(vK), aR = lane_down1(aK);
             if (kk == N - 1) { vR = vTail; aR = aTail; }
             // piece coefficients of this axis (quintic Hermite, hermite_coeffs term by term): piece kk between knots kk and kk + 1
             if (kk < N) {
@@ -1404,12 +1404,12 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         }
         // knot states recovered from the coefficients: p = c0, v = c1, a = 2 c2 at the piece start; the next knot's from the next lane
         const double P0 = cq[0], V0 = cq[1], A0 = 2.0 * cq[2];
-        double P1 = __shfl_down(P0, 1, 64), V1 = __shfl_down(V0, 1, 64), A1 = __shfl_down(A0, 1, 64);
+        double P1 = lane_down1(P0), V1 = lane_down1(V0), A1 = lane_down1(A0);
         if (kk == N - 1) { P1 = r_tl[0]; V1 = r_tl[1]; A1 = r_tl[2]; }
         // ---- Hermite adjoint of the piece; its end-of-piece parts belong to the next knot (= next lane) ----
         double db[6] = {0, 0, 0, 0, 0, 0}, hb = 0.0;
         if (piece) hermite_adjoint(h, P0, V0, A0, P1, V1, A1, cbq, db, hb);
-        const double ePu = __shfl_up(db[3], 1, 64), eVu = __shfl_up(db[4], 1, 64), eAu = __shfl_up(db[5], 1, 64);
+        const double ePu = lane_up1(db[3]), eVu = lane_up1(db[4]), eAu = lane_up1(db[5]);
         double r0 = 0.0, r1 = 0.0, pbk = 0.0;
         if (act) { r0 = db[1] + eVu; r1 = db[2] + eAu; pbk = db[0] + ePu; }      // right-hand side of K mu = wbar; direct d f / d p_k (both adjacent pieces)
         FRX_STAMP_AX(26);
@@ -1458,11 +1458,11 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         }
         FRX_STAMP_AX(27);
         // ---- through the knot system: duration term and d f / d(p_{k+1} - p_k) ----
-        double mu1v = __shfl_down(muv, 1, 64), mu1a = __shfl_down(mua, 1, 64);
+        double mu1v = lane_down1(muv), mu1a = lane_down1(mua);
         if (kk >= N - 1) { mu1v = 0.0; mu1a = 0.0; }
         double dlb = 0.0;
         if (piece) dlb = knot_adjoint_piece(h, P1 - P0, V0, A0, V1, A1, muv, mua, mu1v, mu1a, hb);
-        const double dlu = __shfl_up(dlb, 1, 64);                    // + dl of the piece ending at this knot
+        const double dlu = lane_up1(dlb);                    // + dl of the piece ending at this knot
         if (piece) KN(KV, ax, kk) = hb;
         if (act) KN(KP, ax, kk) = pbk + dlu - dlb;                   // d f / d q_k for the pair that owns the waypoint
         FRX_STAMP_AX(28);

@@ -908,7 +908,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                     const int o = t + 256 * h2;
                     double s = 0.0;
 #pragma unroll
-                    for (int w2 = 0; w2 < NB; w2++) if (w2 < nh) s += pv[h2][w2];
+                    for (int w2 = 0; w2 < NB; w2++) s += w2 < nh ? pv[h2][w2] : 0.0;       // (the select outside the chain of additions)
                     for (int w2 = NB; w2 < nh; w2++) s += ldg<true>(part + (size_t)w2 * 512 + o);
                     (o < 128 ? va : o < 256 ? vb : o < 384 ? vc : ve)[o & 127] = s;
                 }

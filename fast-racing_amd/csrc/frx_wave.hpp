@@ -63,6 +63,20 @@ template <bool spread> __device__ __forceinline__ double wave_sum4_packed(double
 }
 
 
+// Neighbour exchange by ONE lane as a DPP move (wave_shr:1 / wave_shl:1, 2 instructions per double) instead of __shfl_up / __shfl_down, which
+// go through the LDS crossbar (address arithmetic + 2 ds_bpermute + a wait for their round trip).  Same semantics: the lane without a
+// neighbour (0 resp. 63) keeps its own value.
+__device__ __forceinline__ double lane_up1(double v) {            // lane i <- lane i - 1
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_down1(double v) {          // lane i <- lane i + 1
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // sum over the 4 lanes of a quad, result in every lane of the quad (two quad permutes; replaces two ds_bpermute round trips)
 __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
