@@ -93,8 +93,8 @@ struct RoundArgs {
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20, *pcrw;           // leader-private vectors + the evaluation's stage buffers
     double *pubsyg;          // [S][3 NXP + 2] leader -> cluster: the point x and its gradient g (first 2 NXP doubles, zero beyond n), then (slot, pair count)
     double *part;            // [S][G][4][128] cluster -> dense: partial dot products
-    double *upub;            // [S][258]      dense -> cluster: -u, gamma w, gamma
-    double *dpub;            // [S][NXP]      cluster -> leader: direction chunks
+    double *upub;            // [S][257] granules (2 words per value, rk_ll_put)      dense -> cluster: -u, gamma w, gamma
+    double *dpub;            // [S][NXP] granules      cluster -> leader: direction chunks
     unsigned *phase, *cntA, *uflag, *cntL;   // word k * RK_WSTRIDE of each (k: cluster) (zeroed before every launch); the four bases are 32 words apart
     unsigned *census, *status;               // [1] each (zeroed before every launch)
     unsigned *xcc;                           // [S][G] XCC id + 1 of every workgroup (zeroed before every launch)
@@ -185,6 +185,21 @@ __device__ __forceinline__ void rk_drain_and_meet() {
     __syncthreads();
 }
 
+// ---- hand-offs without a flag: self-validating granules --------------------------------------------------------------------------------------------
+// A double that another workgroup waits for can travel as TWO 8-byte words {low half | tag << 32}, {high half | tag << 32} (the LL form of the
+// collectives libraries): the consumer polls the payload itself and takes a value when both words carry the tag it expects (the number of the
+// direction phase - never repeated within a launch; the buffers start zeroed).  Each word is one naturally atomic 8-byte access, so nothing is
+// drained, no flag follows, no workgroup meets: one L2 round trip where flag-then-payload (drain, barrier, flag; poll, barrier, payload loads)
+// takes two and a half.  Used where every consumer thread polls a FEW granules (dense -> history workgroups: 2 per thread, history -> leader: 3);
+// for the partial sums into the dense workgroup (2 x 6..14 per thread) the polling sweeps themselves were the cost and the counter stayed.
+__device__ __forceinline__ void rk_ll_put(rk_u64 *slot, double v, unsigned tag, bool wt) {
+    const rk_u64 b = (rk_u64)__double_as_longlong(v), tg = (rk_u64)tag << 32;
+    const rk_u64 w0 = (b & 0xFFFFFFFFull) | tg, w1 = (b >> 32) | tg;
+    if (wt) { __hip_atomic_store(slot, w0, FRX_RLX_AGENT); __hip_atomic_store(slot + 1, w1, FRX_RLX_AGENT); }
+    else { slot[0] = w0; slot[1] = w1; }
+}
+__device__ __forceinline__ bool rk_ll_ok(rk_u64 w0, rk_u64 w1, unsigned tag) { return (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag; }
+__device__ __forceinline__ double rk_ll_value(rk_u64 w0, rk_u64 w1) { return __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32))); }
 
 // ---- pieces shared by the two role loops ----
 struct RoundView {                       // per-workgroup constants; c, n, xbase, p0, N change when the cluster takes another candidate (DV_NEXT)
@@ -254,6 +269,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     // so it forms s and y itself - bit for bit the values the leader would have sent.  Round 2 published s, y and g here: 2016 stores and
     // their drain (1.5-2 us) between the end of the adjoint and the phase word of every accepted step.
     unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
+    unsigned nadv_tag = 0;                                                  // direction phases of this LAUNCH so far = the tag of the granules the cluster sends back (never reset)
     bool trial_done = false, dg_pending = false;
     // The cluster needs nothing of the leader's own bookkeeping of an accepted step (xp = x, gp = g in its LDS) to start on the new direction -
     // the point and its gradient are in `pub` already - so the phase word leaves first and the copies run while the members work (round 4:
@@ -449,10 +465,15 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
         RK_TR(37);
         nphase++;
-        if (t == 0) { const bool ok = rk_wait_eq(a.cntL + k * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!ok) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = ok ? 1u : 0u; }
-        __syncthreads();
-        const bool ok = ctlU[0] != 0u;
-        __syncthreads();
+        // (A direction phase is not waited for here: the direction arrives as granules that the gather below polls, and the arrivals of this phase are
+        // part of the count the NEXT phase waits for.)
+        bool ok = true;
+        if (kind != PH_ADV) {
+            if (t == 0) { const bool okw = rk_wait_eq(a.cntL + k * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!okw) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = okw ? 1u : 0u; }
+            __syncthreads();
+            ok = ctlU[0] != 0u;
+            __syncthreads();
+        }
         RK_PROF(RK_P_WAIT_ARRIVE);
         if (__builtin_expect(!ok, 0)) {                                     // tell the host and the cluster, then leave
             flush(x, g);
@@ -469,11 +490,27 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             // ... and, in the same sweep, the first trial point of the new search x = xp + step d (lbfgs.hpp:825-826; every ADVANCE command
             // carries TRIAL): the element a thread gathers is the element it moves, so no barrier lies between the two
             double acc = 0.0;
+            nadv_tag++;
             const bool with_trial = (flags & DV_TRIAL) != 0;
             for (int i0 = t; i0 < n; i0 += 3 * 256) {                       // three elements per thread and trip, their loads in flight together (the plain loop
                 double dl[3];                                               // compiled to load / s_waitcnt vmcnt(0) / use per element: three L2 round trips in a row)
+                {   // the elements travel as granules tagged with the number of the direction phase (rk_ll_put by the history workgroups): poll until all three are this phase's
+                    rk_u64 w[3][2];
+                    const rk_u64 dl_t = wall_clock64() + a.timeout_ticks;
+                    for (unsigned spins = 0;; spins++) {
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int i = i0 + 256 * u; dl[u] = ldg<true>(dpub + (i < n ? i : n - 1)); }
+                        for (int u = 0; u < 3; u++) {
+                            const int i = i0 + 256 * u;
+                            const rk_u64 *gsl = (const rk_u64 *)dpub + 2 * (size_t)(i < n ? i : n - 1);
+                            w[u][0] = __hip_atomic_load(gsl, FRX_RLX_AGENT); w[u][1] = __hip_atomic_load(gsl + 1, FRX_RLX_AGENT);
+                        }
+                        if (rk_ll_ok(w[0][0], w[0][1], nadv_tag) && rk_ll_ok(w[1][0], w[1][1], nadv_tag) && rk_ll_ok(w[2][0], w[2][1], nadv_tag)) break;
+                        if ((spins & 31u) == 31u && rk_expired(a, dl_t)) { rk_fail(a, RK_ERR_ARRIVE); break; }
+                        RK_PAUSE(a);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) dl[u] = rk_ll_value(w[u][0], w[u][1]);
+                }
 #pragma unroll
                 for (int u = 0; u < 3; u++) {
                     const int i = i0 + 256 * u;
@@ -756,12 +793,24 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             if (t == 0) __hip_atomic_fetch_add(a.cntA + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
             RK_PROF(RK_P_PASS_A);
             // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
-            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + k * RK_WSTRIDE, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
-            __syncthreads();
+            double coefS, coefY;
+            {   // every thread polls the two coefficients of ITS slot (and thread 0 gamma) until they carry this phase's tag
+                const rk_u64 *us = (const rk_u64 *)upub + 2 * slot, *ys = (const rk_u64 *)upub + 2 * (128 + slot), *gs = (const rk_u64 *)upub + 2 * 256;
+                const rk_u64 dl = wall_clock64() + a.timeout_ticks;
+                rk_u64 u0, u1, y0, y1, g0 = 0, g1 = 0;
+                for (unsigned spins = 0;; spins++) {
+                    u0 = __hip_atomic_load(us, FRX_RLX_AGENT); u1 = __hip_atomic_load(us + 1, FRX_RLX_AGENT);
+                    y0 = __hip_atomic_load(ys, FRX_RLX_AGENT); y1 = __hip_atomic_load(ys + 1, FRX_RLX_AGENT);
+                    if (t == 0) { g0 = __hip_atomic_load(gs, FRX_RLX_AGENT); g1 = __hip_atomic_load(gs + 1, FRX_RLX_AGENT); }
+                    if (rk_ll_ok(u0, u1, nadv) && rk_ll_ok(y0, y1, nadv) && (t != 0 || rk_ll_ok(g0, g1, nadv))) break;
+                    if ((spins & 31u) == 31u && rk_expired(a, dl)) { rk_fail(a, RK_ERR_UFLAG); break; }
+                    RK_PAUSE(a);
+                }
+                coefS = rk_ll_value(u0, u1); coefY = rk_ll_value(y0, y1);
+                if (t == 0) ctlD[6] = rk_ll_value(g0, g1);                  // (read behind the barriers of the products below)
+            }
             RK_PROF(RK_P_WAIT_U);
             {
-                double coefS = ldg<true>(upub + slot), coefY = ldg<true>(upub + 128 + slot);
-                if (t == 0) ctlD[6] = ldg<true>(upub + 256);
                 if (!valid) { coefS = 0.0; coefY = 0.0; }                   // a slot without a pair holds zeros or a finished plan's (finite) pair: 0 s + 0 y = 0, no select per element
                 // Element i of the chunk is a sum over the 128 SLOTS of this thread's products - a reduction ACROSS threads for each of the
                 // 2 E elements.  Round 2 did it with 14 packed four-value wave reductions per wave (~460 dependent DPP / crossbar
@@ -800,7 +849,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
                 for (int i = t; i < CHT; i += 256) {
                     const int hh = i / E, e = i - hh * E;
                     const double di = (wsum[(2 * hh) * E + e] + wsum[(2 * hh + 1) * E + e]) - gamma * gC[i];
-                    stg<true>(dpub + hg * CHT + i, di, wt);
+                    rk_ll_put((rk_u64 *)dpub + 2 * (hg * CHT + i), di, nadv, wt);   // granule: the leader polls the elements it gathers
                 }
             }
             RK_PROF(RK_P_PASS_B);
@@ -986,13 +1035,11 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             }
             __syncthreads();
             RK_PROF(RK_P_PASS_B);                                           // (dense workgroup: pass 3)
-            if (t < 128) {
-                stg<true>(upub + t, -(mz[t] + mz[128 + t]), wt);
-                stg<true>(upub + 128 + t, gamma * vw[t], wt);
+            if (t < 128) {                                                  // granules: every history thread polls its own two (rk_ll_put) - no drain, no flag
+                rk_ll_put((rk_u64 *)upub + 2 * t, -(mz[t] + mz[128 + t]), nadv, wt);
+                rk_ll_put((rk_u64 *)upub + 2 * (128 + t), gamma * vw[t], nadv, wt);
             }
-            if (t == 128) stg<true>(upub + 256, gamma, wt);
-            rk_drain_and_meet();
-            if (t == 0) __hip_atomic_store(a.uflag + k * RK_WSTRIDE, nadv, FRX_RLX_AGENT);
+            if (t == 128) rk_ll_put((rk_u64 *)upub + 2 * 256, gamma, nadv, wt);
             RK_PROF(RK_P_SOLVE);
             {   // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are) - behind the publication
                 const int uj = jnew - q0;
@@ -1033,7 +1080,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
     v.xbase = a.dp.xoff[v.c]; v.n = a.dp.xoff[v.c + 1] - v.xbase;
     v.p0 = a.dp.poff[v.c]; v.N = a.dp.poff[v.c + 1] - v.p0;
-    v.pub = a.pubsyg + (size_t)v.k * (3 * a.NXP + 2); v.part = a.part + (size_t)v.k * a.G * 512; v.upub = a.upub + (size_t)v.k * 258; v.dpub = a.dpub + (size_t)v.k * a.NXP;
+    v.pub = a.pubsyg + (size_t)v.k * (3 * a.NXP + 2); v.part = a.part + (size_t)v.k * a.G * 512; v.upub = a.upub + (size_t)v.k * 516; v.dpub = a.dpub + (size_t)v.k * 2 * a.NXP;
     // ---- census: every workgroup of the launch must be resident before anybody waits for anybody ----
     if (v.t == 0) {
         unsigned my_xcc = 0;
