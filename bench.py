@@ -385,7 +385,11 @@ def main():
             if r_q is not None:
                 plan.update({"plan_ms_work_queue": r_q["ms_total"], "plan_clusters_work_queue": int(r_q["clusters"]), "plans_per_s_work_queue": B / (r_q["ms_total"] * 1e-3),
                              "plan_commands_of_the_busiest_cluster": r_q["rounds"], "plan_evals_mean": float(r_q["evals"].mean()),
-                             "work_queue_equals_default_path_status": bool(np.array_equal(r_q["status"], r["status"]))})
+                             "work_queue_equals_default_path_status": bool(np.array_equal(r_q["status"], r["status"])),
+                             # the two paths form the direction differently (compact form in registers | two-loop recursion over HBM): same verdict per
+                             # scenario is the claim, the L-BFGS code of a plan that stalls on an infeasible corridor may differ
+                             "work_queue_status_mismatches": int((np.asarray(r_q["status"]) != np.asarray(r["status"])).sum()),
+                             "work_queue_verdict_mismatches": int(((np.asarray(r_q["status"]) >= 0) != (np.asarray(r["status"]) >= 0)).sum())})
         if r_lib is not None:
             plan.update({"plan_front_end": "frx_multi_* (one process, one host thread + handle per device)", "plan_ms_whole_job": r_lib["ms_wall"],
                          "plan_shards": int(r_lib["n_shards"]), "plan_winner_exchange": r_lib["exchange"],

@@ -35,8 +35,8 @@ for p in sorted(mem[32]):                                      # phases in which
     q = p + 1                                                   # the evaluation phase of the same command
     try:
         m = {"adj_end(prev)": lead[13][p - 1], "confirmed": lead[4][p - 1], "predicted": lead[5][p - 1], "member sees ADV": mem[3][p], "chunk loaded": mem[32][p], "dots done": mem[33][p], "partials out": mem[4][p],
-             "dense has all": den[5][p], "dense gathered": den[6][p], "pass1": den[4][p], "pass2": den[2][p], "pass3": den[9][p], "u,w published": den[7][p], "member sees u": mem[8][p],
-             "products": mem[34][p], "colsums": mem[35][p], "pass B stored": mem[9][p], "member cntL": mem[36][p], "leader arrived": lead[11][p], "gathered": lead[12][p], "forward starts": lead[1][p],
+             "dense has all": den[5][p], "dense gathered": den[6][p], "pass1": den[4][p], "pass2": den[2][p], "pass3": den[9][p], "u,w granules out": den[7][p], "member has its coefficients": mem[8][p],
+             "products": mem[34][p], "colsums": mem[35][p], "direction granules out": mem[9][p], "leader has direction + trial point": lead[12][p], "forward starts": lead[1][p],
              "forward done": lead[2][p], "drained": lead[7][p], "member sees CT": mem[3][q], "penalty done": mem[10][q], "member cntL (CT)": mem[36][q], "leader arrived (CT)": lead[11][q], "adj_end": lead[13][q]}
     except KeyError:
         continue
@@ -46,4 +46,4 @@ A = np.array([[row[n] for n in names] for row in rows], dtype=np.float64) / 100.
 d = np.diff(A, axis=1)
 print(json.dumps({"B": B, "rounds_in_the_sample": len(rows), "us_per_round_instrumented": 1e3 * r["ms_total"] / r["rounds"], "round_us_mean (adjoint end to adjoint end)": float((A[:, -1] - A[:, 0]).mean())}))
 for i, n in enumerate(names[1:]):
-    print(f"{names[i]:>22s} -> {n:<22s} mean {d[:, i].mean():6.2f}  median {np.median(d[:, i]):6.2f}  p90 {np.percentile(d[:, i], 90):6.2f}  max {d[:, i].max():6.2f}")
+    print(f"{names[i]:>34s} -> {n:<34s} mean {d[:, i].mean():6.2f}  median {np.median(d[:, i]):6.2f}  p90 {np.percentile(d[:, i], 90):6.2f}  max {d[:, i].max():6.2f}")
