@@ -1,22 +1,24 @@
-// The resident round kernel: a whole optimisation of B candidates as ONE launch.
+// The resident round kernel: a whole optimisation of B candidates as ONE launch.  (Design: DESIGN.md section 3.5; history of its steps: profiles/NOTES.md.)
 //
 // What the reference does on its device (cuda_computer.cu:51-64, 384-405, 454-466, 535-548): the penalty kernel is launched once,
 // polls a flag in mapped host memory, evaluates, posts `done`, and the host spins on it; every other stage of a round runs on the
 // CPU.  Here every stage of a round runs on the device and the kernel stays resident for the whole plan: the host keeps the
-// line-search DECISIONS (frx_lbfgs.hpp, SolverDV) and talks to each candidate through a 16-byte command / 64-byte result mailbox
+// line-search DECISIONS (frx_lbfgs.hpp, SolverDV) and talks to each cluster through a 16-byte command / 64-byte result mailbox
 // in mapped host memory; candidates advance independently of each other (no batch-wide round barrier).
 //
-// Geometry: a CLUSTER of G workgroups (256 threads, one per CU) per candidate, grid = B x G <= number of CUs.
-//   workgroup 0      LEADER: owns x, g, xp, gp, d (global memory, touched by this CU only), talks to the host, runs the MINCO
-//                    forward map and the adjoint (forward_knot_body / backward_knot_body of frx_kernels.hpp, unchanged arithmetic).
-//                    It carries no history: its loop is a separate branch of the kernel, so the evaluation bodies get the whole
-//                    register file (with the history live across them the compiler spilled 93 VGPRs into the adjoint).
+// Geometry: a CLUSTER of G workgroups (256 threads, one per CU) per candidate, grid = 8 G ceil(S / 8) <= number of CUs; S clusters take
+// B >= S candidates one after the other (work queue, DV_NEXT).
+//   workgroup 0      LEADER: x, g, xp, gp, d, the waypoint polytopes, the reduction multipliers and (C, T) live in its LDS for the whole plan
+//                    (global x is read once and written once); it talks to the host, predicts the host's next command (LineSearch runs on
+//                    both sides) and runs the MINCO forward map and the adjoint (forward_knot_body / backward_knot_body of frx_kernels.hpp,
+//                    shared arithmetic).  It carries no history: its loop is a separate branch of the kernel, so the evaluation bodies get
+//                    the whole register file.
 //   workgroups 1..G-2 keep 1/(G-2) of the candidate's (s, y) HISTORY RESIDENT IN REGISTERS: thread (slot j, half h) holds the elements
-//                    [h E, (h+1) E) of its workgroup's chunk of s_j and y_j - 2 E doubles; the whole 46 MB history of the headline
-//                    batch lives in the register files of the chip and is never re-read from HBM (k_lbfgs_pre streams it twice
-//                    per accepted step: 55 us of a 101 us round at the headline batch).
+//                    [h E, (h+1) E) of its workgroup's chunk of s_j and y_j - 2 E doubles (E = 56, or 28 on twice the workgroups when the chip
+//                    has room); the history of the headline batch (46 MB) lives in the register files of the chip and is never read from HBM
+//                    (k_lbfgs_pre streams it twice per accepted step).  They form s and y themselves from the point and gradient the leader publishes.
 //   workgroup G-1    DENSE: the m x m factors of the compact L-BFGS representation, resident in LDS (R^-1) and registers (Y^T Y)
-//   workgroups 0..G-2 evaluate the penalty integrand of their share of the pieces (penalty_body)
+//   workgroups 1..G-2 (and the leader, last in line) evaluate the penalty integrand of their share of the pieces (penalty_body)
 //
 // Direction: with the history distributed by ELEMENTS, the two-loop recursion (2 m strictly sequential dot products of length n,
 // lbfgs.hpp:1381-1411) would need 2 m cross-CU reductions.  The same product  d = -H g  is evaluated in the compact form of
@@ -24,13 +26,14 @@
 //       w = R^-1 (S^T g),   v = (D + gamma Y^T Y) w - gamma Y^T g,   u = R^-T v,        R_ij = s_i . y_j (i not newer than j)
 //       d = -gamma g - S u + gamma Y w
 // i.e. one pass over the history for 4 m dot products (S^T g, Y^T g and the new column S^T y_new, Y^T y_new of R and Y^T Y,
-// all from registers), two triangular solves + one mat-vec on the dense workgroup, one pass for the linear combination.
-// In exact arithmetic this IS the two-loop recursion; in FP64 the iterates agree to rounding (tests: plans and per-round traces against the one-launch-per-stage
-// path, whose direction kernel is checked against the host recursion).
+// all from registers), three matrix-vector passes on the dense workgroup, one pass for the linear combination.
+// In exact arithmetic this IS the two-loop recursion; in FP64 every accepted step's direction agrees with a host recursion over the same
+// pairs to 1e-13 (tests/test_gpu_resident.py, both sizes of E).
 //
-// Cross-workgroup data uses write-through stores + L1-bypassing loads ordered by drained flags / counters (ldg / stg in
-// frx_kernels.hpp; MI355X guide, Guideline 16 form R1).  Every spin is bounded: a wait that expires records an error code in
-// `status`, which ends every workgroup of the launch, and the host driver falls back to the one-launch-per-stage path.
+// Cross-workgroup data: (i) write-through stores + L1-bypassing loads ordered by drained flags / counters (ldg / stg in frx_kernels.hpp;
+// MI355X guide, Guideline 16 form R1), (ii) self-validating granules polled by the consumer itself (rk_ll_put below).  Every spin is
+// bounded: a wait that expires records an error code in `status`, which ends every workgroup of the launch, and the host driver reports
+// the failure or falls back to the one-launch-per-stage path.
 #pragma once
 #include <hip/hip_runtime.h>
 
