@@ -972,6 +972,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     { const char *fc = std::getenv("FRX_RESIDENT_FAST_CONTROL"); rl.fast_control = fc && fc[0] == '0' ? 0 : 1; }
     { const char *tr = std::getenv("FRX_RESIDENT_TIMED_READ"); if (tr && tr[0] == '1') rl.fast_control |= 2; }
     { const char *er = std::getenv("FRX_RESIDENT_EARLY_READ"); if (er && er[0] == '0') rl.fast_control |= 4; }
+    { const char *wt = std::getenv("FRX_RESIDENT_WRITE_THROUGH"); if (wt && wt[0] == '1') rl.fast_control |= 8; }   // no cluster trusts its XCD census: write-through stores everywhere (what a cluster spread over XCDs does)
     { const char *sr = std::getenv("FRX_RESIDENT_STAMP_ROUND"); rl.stamp_round = want_prof && sr ? std::max(0, std::atoi(sr)) : 0; }
     rl.ls_ftol = pm.f_dec_coeff; rl.ls_gtol = pm.s_curv_coeff; rl.ls_min_step = pm.min_step; rl.ls_max_step = pm.max_step; rl.ls_xtol = pm.xtol; rl.ls_max_linesearch = pm.max_linesearch;
     {   // What the leader expects of the host (frx_round_kernel.hpp): 0 nothing, it waits for every command; 1 the acceptance of a trial (ADVANCE, next

@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
             rk_fail(a, RK_ERR_CENSUS);
             if (v.wg == 0) __hip_atomic_store(&a.h_res[v.k].seq, ~(rk_u64)0, FRX_RLX_SYS);
         }
-        bool same = ok;
+        bool same = ok && !(a.fast_control & 8);                            // (FRX_RESIDENT_WRITE_THROUGH=1: every cluster takes the cross-XCD form of its hand-offs - tests)
         for (int k = 0; k < a.G; k++) same = same && (__hip_atomic_load(a.xcc + v.k * a.G + k, FRX_RLX_AGENT) & 0xFFu) == my_xcc;
         ctlU[0] = ok ? 1u : 0u;
         ctlU[3] = same ? 1u : 0u;

@@ -256,3 +256,22 @@ def test_size_classes_of_the_kernel_agree(frx, sc, monkeypatch):
     assert a["resident"] == 14 and b["resident"] == 8 and a["device_status"] == 0 and b["device_status"] == 0
     assert np.array_equal(a["status"] >= 0, b["status"] >= 0)
     assert np.abs(a["objective"] / b["objective"] - 1).max() < 5e-3
+
+
+@pytest.mark.parametrize("chunk", [28, 56])
+def test_cross_xcd_form_of_the_hand_offs_gives_the_same_plan(frx, sc, monkeypatch, chunk):
+    """A cluster that finds its workgroups on ONE XCD uses plain stores for what it hands to its neighbours, any other cluster write-through (atomic)
+    stores - including the two words of every granule (rk_ll_put).  On the test box every cluster sits on one XCD, so the other form would never
+    run: FRX_RESIDENT_WRITE_THROUGH=1 makes every cluster take it.  Same arithmetic, other transport: the plans are bit-identical."""
+    cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(3)]
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    monkeypatch.setenv("FRX_RESIDENT_E", str(chunk))
+    out = []
+    for wt in ("0", "1"):
+        monkeypatch.setenv("FRX_RESIDENT_WRITE_THROUGH", wt)
+        prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+        out.append(prob.optimize(tol, max_iterations=1500))
+        prob.close()
+    a, b = out
+    assert a["resident"] > 0 and b["resident"] > 0 and a["device_status"] == 0 and b["device_status"] == 0
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["evals"], b["evals"])
