@@ -117,7 +117,7 @@ struct frx_problem {
     unsigned *tap_arrive = nullptr; volatile unsigned *tap_flag = nullptr; unsigned tap_round = 0;
     DevBuf<unsigned> d_arrive; PinBuf<unsigned> h_flag; DevBuf<int> d_flags, d_pflags;
     // resident round kernel (frx_round_kernel.hpp): cluster exchange buffers and mapped mailboxes, allocated on first use
-    DevBuf<double> d_pubsyg, d_part, d_upub, d_dpub, d_rdbg;
+    DevBuf<double> d_pubsyg, d_part, d_upub, d_dpub, d_rdbg, d_out20ll;
     int dirlog_cap = 0, dirlog_cands = 0, dirlog_nxp = 0;   // direction log of the resident kernel (frx_debug_direction_log): records asked for / row geometry of the last plan
     std::vector<double> dirlog;                             // [B] counts, then dirlog_cands x dirlog_cap records of 4 NXP + 2 doubles
     DevBuf<unsigned long long> d_rprof;                     // FRX_RESIDENT_PROF: [B][G][16] per-segment ticks of the last resident launch
@@ -915,7 +915,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
         if ((e = p->d_pubsyg.alloc((size_t)S * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)S * G * 512)) != hipSuccess ||
             (e = p->d_upub.alloc((size_t)S * 516)) != hipSuccess || (e = p->d_dpub.alloc((size_t)S * 2 * NXP)) != hipSuccess ||
-            (e = p->d_rwords.alloc(n_words)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * S)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * S)) != hipSuccess ||
+            (e = p->d_out20ll.alloc((size_t)p->P * 40)) != hipSuccess || (e = p->d_rwords.alloc(n_words)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * S)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * S)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
@@ -940,6 +940,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     const double timeout_ms = [] { const char *ev = std::getenv("FRX_ROUND_TIMEOUT_MS"); const double v = ev ? std::atof(ev) : 0.0; return v > 0.0 ? v : 5000.0; }();
     // state of this launch: all polled words zero, mailboxes empty
     HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * n_words, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_out20ll.p, 0, sizeof(double) * (size_t)p->P * 40, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_upub.p, 0, sizeof(double) * (size_t)S * 516, p->stream));               // granules of the cluster's hand-offs: tag 0 = nothing yet
     HIP_TRY(hipMemsetAsync(p->d_dpub.p, 0, sizeof(double) * (size_t)S * 2 * NXP, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)S * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
@@ -949,7 +950,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
     frx::RoundLaunch rl;
     rl.x = p->d_x.p; rl.g = p->d_g.p; rl.xp = p->d_xp.p; rl.gp = p->d_gp.p; rl.d = p->d_dir.p; rl.f = p->d_f.p; rl.T = p->d_T.p; rl.C = p->d_C.p; rl.out20 = p->d_out20.p;
-    rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr; rl.dbg_cap = want_dbg ? p->dirlog_cap : 0; rl.dbg_cands = want_dbg ? log_cands : 0;
+    rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.out20ll = std::getenv("FRX_RESIDENT_NO_LL20") ? nullptr : (unsigned long long *)p->d_out20ll.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr; rl.dbg_cap = want_dbg ? p->dirlog_cap : 0; rl.dbg_cands = want_dbg ? log_cands : 0;
     rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.S = S; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;

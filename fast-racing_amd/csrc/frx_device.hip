@@ -111,6 +111,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nrow = g.knot_threads; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax;
     a.pen_lds = g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21;
     a.x = r.x; a.g = r.g; a.xp = r.xp; a.gp = r.gp; a.d = r.d; a.f = r.f; a.T = r.T; a.C = r.C; a.out20 = r.out20; a.pcrw = g.pcrw;
+    a.out20ll = g.knot_threads == 64 ? r.out20ll : nullptr;                                                      // (only the <= 64-piece adjoint polls granules)
     a.pubsyg = r.pubsyg; a.part = r.part; a.upub = r.upub; a.dpub = r.dpub; a.dbg = r.dbg; a.dbg_cap = r.dbg_cap; a.dbg_cands = r.dbg_cands;
     a.phase = r.words; a.cntA = r.words + 32; a.uflag = r.words + 64; a.cntL = r.words + 96;                     // one 512-byte block per candidate, one 128-byte line per word
     if (r.S < 1 || r.S > r.B) return (int)hipErrorInvalidValue;

@@ -60,6 +60,24 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
     else *p = v;
 }
 
+// ---- hand-offs without a flag: self-validating granules (resident round kernel) -----------------------------------------------------------------
+// A double that another workgroup waits for can travel as TWO 8-byte words {low half | tag << 32}, {high half | tag << 32} (the LL form of the
+// collectives libraries): the consumer polls the payload itself and takes a value when both words carry the tag it expects (the number of the
+// phase - never repeated within a launch; the buffers start zeroed).  Each word is one naturally atomic 8-byte access, so nothing is
+// drained, no flag follows, no workgroup meets: one L2 round trip where flag-then-payload (drain, barrier, flag; poll, barrier, payload loads)
+// takes two and a half.  Used where a consumer thread polls a FEW granules (dense -> history workgroups: 2 per thread, history -> leader: 3,
+// penalty partials -> adjoint: 2 or 6); for the partial sums into the dense workgroup (2 x 6..14 per thread) the polling sweeps themselves were
+// the cost and the counter stayed.
+typedef unsigned long long ll_u64;
+__device__ __forceinline__ void rk_ll_put(ll_u64 *slot, double v, unsigned tag, bool wt) {
+    const ll_u64 b = (ll_u64)__double_as_longlong(v), tg = (ll_u64)tag << 32;
+    const ll_u64 w0 = (b & 0xFFFFFFFFull) | tg, w1 = (b >> 32) | tg;
+    if (wt) { __hip_atomic_store(slot, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(slot + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else { slot[0] = w0; slot[1] = w1; }
+}
+__device__ __forceinline__ bool rk_ll_ok(ll_u64 w0, ll_u64 w1, unsigned tag) { return (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag; }
+__device__ __forceinline__ double rk_ll_value(ll_u64 w0, ll_u64 w1) { return __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32))); }
+
 // Operands that a RESIDENT caller (frx_round_kernel.hpp, leader workgroup) keeps in LDS from round to round, so that the evaluation
 // bodies neither stage them from global memory nor send the reduction multipliers through it: xs = the candidate's variables,
 // vs = its waypoint polytopes, dsv = the search direction, pw = [nrow][8 steps + 5] multipliers (only used by the wave-specialised
@@ -68,7 +86,8 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
 // packed layout.  The blocks of consecutive waypoints are 3 nv doubles apart (36 for the 12-vertex overlaps of box corridors: a
 // multiple of 4 - the lanes of a wave, one waypoint per lane pair, then hit 8 of the 32 LDS double-banks, a four-way conflict on
 // every read of the waypoint map and of its adjoint, measured 2.7 k cycles for a 12-vertex pass); one double of skew makes the stride odd.  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
-struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; double *gpub = nullptr; bool gwt = true; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g; gpub (optional, global): and to this array, for the other workgroups of the cluster (write-through unless gwt is false)
+struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; double *gpub = nullptr; bool gwt = true;
+                     const ll_u64 *o20ll = nullptr; unsigned o20tag = 0; unsigned *status = nullptr; ll_u64 spin_ticks = 0; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g; gpub (optional, global): and to this array, for the other workgroups of the cluster (write-through unless gwt is false)
 
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
@@ -297,7 +316,7 @@ __device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const
 }
 // fixed-order reduction over the samples of each piece (lane slots red[lane * 21 ..]): thread = (piece of the group, value)
 template <bool SH>
-__device__ __forceinline__ void penalty_reduce(const double *red, int npieces, int lpp, double *__restrict__ out, int lane, int nthr, bool wt) {
+__device__ __forceinline__ void penalty_reduce(const double *red, int npieces, int lpp, double *__restrict__ out, int lane, int nthr, bool wt, ll_u64 *out_ll = nullptr, unsigned ll_tag = 0) {
     for (int idx = lane; idx < npieces * 20; idx += nthr) {
         const int p2 = idx / 20, v = idx - p2 * 20;
         const double *src = red + (p2 * lpp) * 21 + v;
@@ -316,7 +335,8 @@ __device__ __forceinline__ void penalty_reduce(const double *red, int npieces, i
         }
 #pragma unroll 4
         for (; l < lpp; l++) s += src[l * 21];
-        stg<SH>(out + idx, s, wt);
+        if (SH && out_ll) rk_ll_put(out_ll + 2 * idx, s, ll_tag, wt);      // resident caller: the partials travel as granules that the adjoint polls (no drain, no arrival count in front of it)
+        else stg<SH>(out + idx, s, wt);
     }
 }
 
@@ -329,7 +349,7 @@ __device__ __forceinline__ void penalty_reduce(const double *red, int npieces, i
 template <bool SH, bool LAT = false>
 __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double *__restrict__ T, const double *__restrict__ C,
                                              double *__restrict__ out20, int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, bool wt = true,
-                                             int nthr = 64) {
+                                             int nthr = 64, ll_u64 *out20ll = nullptr, unsigned ll_tag = 0) {
     const int hstride = (Kmax + 1) * 4;
     double *cS = sm;
     double *tS = cS + ppw * 18;
@@ -374,7 +394,7 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     const bool active = pl < npieces && (pfl & DV_EVAL);
     if (active) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, Kmax, red + lane * 21);
     __syncthreads();
-    penalty_reduce<SH>(red, npieces, lpp, out20 + (size_t)gp0 * 20, lane, nthr, wt);
+    penalty_reduce<SH>(red, npieces, lpp, out20 + (size_t)gp0 * 20, lane, nthr, wt, out20ll ? out20ll + (size_t)gp0 * 40 : nullptr, ll_tag);
 }
 // Stage kernels: a workgroup of blockDim.x = 64 W threads owns ppg = floor(64 W / lpp) consecutive pieces (LaunchGeom::pen_w, ::ppg).
 __global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
@@ -1327,8 +1347,9 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         const double *ci = Cin + (size_t)(p0 + kp) * 18;
         const double *o = out20 + (size_t)(p0 + kp) * 20;
         h = ct_lds ? ct_lds[kp * 19 + 18] : ldg<SH>(Tin + p0 + kp);
+        const bool o_ll = SH && ro && ro->o20ll;                             // resident caller: the penalty partials arrive as granules (rk_ll_put in penalty_reduce), polled below
         if (wave == 0) {
-            o0 = ldg<SH>(o); o1 = ldg<SH>(o + 1);
+            if (!o_ll) { o0 = ldg<SH>(o); o1 = ldg<SH>(o + 1); }
             // (the coarse-interval table of mergeToCoarseGradT too: loaded behind the barrier below, these two sat BEHIND the resident
             // caller's read of the host's command word - vmcnt retires in order - and wave 0 waited out a PCIe round trip for them)
             if (kk < cN) { r_iv = dp.coarse_iv[c0 + kk]; r_fb = dp.coarse_fbeg[c0 + kk] - p0; }
@@ -1337,13 +1358,46 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         } else {
             const int ax = wave - 1;
 #pragma unroll
-            for (int q = 0; q < 6; q++) { cbq[q] = ldg<SH>(o + 2 + q * 3 + ax); cq[q] = ct_lds ? ct_lds[kp * 19 + q * 3 + ax] : ldg<SH>(ci + q * 3 + ax); }
+            for (int q = 0; q < 6; q++) { if (!o_ll) cbq[q] = ldg<SH>(o + 2 + q * 3 + ax); cq[q] = ct_lds ? ct_lds[kp * 19 + q * 3 + ax] : ldg<SH>(ci + q * 3 + ax); }
             r_tl[0] = dp.tailPVA[b * 9 + ax]; r_tl[1] = dp.tailPVA[b * 9 + 3 + ax]; r_tl[2] = dp.tailPVA[b * 9 + 6 + ax];
             if ((t2 >> 1) < N - 1) {                                // pair t2 >> 1 = waypoint
                 const int gw = p0 - b + (t2 >> 1);
                 r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw];
                 if (!ro && dp.wq_glob) { const double2 *wq = (const double2 *)(dp.wq_glob + 4 * (size_t)gw); r_wq0 = wq[0]; r_wq1 = wq[1]; }
             }
+        }
+    }
+    if (SH && ro && ro->o20ll) {
+        // Resident caller: the 20 partials of piece kp arrive as granules tagged with the number of this evaluation; lane kk of wave 0 polls {cost, d/dT},
+        // lane kk of an axis wave its six d/dc - the workgroups that integrate the penalty neither drain nor count in front of this read, and the leader
+        // does not wait for them before it calls this body.  Bounded: an expired wait records RK_ERR_ARRIVE (4) in the launch's status word.
+        const ll_u64 *og = ro->o20ll + 40 * (size_t)(p0 + kp);
+        const unsigned tg = ro->o20tag;
+        const ll_u64 t_end = (ll_u64)wall_clock64() + ro->spin_ticks;
+        constexpr int NG = 6;
+        ll_u64 w[NG][2];
+        const int ng = wave == 0 ? 2 : 6, gbase = wave == 0 ? 0 : 2 + (wave - 1), gstep = wave == 0 ? 1 : 3;
+        for (unsigned spins = 0;; spins++) {
+#pragma unroll
+            for (int q = 0; q < NG; q++) {
+                const ll_u64 *g2 = og + 2 * (gbase + gstep * (q < ng ? q : ng - 1));
+                w[q][0] = __hip_atomic_load(g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); w[q][1] = __hip_atomic_load(g2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool all = true;
+#pragma unroll
+            for (int q = 0; q < NG; q++) all = all && rk_ll_ok(w[q][0], w[q][1], tg);
+            if (all) break;
+            if ((spins & 31u) == 31u && (__hip_atomic_load(ro->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || (ll_u64)wall_clock64() > t_end)) {
+                unsigned expect = 0u;
+                __hip_atomic_compare_exchange_strong(ro->status, &expect, 4u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (wave == 0) { o0 = rk_ll_value(w[0][0], w[0][1]); o1 = rk_ll_value(w[1][0], w[1][1]); }
+        else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) cbq[q] = rk_ll_value(w[q][0], w[q][1]);
         }
     }
     if (!ro) {

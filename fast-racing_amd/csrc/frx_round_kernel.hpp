@@ -95,6 +95,7 @@ struct RoundArgs {
     int maxCN, maxXb, maxVb, nrow, nsteps, lpp, ppw, Kmax, pen_lds;   // geometry of the evaluation bodies (LaunchGeom); pen_lds in doubles per wave
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20, *pcrw;           // leader-private vectors + the evaluation's stage buffers
     double *pubsyg;          // [S][3 NXP + 2] leader -> cluster: the point x and its gradient g (first 2 NXP doubles, zero beyond n), then (slot, pair count)
+    ll_u64 *out20ll;         // [P][20] granules: the penalty partials on their way to the leader's adjoint (use_ll, below); null: plain out20 + arrival count
     double *part;            // [S][G][4][128] cluster -> dense: partial dot products
     double *upub;            // [S][257] granules (2 words per value, rk_ll_put)      dense -> cluster: -u, gamma w, gamma
     double *dpub;            // [S][NXP] granules      cluster -> leader: direction chunks
@@ -188,22 +189,6 @@ __device__ __forceinline__ void rk_drain_and_meet() {
     __syncthreads();
 }
 
-// ---- hand-offs without a flag: self-validating granules --------------------------------------------------------------------------------------------
-// A double that another workgroup waits for can travel as TWO 8-byte words {low half | tag << 32}, {high half | tag << 32} (the LL form of the
-// collectives libraries): the consumer polls the payload itself and takes a value when both words carry the tag it expects (the number of the
-// direction phase - never repeated within a launch; the buffers start zeroed).  Each word is one naturally atomic 8-byte access, so nothing is
-// drained, no flag follows, no workgroup meets: one L2 round trip where flag-then-payload (drain, barrier, flag; poll, barrier, payload loads)
-// takes two and a half.  Used where every consumer thread polls a FEW granules (dense -> history workgroups: 2 per thread, history -> leader: 3);
-// for the partial sums into the dense workgroup (2 x 6..14 per thread) the polling sweeps themselves were the cost and the counter stayed.
-__device__ __forceinline__ void rk_ll_put(rk_u64 *slot, double v, unsigned tag, bool wt) {
-    const rk_u64 b = (rk_u64)__double_as_longlong(v), tg = (rk_u64)tag << 32;
-    const rk_u64 w0 = (b & 0xFFFFFFFFull) | tg, w1 = (b >> 32) | tg;
-    if (wt) { __hip_atomic_store(slot, w0, FRX_RLX_AGENT); __hip_atomic_store(slot + 1, w1, FRX_RLX_AGENT); }
-    else { slot[0] = w0; slot[1] = w1; }
-}
-__device__ __forceinline__ bool rk_ll_ok(rk_u64 w0, rk_u64 w1, unsigned tag) { return (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag; }
-__device__ __forceinline__ double rk_ll_value(rk_u64 w0, rk_u64 w1) { return __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32))); }
-
 // ---- pieces shared by the two role loops ----
 struct RoundView {                       // per-workgroup constants; c, n, xbase, p0, N change when the cluster takes another candidate (DV_NEXT)
     int k, c, wg, t, lane, wave, m, n, xbase, p0, N;
@@ -215,7 +200,7 @@ struct RoundView {                       // per-workgroup constants; c, n, xbase
 
 // penalty share of workgroup `pw` (0..G-2) in a CT phase
 template <bool PROF>
-__device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const RoundView &v, double *ev, int pw) {
+__device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const RoundView &v, double *ev, int pw, unsigned ct_tag) {
     // Wave-tasks go to the history workgroups (pw = 1 .. G-2) first and to the leader (pw = 0) last: at the headline geometry 22 tasks meet 24
     // member waves and the leader takes none - its wave 0 is the one whose thread 0 waits for the PCIe acknowledgements of a deferred result post
     // (~1.5 us on three rounds out of four) and then had its own three pieces still to do, which made it the last wave of the cluster to finish.
@@ -225,7 +210,7 @@ __device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const Round
         if (base + rank * 4 >= ntasks) break;                               // nothing for this workgroup in this pass (workgroup-uniform: no barrier is skipped by a part of it)
         const int task = base + rank * 4 + v.wave;
         const int np = task < ntasks ? min(a.ppw, v.N - task * a.ppw) : 0;
-        penalty_body<true, true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, v.p0 + task * a.ppw, np, ev + (size_t)v.wave * a.pen_lds, v.lane, v.wt);   // latency form: a wave has its SIMD to itself
+        penalty_body<true, true>(a.dp, a.T, a.C, a.out20, a.lpp, a.ppw, a.Kmax, v.p0 + task * a.ppw, np, ev + (size_t)v.wave * a.pen_lds, v.lane, v.wt, 64, a.out20ll, ct_tag);   // latency form: a wave has its SIMD to itself
         __syncthreads();
     }
 }
@@ -273,6 +258,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     // their drain (1.5-2 us) between the end of the adjoint and the phase word of every accepted step.
     unsigned nadv_l = 0;                                                    // accepted steps so far (index into the direction log)
     unsigned nadv_tag = 0;                                                  // direction phases of this LAUNCH so far = the tag of the granules the cluster sends back (never reset)
+    unsigned nct_tag = 0;                                                   // evaluation phases of this launch so far = the tag of the penalty partials' granules (a.out20ll)
     bool trial_done = false, dg_pending = false;
     // The cluster needs nothing of the leader's own bookkeeping of an accepted step (xp = x, gp = g in its LDS) to start on the new direction -
     // the point and its gradient are in `pub` already - so the phase word leaves first and the copies run while the members work (round 4:
@@ -462,16 +448,17 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
         if (accept_pending) { accept_step(); accept_pending = false; }      // (the gather below reads gp behind the arrival barrier)
         RK_PROF(RK_P_PUBLISH);
         if (__builtin_expect(kind == PH_QUIT, 0)) { leave = true; break; }
-        if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, 0); RK_PROF(RK_P_PENALTY); }
+        if (kind == PH_CT) { nct_tag++; rk_penalty_share<PROF>(a, v, ev, 0, nct_tag); RK_PROF(RK_P_PENALTY); }
         // ---- the phase is complete when every workgroup of the cluster has reported ----
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
         RK_TR(37);
         nphase++;
         // (A direction phase is not waited for here: the direction arrives as granules that the gather below polls, and the arrivals of this phase are
-        // part of the count the NEXT phase waits for.)
+        // part of the count the next phase that DOES wait asks for.  The same holds for an evaluation phase whose penalty partials travel as granules
+        // - a.out20ll, the <= 64-piece geometry: the adjoint polls them itself.)
         bool ok = true;
-        if (kind != PH_ADV) {
+        if (kind != PH_ADV && !(kind == PH_CT && a.out20ll != nullptr)) {
             if (t == 0) { const bool okw = rk_wait_eq(a.cntL + k * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!okw) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = okw ? 1u : 0u; }
             __syncthreads();
             ok = ctlU[0] != 0u;
@@ -541,6 +528,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
             if (dg_pending) { if (t == 0) ctlD[4] = (pair[0] + pair[1]) + (pair[2] + pair[3]); dg_pending = false; }   // gp . d of this round's ADVANCE (read behind the adjoint's barrier)
             LineSearchTap tap{a.d, nullptr, nullptr, nullptr, nullptr, 0u, ctlD};
             if (unconfirmed && !(a.fast_control & 4)) tap.early_cmd = &a.h_cmd[k * a.cmd_stride].word;   // the host's command for a predicted round: thread 0 reads it while the adjoint runs (ctlD[7], ctlD[6])
+            ro.o20ll = a.out20ll; ro.o20tag = nct_tag; ro.status = a.status; ro.spin_ticks = a.timeout_ticks;
             backward_knot_body<true, NR>(a.dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, tap, c, ev, ctl, &ro);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // gradient and line-search sums are in LDS; the gradient's copy in `pub` drains before the next phase word
             RK_PROF(RK_P_BACKWARD);
@@ -710,7 +698,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
     double Sreg[E], Yreg[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
-    unsigned pseq = 0, nadv = 0;
+    unsigned pseq = 0, nadv = 0, nct = 0;                                   // phases seen; direction phases and evaluation phases among them (the tags of this cluster's granules)
     int jnew = 0, bound = 0;
     for (;;) {
         if (t == 0) {
@@ -857,7 +845,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             }
             RK_PROF(RK_P_PASS_B);
         }
-        if (kind == PH_CT) { rk_penalty_share<PROF>(a, v, ev, wg); RK_PROF(RK_P_PENALTY); }
+        if (kind == PH_CT) { nct++; rk_penalty_share<PROF>(a, v, ev, wg, nct); RK_PROF(RK_P_PENALTY); }
         // ---- report the end of this workgroup's part of the phase to the leader ----
         rk_drain_and_meet();
         if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
