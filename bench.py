@@ -450,7 +450,10 @@ def main():
                     bj = json.loads(open(bp).read().split("\n{\"per_stage")[0])
                     tot = bj["leader"]["total"]
                     round_obj["budget"] = {"from_profile": True, "source": "profiles/" + name, "instrumented_us_per_round": bj["us_per_round_wall"],
-                                           "leader_us": bj["leader"], "leader_idle_frac": (bj["leader"].get("wait_arrive", 0.0) + bj["leader"].get("wait_host", 0.0)) / tot,
+                                           "leader_us": bj["leader"], "leader_keys": bj.get("what the keys mean for the leader"),
+                                           # (since the direction and the penalty partials arrive as granules the leader's waits for the cluster are inside `gather` and `backward`:
+                                           # idle = those two minus the gather's own ~1.0 us and the adjoint's ~5.4 us is not separable here - scripts/r04/round_gaps.py has the timeline)
+                                           "leader_idle_frac": (bj["leader"].get("wait_arrive", 0.0) + bj["leader"].get("wait_host", 0.0)) / tot,
                                            "member_idle_frac": (bj["member1"].get("wait_phase", 0.0) + bj["member1"].get("wait_u", 0.0)) / bj["member1"]["total"],
                                            "dense_idle_frac": (bj["dense"].get("wait_phase", 0.0) + bj["dense"].get("wait_part", 0.0)) / bj["dense"]["total"]}
                 except Exception as e:                                   # a malformed profile must not cost the bench line

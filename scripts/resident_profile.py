@@ -21,6 +21,14 @@ pr = prob.resident_profile()
 rounds = int(r["evals"][0])
 G = pr.shape[1]
 out = {"B": B, "N": N, "kappa": kappa, "G": G, "rounds_cand0": rounds, "iters_cand0": int(r["iters"][0]), "plan_ms": r["ms_total"], "us_per_round_wall": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
+# the three roles re-use the 16 accumulators; the keys keep the history workgroups' names, these say what a key means in the other two loops
+out["what the keys mean for the leader"] = {"wait_host": "waiting for a command that was not predicted", "vectors": "trial point (when the gather has not formed it) + barrier",
+    "forward": "forward map", "dense_in": "command decoded / accepted step taken over", "solve": "drain + meeting in front of a phase word", "publish": "phase word, deferred result post, accept copies",
+    "penalty": "own penalty share (none at the headline geometry)", "wait_arrive": "arrival count (only phases that wait: INIT / NEXT / QUIT, or every phase without granules)",
+    "gather": "waiting for the direction granules + gather + first trial point", "backward": "waiting for the penalty partials' granules + adjoint",
+    "pass_a": "confirmation of the command this round ran on", "wait_part": "prediction of the next command", "post": "result post"}
+out["what the keys mean for the dense workgroup"] = {"wait_phase": "idle", "wait_part": "waiting for the partial sums", "dense_in": "gather of the partial sums", "pass_a": "pass 1",
+    "forward": "new column + pass 2", "pass_b": "pass 3", "solve": "granules out", "vectors": "Y^T Y update (off the critical path)"}
 for name, wg in (("leader", 0), ("member1", 1), ("dense", G - 1)):
     out[name] = {SEG[i]: round(float(pr[0, wg, i]) / rounds, 2) for i in range(16) if pr[0, wg, i] > 0}
     out[name]["total"] = round(float(pr[0, wg].sum()) / rounds, 2)
