@@ -37,7 +37,7 @@ for p in sorted(mem[32]):                                      # phases in which
         m = {"adj_end(prev)": lead[13][p - 1], "confirmed": lead[4][p - 1], "predicted": lead[5][p - 1], "member sees ADV": mem[3][p], "chunk loaded": mem[32][p], "dots done": mem[33][p], "partials out": mem[4][p],
              "dense has all": den[5][p], "dense gathered": den[6][p], "pass1": den[4][p], "pass2": den[2][p], "pass3": den[9][p], "u,w granules out": den[7][p], "member has its coefficients": mem[8][p],
              "products": mem[34][p], "colsums": mem[35][p], "direction granules out": mem[9][p], "leader has direction + trial point": lead[12][p], "forward starts": lead[1][p],
-             "forward done": lead[2][p], "drained": lead[7][p], "member sees CT": mem[3][q], "penalty done": mem[10][q], "member cntL (CT)": mem[36][q], "leader arrived (CT)": lead[11][q], "adj_end": lead[13][q]}
+             "forward done": lead[2][p], "drained": lead[7][p], "member sees CT": mem[3][q], "penalty done": mem[10][q], "adj_end (partials polled + adjoint)": lead[13][q]}
     except KeyError:
         continue
     rows.append(m)
