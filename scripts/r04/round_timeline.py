@@ -11,9 +11,9 @@ SEG = ["wait_host", "vectors", "forward", "wait_phase", "pass_a", "wait_part", "
 EXTRA = {32: "chunk_loaded", 33: "dots_done", 34: "products_in_lds", 35: "column_sums_done", 36: "cntL_added", 37: "leader_cntL_added", 40: "loop top", 41: "before the barrier in front of the forward map"}
 # what a segment id means at the END of which the event is logged, per role (the macro is shared)
 LEADER = {0: "command ready", 1: "trial point formed", 2: "forward map done", 6: "command decoded", 7: "stores drained + met", 15: "phase word out (+ deferred post, accept copies)", 10: "own penalty share done",
-          11: "cluster arrived", 12: "direction gathered + trial point", 13: "adjoint done", 4: "command confirmed", 5: "next command predicted", 14: "result posted / round closed"}
-MEMBER = {3: "phase word seen", 4: "pass A: partials out, cntA added", 8: "u, w flag seen", 9: "pass B: direction chunk stored", 10: "penalty share done"}
-DENSE = {3: "phase word seen", 5: "all partials in (cntA)", 6: "partials gathered", 4: "pass 1 done", 2: "column + pass 2 done", 9: "pass 3 done", 7: "u, w published (flag)", 1: "YtY updated"}
+          11: "arrival wait over (a no-op in direction / evaluation phases whose data come as granules)", 12: "direction granules polled + gathered + trial point", 13: "penalty partials polled + adjoint done", 4: "command confirmed", 5: "next command predicted", 14: "result posted / round closed"}
+MEMBER = {3: "phase word seen", 4: "pass A: partials out, cntA added", 8: "own coefficients (-u, gamma w) polled", 9: "pass B: direction granules stored", 10: "penalty share done"}
+DENSE = {3: "phase word seen", 5: "all partials in (cntA)", 6: "partials gathered", 4: "pass 1 done", 2: "column + pass 2 done", 9: "pass 3 done", 7: "-u, gamma w granules stored", 1: "YtY updated"}
 cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(B)]
 prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
 x0 = prob.initial_guess()
