@@ -275,3 +275,29 @@ def test_cross_xcd_form_of_the_hand_offs_gives_the_same_plan(frx, sc, monkeypatc
     a, b = out
     assert a["resident"] > 0 and b["resident"] > 0 and a["device_status"] == 0 and b["device_status"] == 0
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["evals"], b["evals"])
+
+
+def test_more_than_64_pieces_take_the_per_stage_rounds(frx, sc):
+    """The leader keeps the candidate's (C, T), x, polytopes, direction and reduction multipliers in LDS; with the 128-row knot arrays of 65 ... 128
+    pieces that does not fit the CU's 160 KB, so such plans run as per-stage rounds (resident == 0) - silently, with the same result as with the
+    resident kernel switched off.  (Should a geometry of that class ever fit, the generic instantiation of the round kernel takes it and the
+    scalars crossing the mailbox must equal the per-stage path's, as for the small geometries.)"""
+    cands = sc.make_batch(13, 1, 100, 20)
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=8)
+    x0 = prob.initial_guess()
+    a = _plan(prob, 1e-6, True, trace=True, x0=x0, max_iterations=30)
+    b = _plan(prob, 1e-6, False, trace=True, x0=x0, max_iterations=30)
+    assert b["resident"] == 0 and a["device_status"] == 0
+    if a["resident"] == 0:
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["evals"], b["evals"])
+    else:
+        ta, tb = a["trace"], b["trace"]
+        rows = min(len(ta), len(tb), 30)
+        assert rows >= 10
+        for i in range(rows):
+            fa, fb = ta[i], tb[i]
+            assert int(fa[0]) == int(fb[0]), f"command {i}: flags {fa[0]} vs {fb[0]}"
+            errs = [abs(fa[1] - fb[1]) / max(abs(fb[1]), 1e-300), abs(fa[2] - fb[2]) / abs(fb[2]), abs(fa[5] - fb[5]) / max(fb[5], 1e-300), abs(fa[6] - fb[6]) / max(fb[6], 1e-300)]
+            assert max(errs) < 1e-8, f"command {i}: {errs}"
+        assert np.abs(a["x"] - b["x"]).max() <= 1e-5 * np.abs(b["x"]).max()
+    prob.close()
