@@ -914,7 +914,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         p->rk_B = 0;
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
         if ((e = p->d_pubsyg.alloc((size_t)S * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)S * G * 512)) != hipSuccess ||
-            (e = p->d_upub.alloc((size_t)S * 516)) != hipSuccess || (e = p->d_dpub.alloc((size_t)S * 2 * NXP)) != hipSuccess ||
+            (e = p->d_upub.alloc((size_t)S * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)S * 2 * NXP)) != hipSuccess ||
             (e = p->d_out20ll.alloc((size_t)p->P * 40)) != hipSuccess || (e = p->d_rwords.alloc(n_words)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * S)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * S)) != hipSuccess ||
             (e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess) {
             (void)hipGetLastError();
@@ -941,8 +941,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     // state of this launch: all polled words zero, mailboxes empty
     HIP_TRY(hipMemsetAsync(p->d_rwords.p, 0, sizeof(unsigned) * n_words, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_out20ll.p, 0, sizeof(double) * (size_t)p->P * 40, p->stream));
-    HIP_TRY(hipMemsetAsync(p->d_upub.p, 0, sizeof(double) * (size_t)S * 516, p->stream));               // granules of the cluster's hand-offs: tag 0 = nothing yet
-    HIP_TRY(hipMemsetAsync(p->d_dpub.p, 0, sizeof(double) * (size_t)S * 2 * NXP, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_dpub.p, 0, sizeof(double) * (size_t)S * 2 * NXP, p->stream));           // granules of the cluster's hand-offs: tag 0 = nothing yet
     HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)S * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
     std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * S);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * S);

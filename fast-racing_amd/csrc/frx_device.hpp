@@ -85,7 +85,7 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 struct RoundLaunch {
     double *x, *g, *xp, *gp, *d, *f, *T, *C, *out20;              // leader vectors and stage buffers (the handle's own)
     unsigned long long *out20ll = nullptr;                         // [P][20] granules (2 words per value): the penalty partials' way to the adjoint when every candidate has <= 64 pieces; null: out20 + arrival count
-    double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([S][3 NXP + 2], [S][G][512], [S][257] granules, [S][NXP] granules)
+    double *pubsyg, *part, *upub, *dpub, *dbg;                     // cluster exchange buffers ([S][3 NXP + 2], [S][G][512], [S][258], [S][NXP] granules)
     unsigned *words;                                               // [ROUND_WORDS_PER_CAND S + 2 + S G + 4 B]: a 512-byte block per cluster (phase, cntA, uflag, cntL in separate lines), then census, status, XCC ids, prediction counters per candidate
     void *h_cmd, *h_res;                                           // mapped host mailboxes, [S] x 16 B (x cmd_stride) and [S] x 64 B
     unsigned long long timeout_ticks;

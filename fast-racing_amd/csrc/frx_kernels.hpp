@@ -65,9 +65,9 @@ template <bool SH> __device__ __forceinline__ void stg(double *p, double v, bool
 // collectives libraries): the consumer polls the payload itself and takes a value when both words carry the tag it expects (the number of the
 // phase - never repeated within a launch; the buffers start zeroed).  Each word is one naturally atomic 8-byte access, so nothing is
 // drained, no flag follows, no workgroup meets: one L2 round trip where flag-then-payload (drain, barrier, flag; poll, barrier, payload loads)
-// takes two and a half.  Used where a consumer thread polls a FEW granules (dense -> history workgroups: 2 per thread, history -> leader: 3,
-// penalty partials -> adjoint: 2 or 6); for the partial sums into the dense workgroup (2 x 6..14 per thread) the polling sweeps themselves were
-// the cost and the counter stayed.
+// takes two and a half.  Used where ONE workgroup is the consumer and each of its threads polls a few granules (history -> leader: 3 per thread, penalty
+// partials -> adjoint: 2 or 6).  Where many workgroups would poll (the dense result: every thread of 6-12 history workgroups) or a thread many granules
+// (partial sums into the dense workgroup: 2 x 6..14), the polls cost more than the flag - measured - and the drained flag / counter stayed.
 typedef unsigned long long ll_u64;
 __device__ __forceinline__ void rk_ll_put(ll_u64 *slot, double v, unsigned tag, bool wt) {
     const ll_u64 b = (ll_u64)__double_as_longlong(v), tg = (ll_u64)tag << 32;

@@ -97,7 +97,7 @@ struct RoundArgs {
     double *pubsyg;          // [S][3 NXP + 2] leader -> cluster: the point x and its gradient g (first 2 NXP doubles, zero beyond n), then (slot, pair count)
     ll_u64 *out20ll;         // [P][20] granules: the penalty partials on their way to the leader's adjoint (use_ll, below); null: plain out20 + arrival count
     double *part;            // [S][G][4][128] cluster -> dense: partial dot products
-    double *upub;            // [S][257] granules (2 words per value, rk_ll_put)      dense -> cluster: -u, gamma w, gamma
+    double *upub;            // [S][258]      dense -> cluster: -u, gamma w, gamma
     double *dpub;            // [S][NXP] granules      cluster -> leader: direction chunks
     unsigned *phase, *cntA, *uflag, *cntL;   // word k * RK_WSTRIDE of each (k: cluster) (zeroed before every launch); the four bases are 32 words apart
     unsigned *census, *status;               // [1] each (zeroed before every launch)
@@ -785,21 +785,10 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             RK_PROF(RK_P_PASS_A);
             // -- 5. linear combination d = -gamma g - S u + gamma Y w over this workgroup's elements --
             double coefS, coefY;
-            {   // every thread polls the two coefficients of ITS slot (and thread 0 gamma) until they carry this phase's tag
-                const rk_u64 *us = (const rk_u64 *)upub + 2 * slot, *ys = (const rk_u64 *)upub + 2 * (128 + slot), *gs = (const rk_u64 *)upub + 2 * 256;
-                const rk_u64 dl = wall_clock64() + a.timeout_ticks;
-                rk_u64 u0, u1, y0, y1, g0 = 0, g1 = 0;
-                for (unsigned spins = 0;; spins++) {
-                    u0 = __hip_atomic_load(us, FRX_RLX_AGENT); u1 = __hip_atomic_load(us + 1, FRX_RLX_AGENT);
-                    y0 = __hip_atomic_load(ys, FRX_RLX_AGENT); y1 = __hip_atomic_load(ys + 1, FRX_RLX_AGENT);
-                    if (t == 0) { g0 = __hip_atomic_load(gs, FRX_RLX_AGENT); g1 = __hip_atomic_load(gs + 1, FRX_RLX_AGENT); }
-                    if (rk_ll_ok(u0, u1, nadv) && rk_ll_ok(y0, y1, nadv) && (t != 0 || rk_ll_ok(g0, g1, nadv))) break;
-                    if ((spins & 31u) == 31u && rk_expired(a, dl)) { rk_fail(a, RK_ERR_UFLAG); break; }
-                    RK_PAUSE(a);
-                }
-                coefS = rk_ll_value(u0, u1); coefY = rk_ll_value(y0, y1);
-                if (t == 0) ctlD[6] = rk_ll_value(g0, g1);                  // (read behind the barriers of the products below)
-            }
+            if (t == 0) { const bool ok = rk_wait_eq(a.uflag + k * RK_WSTRIDE, nadv, a); if (!ok) rk_fail(a, RK_ERR_UFLAG); }
+            __syncthreads();
+            coefS = ldg<true>(upub + slot); coefY = ldg<true>(upub + 128 + slot);
+            if (t == 0) ctlD[6] = ldg<true>(upub + 256);
             RK_PROF(RK_P_WAIT_U);
             {
                 if (!valid) { coefS = 0.0; coefY = 0.0; }                   // a slot without a pair holds zeros or a finished plan's (finite) pair: 0 s + 0 y = 0, no select per element
@@ -1033,11 +1022,15 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
             }
             __syncthreads();
             RK_PROF(RK_P_PASS_B);                                           // (dense workgroup: pass 3)
-            if (t < 128) {                                                  // granules: every history thread polls its own two (rk_ll_put) - no drain, no flag
-                rk_ll_put((rk_u64 *)upub + 2 * t, -(mz[t] + mz[128 + t]), nadv, wt);
-                rk_ll_put((rk_u64 *)upub + 2 * (128 + t), gamma * vw[t], nadv, wt);
+            // (Round 4 tried this hand-off as granules polled by every history thread: no faster at 32 candidates, 0.25 us per round slower with twelve history
+            // workgroups per cluster - 3072 polling threads instead of 12; the flag stayed.  profiles/NOTES.md)
+            if (t < 128) {
+                stg<true>(upub + t, -(mz[t] + mz[128 + t]), wt);
+                stg<true>(upub + 128 + t, gamma * vw[t], wt);
             }
-            if (t == 128) rk_ll_put((rk_u64 *)upub + 2 * 256, gamma, nadv, wt);
+            if (t == 128) stg<true>(upub + 256, gamma, wt);
+            rk_drain_and_meet();
+            if (t == 0) __hip_atomic_store(a.uflag + k * RK_WSTRIDE, nadv, FRX_RLX_AGENT);
             RK_PROF(RK_P_SOLVE);
             {   // Y^T Y: row and column jnew (zero where there is no pair: the partial sums are) - behind the publication
                 const int uj = jnew - q0;
@@ -1078,7 +1071,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
     v.xbase = a.dp.xoff[v.c]; v.n = a.dp.xoff[v.c + 1] - v.xbase;
     v.p0 = a.dp.poff[v.c]; v.N = a.dp.poff[v.c + 1] - v.p0;
-    v.pub = a.pubsyg + (size_t)v.k * (3 * a.NXP + 2); v.part = a.part + (size_t)v.k * a.G * 512; v.upub = a.upub + (size_t)v.k * 516; v.dpub = a.dpub + (size_t)v.k * 2 * a.NXP;
+    v.pub = a.pubsyg + (size_t)v.k * (3 * a.NXP + 2); v.part = a.part + (size_t)v.k * a.G * 512; v.upub = a.upub + (size_t)v.k * 258; v.dpub = a.dpub + (size_t)v.k * 2 * a.NXP;
     // ---- census: every workgroup of the launch must be resident before anybody waits for anybody ----
     if (v.t == 0) {
         unsigned my_xcc = 0;
