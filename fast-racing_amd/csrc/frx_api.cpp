@@ -1049,7 +1049,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     // Mailbox service: thread tid serves the clusters [S tid / nsrv, S (tid + 1) / nsrv) (the caller is thread 0).  The clusters of a batch
     // run in near lock-step, so their results arrive together and a thread's k-th mailbox waits for the k - 1 before it.
-    int nsrv = std::max(1, std::min(8, S / 4));                                       // four clusters per thread (see Slot above)
+    // Sixteen clusters per thread, at most four threads (round 4; four per thread, at most eight, until then): 1, 2, 4 and 8 threads measure the same round
+    // (25.2-25.4 us at 32 clusters, profiles/r04_host_threads.txt) - a scan of 16 mailboxes and the line-search step of those that answered take a few
+    // microseconds of a 25 us round - and every one of them SPINS for the length of the plan: under a CPU quota (the GPU boxes of this project run the
+    // process with 16 CPUs' worth) eight ranks of a node with nine spinning threads each are throttled to a crawl, eight ranks with two are not.
+    int nsrv = std::max(1, std::min(4, S / 16));
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), S));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     const int scan_pause = [] { const char *e = std::getenv("FRX_RESIDENT_SCAN_PAUSE"); return e ? std::max(0, std::atoi(e)) : 0; }();   // extra pauses between two scans of a thread's mailboxes (experiments)
