@@ -43,6 +43,16 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
     cores = os.cpu_count() or 1
+    # CPUs this process may actually use: the GPU boxes run it under a cgroup quota (cpu.max "1600000 100000" = 16 CPUs' worth on a 256-CPU node) - more
+    # threads than that are throttled, so the baseline's `cores` is min(threads, quota), not the thread count
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max": quota = float(q) / float(per)
+    except Exception:
+        pass
+    try: affinity = len(os.sched_getaffinity(0))
+    except Exception: affinity = cores
     workers = min(cores, len(cands), 32)                # (bounded: the GPU boxes' 256 logical cores are shared, and a 512-candidate share must not turn the baseline into minutes)
     cands = cands[:workers]                            # one candidate per thread
     oracles = [ob.Oracle(c, params, qd_intervals=kappa) for c in cands]
@@ -84,9 +94,10 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     cpu_baseline.plans = rs; cpu_baseline.plans_other_rounding = rs2          # for main(): coefficient spread against the device's plans of the SAME candidates
     nb = len(batch)
     return {
-        "value": samples / dt, "unit": "constraint-samples/s", "cores": workers, "node_cores": cores, "threads": workers, "kind": "port",
+        "value": samples / dt, "unit": "constraint-samples/s", "cores": int(max(1, min(workers, affinity, quota if quota else workers))), "node_cores": cores, "threads": workers,
+        "cpu_quota": quota, "cpu_affinity": affinity, "kind": "port",
         "sample": f"{done} objective evaluations (x->f,grad) of {len(cands)} candidates of the workload at the bench state, "
-                  f"{workers} threads on a node with {cores} logical cores, oracle built -O3 -march=x86-64-v3 -ffp-contract=off",
+                  f"{workers} threads on a node with {cores} logical cores (cgroup quota: {quota if quota else 'none'} CPUs), oracle built -O3 -march=x86-64-v3 -ffp-contract=off",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
         "plan_ms_one_candidate_1thread": plan_ms, "plan_evals": int(r["evals"]), "plan_iters": int(r["iters"]),
         # (the CPU leg plans at most 32 candidates, one per thread, whatever the GPU batch is: the field says how many, and the rate is per candidate)
