@@ -301,3 +301,19 @@ def test_more_than_64_pieces_take_the_per_stage_rounds(frx, sc):
             assert max(errs) < 1e-8, f"command {i}: {errs}"
         assert np.abs(a["x"] - b["x"]).max() <= 1e-5 * np.abs(b["x"]).max()
     prob.close()
+
+
+def test_penalty_partials_as_granules_or_through_the_plain_array(frx, sc, monkeypatch):
+    """The penalty partials reach the adjoint as granules that its lanes poll (<= 64 pieces) or - FRX_RESIDENT_NO_LL20=1, and the form every larger
+    geometry would take - through the plain array behind the arrival count.  Other transport, same values: bit-identical plans."""
+    cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(3)]
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    out = []
+    for plain in (None, "1"):
+        if plain: monkeypatch.setenv("FRX_RESIDENT_NO_LL20", plain)
+        prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+        out.append(prob.optimize(tol, max_iterations=1500))
+        prob.close()
+    a, b = out
+    assert a["resident"] > 0 and b["resident"] > 0 and a["device_status"] == 0 and b["device_status"] == 0
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["evals"], b["evals"])
