@@ -25,7 +25,9 @@ def _plan(prob, tol, resident, trace=False, **kw):
     return r
 
 
-@pytest.mark.parametrize("B,N,gates,kappa", [(3, 32, 8, 8), (1, 64, 16, 16), (2, 40, 10, 12)])
+# (the last geometry: 17 candidates = eight workgroups per cluster, one piece per wave-task at kappa = 32 - 64 tasks in three passes over the cluster's 28
+# waves, the LEADER's included: its waves write their partials' granules and then poll them like everybody else's)
+@pytest.mark.parametrize("B,N,gates,kappa", [(3, 32, 8, 8), (1, 64, 16, 16), (2, 40, 10, 12), (17, 64, 16, 32)])
 def test_resident_rounds_equal_per_stage_rounds(frx, sc, B, N, gates, kappa):
     cands = sc.make_batch(11, B, N, gates)
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
