@@ -96,6 +96,8 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     return {
         "value": samples / dt, "unit": "constraint-samples/s", "cores": int(max(1, min(workers, affinity, quota if quota else workers))), "node_cores": cores, "threads": workers,
         "cpu_quota": quota, "cpu_affinity": affinity, "kind": "port",
+        "note": "port = the CPU restatement of the reference path (oracle/, pinned to the reference's own sources compiled here); the reference itself is NOT timed: "
+                "it only compiles against oracle/eigen_shim (eager, index-order stand-in for Eigen) and is 41x slower per evaluation in that form (8091 vs 195 us) - not a fair baseline",
         "sample": f"{done} objective evaluations (x->f,grad) of {len(cands)} candidates of the workload at the bench state, "
                   f"{workers} threads on a node with {cores} logical cores (cgroup quota: {quota if quota else 'none'} CPUs), oracle built -O3 -march=x86-64-v3 -ffp-contract=off",
         "us_per_eval_per_candidate_1thread": per_eval * 1e6,
@@ -150,7 +152,7 @@ def main():
         if world > 1 and not lib_mode:
             dist.init_process_group(backend="gloo"); dist.barrier()
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "front_end": args.multi, "self_launched": os.environ.get("TORCHELASTIC_RUN_ID") is not None or world == 1}), flush=True)
+            print(json.dumps({"launch_check": True, "n_gpus": world, "front_end": args.multi, "self_launched": os.environ.get("FRX_BENCH_SELF_LAUNCHED") == "1" or world == 1}), flush=True)
         if world > 1 and not lib_mode:
             dist.barrier(); dist.destroy_process_group()
         return
@@ -214,23 +216,80 @@ def main():
         for pr, xd, fd, gd, st_r in lib_shards:
             pr.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), st_r.cuda_stream)
 
+    # The K timed steps are bracketed by barrier + synchronize on both sides (host wall clock of the bracket: `ms_per_step_host_wall`) and timed INSIDE the
+    # bracket with HIP events recorded on the launch stream(s) - first launch to last kernel end (at K = 20 the bracket is 0.45 ms and
+    # the closing synchronize + barrier, ~40 us of host work, was 10 % of it).  `value` and `ms_per_step` are the event figure, MAX over ranks and streams.
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
+    for _pr, _xd, _fd, _gd, st_r in lib_shards:
+        with torch.cuda.device(st_r.device): ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+    main_stream = torch.cuda.current_stream()
+
+    def record(which):
+        ev[0][which].record(main_stream)
+        for i, sh in enumerate(lib_shards): ev[1 + i][which].record(sh[4])
+
     for _ in range(args.warmup):
         step()
     sync_all()
     if dist: dist.barrier()
     sync_all()
     t0 = time.perf_counter()
+    record(0)
     for _ in range(args.steps):
         step()
+    record(1)
     sync_all()
     if dist: dist.barrier()
     sync_all()
-    dt = time.perf_counter() - t0
+    dt_wall = time.perf_counter() - t0
+    dt = max(a.elapsed_time(b) for a, b in ev) * 1e-3
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_wall = float(t[0].item()), float(t[1].item())
     samples_per_step = prob.samples()
+
+    # ---- the job's plan: every rank plans its own 32 candidates at the same time, then the only exchange of the whole job (winner selection) ----
+    # Everything that only rank 0 does (stage-kernel times, the per-stage and one-candidate plans, the CPU baseline, ...) runs AFTER the process group is
+    # gone: ranks 1 .. N-1 used to sit in a collective - a spinning host thread each, under the boxes' quota of 16 CPUs - while
+    # rank 0 ran those legs.
+    r = None
+    if not args.no_plan:
+        if dist: dist.barrier()
+        # setup-equivalent host work (SE3GCOPTER::setup incl. H->V enumeration, CPU.hpp:1076-1186, and the first half of optimize:
+        # setInitial/backwardT/backwardP, CPU.hpp:1237-1240), timed on a second handle built from the H-polytopes alone
+        packed = frx.pack_batch(cands)                                     # (the harness' own repacking of the Python candidates is not set-up work of the library)
+        # twice: the first from-H handle of a process may also create the library's sleeping setup pool (threads: ~5 ms, once per process - it is warm already
+        # when an earlier leg of this run used it); the second is what every further plan of a planner process pays
+        t_s = time.perf_counter()
+        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True, packed=packed)
+        t_setup_first = (time.perf_counter() - t_s) * 1e3
+        p2.close()
+        t_s = time.perf_counter()
+        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True, packed=packed)
+        t_setup = (time.perf_counter() - t_s) * 1e3
+        t_s = time.perf_counter()
+        p2.initial_guess()
+        t_guess = (time.perf_counter() - t_s) * 1e3
+        p2.close()
+        r = prob.optimize(params["opt_rel_tol"], x0=x0)
+        if dist:                                                         # the job's plan time is the slowest rank's
+            tm = torch.tensor([r["ms_total"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            r["ms_total"] = float(tm.item())
+        # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
+        from fast_racing_amd.dist import select_winner
+        ids = np.arange(rank * B, rank * B + B)
+        gid, obj, owner, wc, wT = select_winner(
+            dist, torch.device("cuda", local_rank), r["objective"], ids,
+            lambda i: r["C"][6 * prob.piece_off[i]:6 * prob.piece_off[i + 1]], lambda i: r["T"][prob.piece_off[i]:prob.piece_off[i + 1]], N, local_status=r["status"])
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+    if rank != 0:
+        prob.close()
+        return
 
     # the three stage kernels one at a time (HIP events on the library's launch stream, frx_eval_stage_times): the roofline object is
     # reported for the penalty integrator (the kernel SURVEY.md 8d prices); the two knot kernels get sub-objects with their implementation traffic
@@ -328,24 +387,6 @@ def main():
 
     plan = {}
     if not args.no_plan:
-        if dist: dist.barrier()
-        # setup-equivalent host work (SE3GCOPTER::setup incl. H->V enumeration, CPU.hpp:1076-1186, and the first half of optimize:
-        # setInitial/backwardT/backwardP, CPU.hpp:1237-1240), timed on a second handle built from the H-polytopes alone
-        packed = frx.pack_batch(cands)                                     # (the harness' own repacking of the Python candidates is not set-up work of the library)
-        # twice: the first from-H handle of a process may also create the library's sleeping setup pool (threads: ~5 ms, once per process - it is warm already
-        # when an earlier leg of this run used it); the second is what every further plan of a planner process pays
-        t_s = time.perf_counter()
-        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True, packed=packed)
-        t_setup_first = (time.perf_counter() - t_s) * 1e3
-        p2.close()
-        t_s = time.perf_counter()
-        p2 = frx.Problem(cands, params, device=local_rank, qd_intervals=kappa, enumerate_v=True, packed=packed)
-        t_setup = (time.perf_counter() - t_s) * 1e3
-        t_s = time.perf_counter()
-        p2.initial_guess()
-        t_guess = (time.perf_counter() - t_s) * 1e3
-        p2.close()
-        r = prob.optimize(params["opt_rel_tol"], x0=x0)
         if rank == 0:
             # the same plan with one launch per stage and round (the round-1 path), and the reference's real use: ONE candidate
             prob.set_resident(False)
@@ -379,10 +420,6 @@ def main():
             r_lib["ms_wall"] = (time.perf_counter() - t_s) * 1e3
             r_lib["n_shards"], r_lib["uses_rccl"] = mp_.n_shards, mp_.uses_rccl
             mp_.close()
-        if dist:                                                         # the job's plan time is the slowest rank's
-            tm = torch.tensor([r["ms_total"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            r["ms_total"] = float(tm.item())
         plan = {"plan_setup_ms": t_setup, "plan_setup_ms_first_handle_of_this_kind_in_the_process": t_setup_first, "plan_initial_guess_ms": t_guess, "plan_ms_with_setup": r["ms_total"] + t_setup + t_guess,
                 "plan_lbfgs_mode": os.environ.get("FRX_LBFGS", "device"), "plan_ms": r["ms_total"], "plan_ms_device": r["ms_device"], "plan_ms_host_lbfgs": r["ms_host"],
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
@@ -413,12 +450,6 @@ def main():
                          "plan_status_ok_whole_job": int(np.sum(r_lib["status"] >= 0)), "lib_winner_id": r_lib["winner_id"], "lib_winner_objective": r_lib["winner_objective"]})
             r["ms_total"] = r_lib["ms_wall"]                                 # the job's plan time: all shards, planned concurrently by the library
             plan["plan_ms"] = r_lib["ms_wall"]
-        # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
-        from fast_racing_amd.dist import select_winner
-        ids = np.arange(rank * B, rank * B + B)
-        gid, obj, owner, wc, wT = select_winner(
-            dist, torch.device("cuda", local_rank), r["objective"], ids,
-            lambda i: r["C"][6 * prob.piece_off[i]:6 * prob.piece_off[i + 1]], lambda i: r["T"][prob.piece_off[i]:prob.piece_off[i + 1]], N, local_status=r["status"])
         plan["plans_per_s"] = world * B / (r["ms_total"] * 1e-3)           # whole-job candidate optimisations per second
         plan.update({"winner_id": gid, "winner_rank": owner, "winner_objective": obj, "winner_total_time_s": float(wT.sum())})
         if r_lib is not None:                                            # one process: the library selected the winner over all shards itself
@@ -481,6 +512,8 @@ def main():
         out = {
             "metric": "constraint-samples/s", "value": world * samples_per_step * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_host_wall": dt_wall / args.steps * 1e3, "value_host_wall": world * samples_per_step * args.steps / dt_wall,
+            "timing": "HIP events on the launch stream around the K steps (first launch -> last kernel end), inside the barrier + synchronize bracket whose host wall clock is ms_per_step_host_wall; max over ranks",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {B} candidate trajs/GPU x {N} pieces x {kappa} quadrature intervals "
                                    f"({samples_per_step} constraint samples/step/GPU), 16-gate Zhangjiajie-like corridor, K_i=8",
@@ -513,9 +546,6 @@ def main():
         print(json.dumps(out), flush=True)
     prob.close()
     for sh in lib_shards: sh[0].close()
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -85,7 +85,48 @@ template <class T> struct PinBuf {
 
 } // namespace
 
-namespace frx { int set_error(int code, const std::string &msg) { return fail(code, msg); } }
+namespace frx {
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+
+// ---- this plan's share of the host CPUs (the mailbox threads of a resident plan SPIN for its whole length) ----
+static std::atomic<int> g_extra_plans{0};                 // plans of this process that run next to the caller's (frx_multi: shards - 1)
+void concurrent_plans_hint(int delta) { g_extra_plans.fetch_add(delta, std::memory_order_relaxed); }
+// CPUs the process may use: the affinity mask, cut by the cgroup's CPU quota (v2: cpu.max "quota period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us)
+double host_cpu_budget() {
+    double cpus = (double)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) > 0) cpus = std::min(cpus, (double)CPU_COUNT(&allowed));
+    auto read2 = [](const char *path, double &a, double &b) -> int {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return 0;
+        char t0[64] = {0}, t1[64] = {0};
+        const int n = std::fscanf(f, "%63s %63s", t0, t1);
+        std::fclose(f);
+        if (n >= 1 && std::strcmp(t0, "max") == 0) return -1;            // no quota
+        if (n >= 1) a = std::atof(t0);
+        if (n >= 2) b = std::atof(t1);
+        return n;
+    };
+    double q = 0.0, per = 0.0;
+    const int n2 = read2("/sys/fs/cgroup/cpu.max", q, per);
+    if (n2 == 2 && q > 0.0 && per > 0.0) cpus = std::min(cpus, q / per);
+    else if (n2 == 0) {
+        double q1 = 0.0, p1 = 0.0, dummy = 0.0;
+        if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, dummy) >= 1 && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, dummy) >= 1 && q1 > 0.0 && p1 > 0.0)
+            cpus = std::min(cpus, q1 / p1);
+    }
+    if (const char *e = std::getenv("FRX_HOST_CPUS")) { const double v = std::atof(e); if (v > 0.0) cpus = v; }   // (tests, experiments)
+    return std::max(1.0, cpus);
+}
+int host_cpu_share() {
+    int ranks = 1;
+    if (const char *e = std::getenv("FRX_LOCAL_RANKS")) ranks = std::max(1, std::atoi(e));
+    else if (const char *e2 = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(e2));
+    const int plans = ranks * (1 + std::max(0, g_extra_plans.load(std::memory_order_relaxed)));
+    return std::max(1, (int)(host_cpu_budget() / plans));
+}
+} // namespace frx
 
 struct frx_problem {
     frx_config cfg;
@@ -1040,6 +1081,10 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     };
     for (int b = 0; b < B; b++) status[b] = 0;
     for (int k = 0; k < S; k++) { slot_[k].cand = k; slot_[k].sv.start(p->xoff[k + 1] - p->xoff[k], pm, &slot_[k].cmd); }
+    // the threads that talk to the device stay on the device's NUMA node for the length of the plan (FRX_NUMA=0: wherever the scheduler puts them);
+    // the caller's own affinity is put back when the plan is over.  Looked up (cached per device) before the launch: the clusters spin from then on
+    cpu_set_t numa_set, caller_set;
+    const bool numa_pin = !([] { const char *e = std::getenv("FRX_NUMA"); return e && e[0] == '0'; }()) && device_numa_cpus(p->device, &numa_set);
     std::unique_lock<std::mutex> device_slot(resident_device_lock(p->device));        // one resident grid per device at a time (see above)
     const auto t0 = clk::now();
     HIP_TRY((hipError_t)frx::launch_round(p->dp, p->geo, rl, p->stream));
@@ -1054,15 +1099,18 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     // microseconds of a 25 us round - and every one of them SPINS for the length of the plan: under a CPU quota (the GPU boxes of this project run the
     // process with 16 CPUs' worth) eight ranks of a node with nine spinning threads each are throttled to a crawl, eight ranks with two are not.
     int nsrv = std::max(1, std::min(4, S / 16));
+    {   // ... and no more of them than this plan's share of the CPUs the process may use: cgroup quota and affinity mask, divided by
+        // the plans that spin next to this one - the other ranks of the node (LOCAL_WORLD_SIZE, set by torch.distributed.run; FRX_LOCAL_RANKS overrides)
+        // and the other shards of a frx_multi job in this process - minus one CPU for the rank's main (interpreter) thread.  Eight ranks under the GPU
+        // boxes' quota of 16 CPUs: the caller alone serves the mailboxes (one thread measures the same round as eight, profiles/r04_host_threads.txt).
+        const int share = frx::host_cpu_share();
+        nsrv = std::max(1, std::min(nsrv, share - 1));
+    }
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), S));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     const int scan_pause = [] { const char *e = std::getenv("FRX_RESIDENT_SCAN_PAUSE"); return e ? std::max(0, std::atoi(e)) : 0; }();   // extra pauses between two scans of a thread's mailboxes (experiments)
     std::vector<double> t_host_thr(nsrv, 0.0);
     std::vector<long> scans(nsrv, 0);
-    // the threads that talk to the device stay on the device's NUMA node for the length of the plan (FRX_NUMA=0: wherever the scheduler puts them);
-    // the caller's own affinity is put back when the plan is over
-    cpu_set_t numa_set, caller_set;
-    const bool numa_pin = !([] { const char *e = std::getenv("FRX_NUMA"); return e && e[0] == '0'; }()) && device_numa_cpus(p->device, &numa_set);
     const bool caller_saved = numa_pin && pthread_getaffinity_np(pthread_self(), sizeof(caller_set), &caller_set) == 0;
     if (caller_saved) (void)pthread_setaffinity_np(pthread_self(), sizeof(numa_set), &numa_set);
     auto serve = [&](int tid) {
@@ -1204,7 +1252,20 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
 // The mailbox threads of a resident plan are kept there: with the threads on the OTHER socket of a two-socket box every command the device reads
 // and every result it writes crosses the socket interconnect and its cache-coherence traffic (measured, 32 candidates: 28.2-28.9 us per round with
 // the process on the device's node, 30.6-32.5 on the other one; waits for the host's confirmation: p90 2.3 against 6.9 us - profiles/r04_numa.txt).
+static bool device_numa_cpus_uncached(int device, cpu_set_t *out);
+//  looked up once per device and process - two sysfs reads and a PCI query are not something to do while a resident kernel's clusters
+// already spin; a change of the process's affinity mask after the first plan on a device is not followed
 static bool device_numa_cpus(int device, cpu_set_t *out) {
+    struct Entry { bool ok; cpu_set_t set; };
+    static std::mutex lock;
+    static std::map<int, Entry> cache;
+    std::lock_guard<std::mutex> g(lock);
+    auto it = cache.find(device);
+    if (it == cache.end()) { Entry e; e.ok = device_numa_cpus_uncached(device, &e.set); it = cache.emplace(device, e).first; }
+    if (it->second.ok) *out = it->second.set;
+    return it->second.ok;
+}
+static bool device_numa_cpus_uncached(int device, cpu_set_t *out) {
     char bdf[64] = {0};
     if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return false;
     for (char *c = bdf; *c; c++) *c = (char)std::tolower(*c);
@@ -1294,15 +1355,31 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
                 for (int b = 0; b < p->B; b++) n_retry += wants_retry(status[b]) ? 1 : 0;
                 const bool retry = n_retry > 0;
                 if (retry) {
+                    //  the resident kernel's result of the candidates that are planned again is kept: when the per-stage path cannot run
+                    // (rc2 > 0: its buffers do not fit), they keep the resident verdict, point and objective instead of ending at their start point
                     std::vector<char> again(p->B, 0);
                     int n_again = 0;
+                    const std::vector<double> x_res(x, x + p->NX);
+                    std::vector<int> st_res(status, status + p->B), it_res, ev_res;
+                    std::vector<double> obj_res;
+                    if (iters) it_res.assign(iters, iters + p->B);
+                    if (evals) ev_res.assign(evals, evals + p->B);
+                    if (objective) obj_res.assign(objective, objective + p->B);
                     for (int b = 0; b < p->B; b++) if (wants_retry(status[b])) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
                     const int used = p->resident_used;
                     const double t_res = p->stats[0];
                     const int rc2 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);
                     if (rc2 < 0) return rc2;
+                    if (rc2 != 0) {
+                        std::copy(x_res.begin(), x_res.end(), x);
+                        std::copy(st_res.begin(), st_res.end(), status);
+                        if (iters) std::copy(it_res.begin(), it_res.end(), iters);
+                        if (evals) std::copy(ev_res.begin(), ev_res.end(), evals);
+                        if (objective) std::copy(obj_res.begin(), obj_res.end(), objective);
+                        n_again = 0;
+                    }
                     p->resident_used = used; p->resident_retried = n_again;
-                    p->stats[0] += t_res;
+                    if (rc2 == 0) p->stats[0] += t_res; else p->stats[0] = t_res;
                 }
             }
         }

@@ -135,7 +135,15 @@ public:
         fn_ = nullptr;
     }
 private:
-    TaskPool() = default;
+    //  fork safety: a forked child has this object but none of its threads - joining them in the static destructor would never return.
+    // The child forgets them (the std::thread objects are leaked on purpose: they name threads that do not exist there) and starts with an empty pool.
+    TaskPool() { pthread_atfork(nullptr, nullptr, &TaskPool::after_fork_in_child); }
+    static void after_fork_in_child() {
+        TaskPool &p = get();
+        new std::vector<std::thread>(std::move(p.th_));                       // never destroyed
+        p.th_.clear();
+        p.fn_ = nullptr; p.ntasks_ = 0; p.want_ = 0; p.joined_ = 0; p.running_ = 0;
+    }
     ~TaskPool() {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();

@@ -237,6 +237,8 @@ int frx_multi_optimize(frx_multi *m, const frx_lbfgs_params *params, double *x, 
         if (s.rc != FRX_OK) s.err = frx_last_error();
     };
     {
+        // (the shards' resident plans spin their mailbox threads side by side: each takes its share of the process's CPUs, frx_api.cpp host_cpu_share)
+        struct PlansHint { int n; explicit PlansHint(int k) : n(k) { frx::concurrent_plans_hint(n); } ~PlansHint() { frx::concurrent_plans_hint(-n); } } hint(G - 1);
         std::vector<std::thread> th;
         for (int g = 1; g < G; g++) th.emplace_back(run, g);
         run(0);

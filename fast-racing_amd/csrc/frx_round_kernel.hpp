@@ -64,7 +64,7 @@ static_assert(sizeof(RoundRes) == 64, "one result per cache line");
 
 // LDS layout (doubles), shared by the kernel and the host-side size computation
 struct RoundLds {
-    int ctl, sC, yC, gC, xpC, gpC, pair, role, total;    // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
+    int ctl, sC, yC, gC, xpC, gpC, zC, pair, role, total;    // offsets; role = eval scratch (leader, members) | dense state (dense workgroup)
     int Rf, vd, va, vb, vc, ve, vw, vv, mv;              // dense state: Rf = R^-1 as [128][129] (row stride 129: conflict-free by row AND by column)
 };
 enum { RK_RS = 129 };                                    // row stride of Rf
@@ -77,6 +77,7 @@ __host__ __device__ inline RoundLds round_lds(int m, int CHT, int eval_doubles) 
     int o = 0;
     L.ctl = o; o += 48;                                   // 16 unsigned | 8 doubles | 16 profile accumulators
     L.sC = o; o += CHT; L.yC = o; o += CHT; L.gC = o; o += CHT; L.xpC = o; o += CHT; L.gpC = o; o += CHT;
+    L.zC = o; o += CHT / 2;                               // E zeros (history workgroups: what the first step of a NEW candidate stores into the slots a finished plan leaves behind)
     L.pair = o; o += 2 * 4 * 128;
     o = (o + 1) & ~1;
     L.role = o;
@@ -150,8 +151,29 @@ template <int... I> __device__ __forceinline__ void rk_pass_a_dots(double (&acc)
     ((rk_fma_row<I % 16>(acc[0], gq[I / 16], S[I]), rk_fma_row<I % 16>(acc[1], gq[I / 16], Y[I]),
       rk_fma_row<I % 16>(acc[2], yq[I / 16], S[I]), rk_fma_row<I % 16>(acc[3], yq[I / 16], Y[I])), ...);
 }
-// a VALU write of `x` must be two instructions old before a DPP operand reads it; the compiler does not see into the asm
-#define RK_DPP_SETTLE() asm volatile("s_nop 1" ::: "memory")
+// A VALU write of `x` must be two wait states old before a DPP operand reads it, and the compiler's hazard recognizer does not see into the asm of
+// rk_fma_row.  The wait states are TIED TO THE DATA: every broadcast operand passes through an empty asm in front of the s_nop (so its
+// producer - a v_cndmask, a conversion - cannot sink below it) and through another one behind it (so no FMA that reads it can rise above); volatile
+// asm statements keep their order.  scripts/check_dpp_hazards.py (tests/test_isa.py) scans the shipped code object for a VALU write of a DPP
+// operand less than two wait states in front of its read, whatever a future compiler does with live ranges.
+template <int N> __device__ __forceinline__ void rk_dpp_settle(double (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
+    asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
+}
+template <int N, int M> __device__ __forceinline__ void rk_dpp_settle(double (&x)[N], double (&y)[M]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+    for (int i = 0; i < M; i++) asm volatile("" : "+v"(y[i]));
+    asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+    for (int i = 0; i < M; i++) asm volatile("" : "+v"(y[i]));
+}
 
 // One 16-byte system-scope load of a candidate's command {word, step} from mapped host memory: the two live in one aligned 16-byte
 // granule that the host fills step first, word (with the sequence number) last, so a word that carries the expected sequence number
@@ -700,6 +722,9 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
     for (int e = 0; e < E; e++) { Sreg[e] = 0.0; Yreg[e] = 0.0; }
     unsigned pseq = 0, nadv = 0, nct = 0;                                   // phases seen; direction phases and evaluation phases among them (the tags of this cluster's granules)
     int jnew = 0, bound = 0;
+    bool wipe = false;                                                      // work queue: the next step is the first of a new candidate (workgroup-uniform)
+    const double *zC = sm + L.zC;
+    if (t < E) sm[L.zC + t] = 0.0;                                          // (ordered before its first use by the barriers of the first phases)
     for (;;) {
         if (t == 0) {
             const rk_u64 dl = wall_clock64() + a.timeout_ticks;
@@ -708,7 +733,9 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             for (unsigned spins = 0;; spins++) {
                 w = __hip_atomic_load(a.phase + k * RK_WSTRIDE, FRX_RLX_AGENT);
                 if ((w >> 4) == pseq + 1) break;
-                if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
+                // (w >> 4 beyond pseq + 1: this workgroup was held up - preempted, a debugger - for longer than a phase the leader does not wait for, and the
+                // word it polls for has been overwritten: fail at once instead of sitting out the round timeout)
+                if ((spins & 31u) == 31u && (rk_expired(a, dl) || (int)((w >> 4) - (pseq + 1)) > 0)) { ok = false; break; }
                 RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
@@ -725,6 +752,12 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             __syncthreads();
             const int cn = __builtin_amdgcn_readfirstlane((int)ctlU[1]);
             v.c = cn; v.p0 = a.dp.poff[cn]; v.N = a.dp.poff[cn + 1] - v.p0;
+            // The finished plan's pairs must go: passes A and B multiply a slot without a pair by zero instead of selecting (every lane runs them), and a
+            // plan that ended on non-finite values (the reference's backtracking search "accepts" NaN objectives; the host gives up after 64 of them)
+            // leaves NaN pairs behind - 0 * NaN would poison the new candidate's direction.  They are overwritten with zeros by the new plan's
+            // FIRST step, in the same conditional block that stores a step's new pair (a second definition of the 2 E history registers - zeroing them
+            // here - sent the E = 56 instantiation to scratch memory).
+            wipe = true;
         }
         if (kind == PH_INIT) {                                              // this workgroup's chunk of the start point and its gradient: the first pair's "previous point"
             const int e0 = hg * CHT;
@@ -751,10 +784,13 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
             RK_TR(32);                                                          // chunk and control words arrived
             jnew = __builtin_amdgcn_readfirstlane((int)ctlU[1]); bound = __builtin_amdgcn_readfirstlane((int)ctlU[2]);   // wave-uniform by construction
             // -- 2. the new pair replaces slot jnew --
-            if (slot == jnew) {
+            if (slot == jnew || wipe) {                                     // (wipe: first step of a candidate this cluster took over - every other slot takes zeros, see PH_NEXT)
+                const bool mine = slot == jnew;
+                const double *ssrc = mine ? sC + half * E : zC, *ysrc = mine ? yC + half * E : zC;
 #pragma unroll
-                for (int e = 0; e < E; e++) { Sreg[e] = sC[half * E + e]; Yreg[e] = yC[half * E + e]; }
+                for (int e = 0; e < E; e++) { Sreg[e] = ssrc[e]; Yreg[e] = ysrc[e]; }
             }
+            wipe = false;
             // -- 3. pass A: s_j.g, y_j.g, s_j.y_new, y_j.y_new over this thread's elements --
             int age = jnew - slot; if (age < 0) age += m;
             const bool valid = slot < m && age < bound;
@@ -770,7 +806,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
                     double gq[NQ], yq[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; q++) { const int el = half * E + min(16 * q + (t & 15), E - 1); gq[q] = gC[el]; yq[q] = yC[el]; }
-                    RK_DPP_SETTLE();
+                    rk_dpp_settle(gq, yq);
                     rk_pass_a_dots(acc, gq, yq, Sreg, Yreg, std::make_integer_sequence<int, E>());
                     if (!valid) { acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }
                 }
@@ -909,7 +945,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                     spins = 0;
                     continue;
                 }
-                if ((spins & 31u) == 31u && rk_expired(a, dl)) { ok = false; break; }
+                if ((spins & 31u) == 31u && (rk_expired(a, dl) || (int)((w >> 4) - (pseq + 1)) > 0)) { ok = false; break; }   // (expired, or overrun: see the members' loop)
                 RK_PAUSE(a);
             }
             if (!ok) { rk_fail(a, RK_ERR_PHASE); w = PH_QUIT; }
@@ -965,7 +1001,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                     const bool dropped = el == jnew;                        // column jnew of the old R^-1 counts as zero
                     xc[q] = dropped ? 0.0 : vc[el]; xa[q] = dropped ? 0.0 : va[el];
                 }
-                RK_DPP_SETTLE();
+                rk_dpp_settle(xc, xa);
 #pragma unroll
                 for (int q = 0; q < 4; q++) rk_dot16x2(sz, st, xc[q], xa[q], er + 16 * q, rk_seq16());
                 mv[hq * 128 + pp] = sz; mz[hq * 128 + pp] = st;
@@ -998,7 +1034,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                     const double ws = wave_sum_dpp(vet * vwt);
                     if (ln == 0) ctlD[t >> 6] = ws;
                 }
-                RK_DPP_SETTLE();
+                rk_dpp_settle(xw);
                 rk_dot16(sacc, xw[0], Ya, rk_seq16()); rk_dot16(sacc, xw[1], Ya + 16, rk_seq16());
                 rk_dot16(sacc, xw[2], Yb, rk_seq16()); rk_dot16(sacc, xw[3], Yb + 16, rk_seq16());
                 mv[hq * 128 + pp] = sacc;
@@ -1015,7 +1051,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
                 double sacc = 0.0, xv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) xv[q] = vv[q0 + 16 * q + l16];
-                RK_DPP_SETTLE();
+                rk_dpp_settle(xv);
 #pragma unroll
                 for (int q = 0; q < 4; q++) rk_dot16(sacc, xv[q], ec + 16 * q, rk_seq16());
                 mz[hq * 128 + pp] = sacc;

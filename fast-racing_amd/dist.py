@@ -65,18 +65,16 @@ def select_winner(dist, device, local_objective: np.ndarray, local_ids: np.ndarr
 
 
 # ---- self-launch of the one-process-per-GPU front end (bench.py --gpus N without an external launcher) ----
-def _free_port() -> int:
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
-
-
 def self_launch_command(n_ranks: int, script: str, argv, port: int = 0):
-    """The command that starts `script argv` as n_ranks ranks of one node - what the driver runs for N > 1
-    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script ...`)."""
+    """The command that starts `script argv` as n_ranks ranks of one node.  With a port: exactly what the driver runs for N > 1
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script ...`).  Without one
+    (what self_launch uses): `--standalone --local-addr 127.0.0.1`, whose rendezvous store binds port 0 itself - a port found free by a probe
+    socket here could be taken again before the launcher binds it."""
     import sys
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port or _free_port()), script] + list(argv)
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}"]
+    if port:
+        return head + ["--master-addr", "127.0.0.1", "--master-port", str(int(port)), script] + list(argv)
+    return head + ["--standalone", "--local-addr", "127.0.0.1", script] + list(argv)
 
 
 def ranks_to_launch(n_gpus: int, env, visible_devices: int) -> int:
@@ -106,4 +104,5 @@ def self_launch(n_ranks: int, script: str, argv, env=None) -> int:
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on these hosts
     e.setdefault("OMP_NUM_THREADS", "1")
+    e["FRX_BENCH_SELF_LAUNCHED"] = "1"                       # the ranks know who started them (any launcher sets TORCHELASTIC_RUN_ID)
     return subprocess.call(self_launch_command(n_ranks, script, argv), env=e)

@@ -107,6 +107,8 @@ def test_self_launch_command_is_the_drivers(frx):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29400"
     assert cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "5"]
+    own = self_launch_command(2, "/x/bench.py", ["--gpus", "2"])              # bench.py's own launch: the rendezvous store picks its port itself
+    assert "--standalone" in own and own[own.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in own and own[-3:] == ["/x/bench.py", "--gpus", "2"]
     assert ranks_to_launch(1, {}, 1) == 0 and ranks_to_launch(8, {}, 8) == 8 and ranks_to_launch(8, {"WORLD_SIZE": "8"}, 8) == 0
     assert ranks_to_launch(2, {"FRX_BENCH_DEVICE": "0"}, 1) == 2          # the 1-GPU-box knob: every rank on one device
     with pytest.raises(SystemExit):
