@@ -301,10 +301,19 @@ __device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const
         const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
         const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
         const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+        // beta_m (x) a_m, m = 0..3, WITHOUT the structural zeros of the derivative bases (beta_m[k] = 0 for k < m).  Written as the full 4-term sum the
+        // compiler kept them - it may not fold 0 * x, which is NaN for a non-finite x: 18 of the 72 FMAs of a sample multiplied by a literal zero
+        // (v_fmac_f64 v, 0, v in the round-4 ISA).  Same products, same order of the remaining additions: the finite results are bit for bit the old ones.
 #pragma unroll
         for (int k = 0; k < 6; k++)
 #pragma unroll
-            for (int d = 0; d < 3; d++) o[2 + 3 * k + d] = b0[k] * adj[d] + b1[k] * adj[3 + d] + b2[k] * adj[6 + d] + b3[k] * adj[9 + d];
+            for (int d = 0; d < 3; d++) {
+                double acc = b0[k] * adj[d];
+                if (k >= 1) acc = acc + b1[k] * adj[3 + d];
+                if (k >= 2) acc = acc + b2[k] * adj[6 + d];
+                if (k >= 3) acc = acc + b3[k] * adj[9 + d];
+                o[2 + 3 * k + d] = acc;
+            }
         if (!first) {
 #pragma unroll
             for (int i = 0; i < 20; i++) o[i] += mine[i];

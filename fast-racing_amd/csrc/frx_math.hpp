@@ -65,7 +65,7 @@ FRX_HD void frame_reverse(const double *U0, const double *U1, const double *U2, 
                           double invM, double *W) {
     double zxU0[3], U0xy[3];
     cross3(zB, U0, zxU0);
-    cross3(U0, yB, U0xy);
+    U0xy[0] = U0[1] * yB[2] - U0[2] * yB[1]; U0xy[1] = -(U0[0] * yB[2]); U0xy[2] = U0[0] * yB[1];   // U0 x yB, yB[0] = 0
     const double Pv[3] = {U1[0] + zxU0[0], U1[1] + zxU0[1], U1[2] + zxU0[2]};
     const double yP = yB[1] * Pv[1] + yB[2] * Pv[2];
     const double Pp1 = (Pv[1] - yB[1] * yP) * invM, Pp2 = (Pv[2] - yB[2] * yP) * invM;
@@ -142,7 +142,8 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
         for (int d = 0; d < 3; d++) { zB[d] = h[d] * invF; pl[d] = pos[d] - hb[d]; }
         invM = rsqrt_fast(zB[2] * zB[2] + zB[1] * zB[1]);
         yB[0] = 0.0; yB[1] = zB[2] * invM; yB[2] = -zB[1] * invM;
-        cross3(yB, zB, xB);
+        // xB = yB x zB with yB[0] = 0 written out (cross3 multiplied by the literal zero twice: 0 * x may not be folded)
+        xB[0] = yB[1] * zB[2] - yB[2] * zB[1]; xB[1] = yB[2] * zB[0]; xB[2] = -(yB[1] * zB[0]);
     }
     if (!LAT) { c.fence(); FRX_PHASE(); }
 
@@ -153,17 +154,26 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
 
     // ---- corridor half-spaces (CPU.hpp:310-345); the sign test avoids the sqrt unless violated ----
     // Two passes over chunks of FRX_HS_CHUNK half-spaces (round 4).  Pass 1 runs the sign test of the whole chunk WITHOUT a branch: independent
-    // chains of ~18 FP64 instructions that the scheduler interleaves, their records read from LDS in one go - the one-loop form tested, branched
-    // and read half-space by half-space, so a lone wave paid an LDS latency plus a dependent chain per half-space (ISA: ds_read2 / s_waitcnt /
-    // 18 VALU / s_cbranch, eight times: ~1.8 k of a sample's ~5 k cycles).  Pass 2 revisits, in the same order, only the half-spaces pass 1
-    // flagged (none for a sample inside its corridor) and does what the branch did.  Same expressions, same order of accumulation.
+    // chains that the scheduler interleaves, their records read from LDS in one go - the one-loop form tested, branched and read half-space by
+    // half-space, so a lone wave paid an LDS latency plus a dependent chain per half-space (ISA: ds_read2 / s_waitcnt / 18 VALU / s_cbranch, eight
+    // times: ~1.8 k of a sample's ~5 k cycles).  Pass 2 revisits, in the same order, only the half-spaces pass 1 flagged (none for a sample inside
+    // its corridor) and does what the branch did.  Same expressions, same order of accumulation.
+    // Round 5 - pre-reject: the ellipsoid's support in direction n is  |E R^T n| <= max(ell) |R^T n| = max(ell)  (R orthonormal, n a unit normal),
+    // so  d0 < -max(ell)  proves  d0 < 0  and  |E R^T n|^2 <= max(ell)^2 < d0^2 : the half-space cannot be flagged, and the three frame
+    // projections, their squares and the comparison against d0^2 (18 of the 22 FP64 instructions of a test) are never issued for it.  The guard
+    // factor (1 + 2^-20) covers the rounding of the computed |R^T n|^2 (a few ulp) many times over; whatever is not rejected takes the full test
+    // of round 4, so the flags - and with them every result bit - are the ones the full test alone would give.  Measured on the headline batch
+    // (scripts/r05/prereject_stats.py, CPU): 98.9 % of the (sample, half-space) pairs and 90 % of the (wave, chunk) pairs are rejected at the
+    // converged trajectories, 98 % of the (wave, chunk) pairs along the way.
     // Kub: wave-uniform bound on K (the corridor block is zero-padded to it); lanes with fewer half-spaces mask the surplus.
     {
         const double e0 = pc.ell[0], e1 = pc.ell[1], e2 = pc.ell[2];
+        const double emax = (e0 > e1 ? (e0 > e2 ? e0 : e2) : (e1 > e2 ? e1 : e2)) * (1.0 + 9.5367431640625e-7);
         double Pcorr = 0.0;
         constexpr int CH = FRX_HS_CHUNK;
         for (int k0 = 0; k0 < Kub; k0 += CH) {
             unsigned need = 0u;
+            unsigned long long maybe = 0;
             double rec[CH][4];
             FRX_PHASE();                                                   // between this fence and the next: the chunk's LDS reads and nothing else
 #if defined(FRX_COUNT_BUILD)                                     // scripts/count_fp64.py: one copy of the test, so that static counts are per half-space
@@ -180,18 +190,42 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
                 rec[j][0] = hb[r]; rec[j][1] = hb[r + 1]; rec[j][2] = hb[r + 2]; rec[j][3] = hb[r + 3];
             }
             FRX_PHASE();                                                   // (... not re-sunk next to their uses: the scheduler minimises registers, not latency)
+#if !defined(FRX_NO_PREREJECT)
 #if defined(FRX_COUNT_BUILD)
 #pragma unroll 1
 #else
 #pragma unroll
 #endif
-            for (int j = 0; j < CH; j++) {
+            for (int j = 0; j < CH; j++) {                                 // pre-reject: the signed distance of the CENTRE alone
                 const double *n = rec[j];
-                // (R^T n) .* ellipsoid
-                const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
-                const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
                 const double d0 = dot3(n, pl) - n[3];                      // n.(pos - p_k) + safeMargin
-                need |= (k0 + j < K && (d0 >= 0.0 || eN2 > d0 * d0)) ? (1u << j) : 0u;
+                const bool open_j = (k0 + j < K) & !(d0 < -emax);          // (NaN stays "open": the full test decides)
+#if defined(__HIP_DEVICE_COMPILE__)
+                // ONE wave-uniform flag for the chunk (lane masks combined on the scalar unit, a scalar branch): a lane whose own half-spaces are all
+                // rejected runs the full test with its wave when another lane needs it - the full test is the authority, its flags are the same
+                maybe |= __builtin_amdgcn_ballot_w64(open_j);
+#else
+                maybe |= open_j ? 1u : 0u;
+#endif
+            }
+            if (maybe != 0) {
+#else
+            maybe = 1;
+            {
+#endif
+#if defined(FRX_COUNT_BUILD)
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+                for (int j = 0; j < CH; j++) {
+                    const double *n = rec[j];
+                    // (R^T n) .* ellipsoid
+                    const double w0 = dot3(xB, n) * e0, w1 = (yB[1] * n[1] + yB[2] * n[2]) * e1, w2 = dot3(zB, n) * e2;
+                    const double eN2 = w0 * w0 + w1 * w1 + w2 * w2;
+                    const double d0 = dot3(n, pl) - n[3];                  // n.(pos - p_k) + safeMargin
+                    need |= (k0 + j < K && (d0 >= 0.0 || eN2 > d0 * d0)) ? (1u << j) : 0u;
+                }
             }
             if (need != 0u) {
 #pragma unroll 1
@@ -271,7 +305,7 @@ FRX_HD void penalty_sample(CV c, double s1, double ws, const PenaltyConst &pc, H
     {   // body-rate limit (CPU.hpp:285-299, 387-398)
         double jer[3];
         poly_eval<3>(c, s1, jer);
-        const double r0 = dot3(xB, jer), r1 = dot3(yB, jer);
+        const double r0 = dot3(xB, jer), r1 = yB[1] * jer[1] + yB[2] * jer[2];   // (yB[0] = 0: the compiler may not drop a 0 * x)
         const double b0 = r0 * invF, b1 = r1 * invF;
         const double sqrMagBdr = b1 * b1 + b0 * b0;
         const double violaBdr = sqrMagBdr - pc.bdrMaxSqr;
