@@ -1376,6 +1376,105 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             }
         }
     }
+    if (!ro) {
+        const int nx = dp.xoff[b + 1] - x0;
+        const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
+        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
+        stage_to_lds<8>(vs, dp.vrec + 3 * (size_t)v0, nvd, k, nthr);
+        if (tapped) stage_to_lds<4>(dsv, tap.d + x0, nx, k, nthr);
+        // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
+        const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
+        const double2 *src = (const double2 *)(pcrw + (size_t)p0 * ws);
+        for (int i0 = k; i0 < n2; i0 += 8 * nthr) {
+            double2 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i2 = i0 + u * nthr; tmp[u] = src[i2 < n2 ? i2 : n2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i2 = i0 + u * nthr;
+                if (i2 < n2) {
+                    const int e = 2 * i2, kn = e / ws, ff = e - kn * ws;        // ws even: both halves belong to the same knot
+                    pw[kn * (ws + 1) + ff] = tmp[u].x; pw[kn * (ws + 1) + ff + 1] = tmp[u].y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    FRX_STAMP(17);
+    // ================================================================================================================================================
+    // Round 5: everything that does NOT depend on the penalty partials runs here, IN FRONT of the poll for them.  In the resident kernel the leader has
+    // ~4.5 us between the end of its forward map and the arrival of the partials (hand-off, the members' penalty share) with nothing to do; until
+    // round 4 it then ran, behind the poll, a chain whose first third did not need them: durations' powers and reciprocals, the Hermite adjoint's and the
+    // knot adjoint's coefficients (functions of h, p, v, a alone), the 52 saved multipliers of its knot (LDS, three axis waves sharing the read
+    // bandwidth), the waypoint layer's vertices, variables and direction elements, x.x, the tau layer's derivative.  The compiler cannot move any of
+    // it across the polling loop.  Same expressions, same order of operations on the values that do depend on the partials: bit-identical results.
+    // (The stage kernels have no poll: for them this is the order the scheduler chose anyway.)
+    // ================================================================================================================================================
+    double costAcc = 0.0, gTl = 0.0;
+    unsigned long long early_word = 0, early_step = 0;
+    int nst = 0;
+    for (int s = 1; s < N - 1; s <<= 1) nst++;
+    const int ax = wave - 1;                                          // (axis waves)
+    const bool act = kk >= 1 && kk <= N - 1;
+    const int kc = act ? kk : 1;
+    // wave 0
+    double jerkE = 0.0, jerkT = 0.0, dtt = 0.0, x_tau = 0.0, d_tau = 0.0;
+    // axis waves: Hermite adjoint / knot adjoint coefficients of piece kk, multipliers of knot kk
+    double cj3 = 0.0, cj4 = 0.0, cj5 = 0.0, P0 = 0.0, V0 = 0.0, A0 = 0.0, P1 = 0.0, V1 = 0.0, A1 = 0.0;
+    double hk_pd3 = 0, hk_pd4 = 0, hk_pd5 = 0, hk_13 = 0, hk_14 = 0, hk_15 = 0, hk_43 = 0, hk_44 = 0, hk_23 = 0, hk_24 = 0, hk_25 = 0, hk_53 = 0, hk_54 = 0, hk_55 = 0, hk_dc3 = 0, hk_dc4 = 0, hk_dc5 = 0;
+    double ka_dLv = 0, ka_dLa = 0, ka_dRv = 0, ka_dRa = 0, ka_ih3 = 0, ka_ih4 = 0;
+    double ab[6][8], Di[4] = {0, 0, 0, 0};
+    // axis waves, waypoint layer: this lane's vertices of its pair's waypoint (two trips of four, as the loop below takes them)
+    constexpr int WPF = 8;
+    const int wpt = t2 >> 1, sub = t2 & 1;
+    const bool wact0 = wave >= 1 && wpt < N - 1;
+    const bool cached_lds = ro && ro->wq, cached0 = cached_lds || (!ro && dp.wq_glob != nullptr);
+    const double *Vw = vs, *xiw = xs;
+    int nv1w = 0, xbw = 0;
+    double qn0 = 0.0, wq1 = 0.0, wq2 = 0.0, wq3 = 0.0, w_c2sc = 0.0, w_iq2 = 0.0, w_sc22 = 0.0;
+    double pxv[WPF], pvx[WPF], pvy[WPF], pvz[WPF], pdd[WPF];
+    if (wave == 0) {
+        // ---- jerk energy + its duration gradient (CPU.hpp:507-520, 65-75): the part that is added to the penalty partials ----
+        if (piece) {
+            Tf[kk] = h;
+            const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
+            const double *c3 = c9, *c4 = c9 + 3, *c5 = c9 + 6;
+            const double s33 = dot3(c3, c3), s43 = dot3(c4, c3), s44 = dot3(c4, c4), s53 = dot3(c5, c3), s54 = dot3(c5, c4), s55 = dot3(c5, c5);
+            jerkE = (36.0 * s33 * t1 + 144.0 * s43 * t2_ + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
+            jerkT = (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2_ + 720.0 * s53 * t2_ + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
+        }
+        if (dp.soft && kk < cN) { x_tau = xs[kk]; dtt = dT_dtau(x_tau, dp.c2 != 0); if (tapped) d_tau = dsv[kk]; }
+    } else {
+        FRX_STAMP_AX(25);
+        {   // jerk-energy part of cbar = d f / d c of this axis (CPU.hpp:84-92)
+            const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
+            cj3 = 72.0 * cq[3] * t1 + 144.0 * cq[4] * t2_ + 240.0 * cq[5] * t3;
+            cj4 = 144.0 * cq[3] * t2_ + 384.0 * cq[4] * t3 + 720.0 * cq[5] * t4;
+            cj5 = 240.0 * cq[3] * t3 + 720.0 * cq[4] * t4 + 1440.0 * cq[5] * t5;
+        }
+        // knot states recovered from the coefficients: p = c0, v = c1, a = 2 c2 at the piece start; the next knot's from the next lane
+        P0 = cq[0]; V0 = cq[1]; A0 = 2.0 * cq[2];
+        P1 = lane_down1(P0); V1 = lane_down1(V0); A1 = lane_down1(A0);
+        if (kk == N - 1) { P1 = r_tl[0]; V1 = r_tl[1]; A1 = r_tl[2]; }
+        {   // hermite_adjoint (frx_minco.hpp), the factors of cbar: term by term the sub-expressions of that function
+            const double ih = rcp_fast(h), ih2 = ih * ih, ih3 = ih2 * ih, ih4 = ih2 * ih2, ih5 = ih4 * ih, ih6 = ih3 * ih3;
+            const double dl = P1 - P0;
+            hk_pd3 = 10.0 * ih3; hk_pd4 = 15.0 * ih4; hk_pd5 = 6.0 * ih5;
+            hk_13 = 6.0 * ih2; hk_14 = 8.0 * ih3; hk_15 = 3.0 * ih4;
+            hk_43 = -4.0 * ih2; hk_44 = 7.0 * ih3;
+            hk_23 = 1.5 * ih; hk_24 = 1.5 * ih2; hk_25 = 0.5 * ih3;
+            hk_53 = 0.5 * ih; hk_54 = ih2; hk_55 = 0.5 * ih3;
+            hk_dc3 = -30.0 * dl * ih4 + 2.0 * (4.0 * V1 + 6.0 * V0) * ih3 + 0.5 * (3.0 * A0 - A1) * ih2;
+            hk_dc4 = 60.0 * dl * ih5 - 3.0 * (7.0 * V1 + 8.0 * V0) * ih4 - (3.0 * A0 - 2.0 * A1) * ih3;
+            hk_dc5 = -30.0 * dl * ih6 + 12.0 * (V1 + V0) * ih5 + 1.5 * (A0 - A1) * ih4;
+            // knot_adjoint_piece (frx_minco.hpp): the rows this piece contributes to its two knots
+            ka_dLv = -504.0 * V0 * ih4 - 48.0 * A0 * ih3 - 576.0 * V1 * ih4 + 72.0 * A1 * ih3 + 1440.0 * dl * ih5;
+            ka_dLa = 48.0 * V0 * ih3 + 3.0 * A0 * ih2 + 72.0 * V1 * ih3 - 9.0 * A1 * ih2 - 180.0 * dl * ih4;
+            ka_dRv = 1440.0 * dl * ih5 - 576.0 * V0 * ih4 - 504.0 * V1 * ih4 - 72.0 * A0 * ih3 + 48.0 * A1 * ih3;
+            ka_dRa = 180.0 * dl * ih4 - 72.0 * V0 * ih3 - 48.0 * V1 * ih3 - 9.0 * A0 * ih2 + 3.0 * A1 * ih2;
+            ka_ih3 = ih3; ka_ih4 = ih4;
+        }
+    }
     if (SH && ro && ro->o20ll) {
         // Resident caller: the 20 partials of piece kp arrive as granules tagged with the number of this evaluation; lane kk of wave 0 polls {cost, d/dT},
         // lane kk of an axis wave its six d/dc - the workgroups that integrate the penalty neither drain nor count in front of this read, and the leader
@@ -1409,43 +1508,8 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             for (int q = 0; q < 6; q++) cbq[q] = rk_ll_value(w[q][0], w[q][1]);
         }
     }
-    if (!ro) {
-        const int nx = dp.xoff[b + 1] - x0;
-        const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
-        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
-        stage_to_lds<8>(vs, dp.vrec + 3 * (size_t)v0, nvd, k, nthr);
-        if (tapped) stage_to_lds<4>(dsv, tap.d + x0, nx, k, nthr);
-        // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
-        const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
-        const double2 *src = (const double2 *)(pcrw + (size_t)p0 * ws);
-        for (int i0 = k; i0 < n2; i0 += 8 * nthr) {
-            double2 tmp[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int i2 = i0 + u * nthr; tmp[u] = src[i2 < n2 ? i2 : n2 - 1]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i2 = i0 + u * nthr;
-                if (i2 < n2) {
-                    const int e = 2 * i2, kn = e / ws, ff = e - kn * ws;        // ws even: both halves belong to the same knot
-                    pw[kn * (ws + 1) + ff] = tmp[u].x; pw[kn * (ws + 1) + ff + 1] = tmp[u].y;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    FRX_STAMP(17);
-    double costAcc = 0.0, gTl = 0.0;
-    unsigned long long early_word = 0, early_step = 0;
     if (wave == 0) {
-        // ---- jerk energy + its duration gradient (CPU.hpp:507-520, 65-75) on top of the penalty partials ----
-        if (piece) {
-            Tf[kk] = h;
-            const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
-            const double *c3 = c9, *c4 = c9 + 3, *c5 = c9 + 6;
-            const double s33 = dot3(c3, c3), s43 = dot3(c4, c3), s44 = dot3(c4, c4), s53 = dot3(c5, c3), s54 = dot3(c5, c4), s55 = dot3(c5, c5);
-            costAcc = o0 + (36.0 * s33 * t1 + 144.0 * s43 * t2_ + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
-            gTl = o1 + (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2_ + 720.0 * s53 * t2_ + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
-        }
+        if (piece) { costAcc = o0 + jerkE; gTl = o1 + jerkT; }
         // Every load of this wave has to have LANDED before the read over PCIe is issued, and no later instruction may wait on vmcnt: the
         // compiler waits for a loaded register at its first use, with vmcnt(0) when a conditional load may lie in between - for the
         // coarse-interval table that use is the merge loop behind the barrier below, and the wait took the host read's round trip with it
@@ -1454,41 +1518,38 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         if (kk < cN) gCo[kk] = (double)(r_iv + (r_fb << 10));
         if (tap.early_cmd && k == 0) { early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); early_step = __hip_atomic_load(tap.early_cmd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // behind the wave's first loads (see LineSearchTap)
     } else {
-        const int ax = wave - 1;
-        const bool act = kk >= 1 && kk <= N - 1;
-        const int kc = act ? kk : 1;
-        FRX_STAMP_AX(25);
-        // ---- cbar = d f / d c of this axis: penalty part + jerk energy (CPU.hpp:84-92) ----
-        {
-            const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
-            cbq[3] += 72.0 * cq[3] * t1 + 144.0 * cq[4] * t2_ + 240.0 * cq[5] * t3;
-            cbq[4] += 144.0 * cq[3] * t2_ + 384.0 * cq[4] * t3 + 720.0 * cq[5] * t4;
-            cbq[5] += 240.0 * cq[3] * t3 + 720.0 * cq[4] * t4 + 1440.0 * cq[5] * t5;
-        }
-        // knot states recovered from the coefficients: p = c0, v = c1, a = 2 c2 at the piece start; the next knot's from the next lane
-        const double P0 = cq[0], V0 = cq[1], A0 = 2.0 * cq[2];
-        double P1 = lane_down1(P0), V1 = lane_down1(V0), A1 = lane_down1(A0);
-        if (kk == N - 1) { P1 = r_tl[0]; V1 = r_tl[1]; A1 = r_tl[2]; }
-        // ---- Hermite adjoint of the piece; its end-of-piece parts belong to the next knot (= next lane) ----
-        double db[6] = {0, 0, 0, 0, 0, 0}, hb = 0.0;
-        if (piece) hermite_adjoint(h, P0, V0, A0, P1, V1, A1, cbq, db, hb);
-        const double ePu = lane_up1(db[3]), eVu = lane_up1(db[4]), eAu = lane_up1(db[5]);
-        double r0 = 0.0, r1 = 0.0, pbk = 0.0;
-        if (act) { r0 = db[1] + eVu; r1 = db[2] + eAu; pbk = db[0] + ePu; }      // right-hand side of K mu = wbar; direct d f / d p_k (both adjacent pieces)
-        FRX_STAMP_AX(26);
-        // ---- mu = K^-1 wbar with the multipliers of the forward reduction (K is symmetric), neighbours by lane shifts ----
-        int nst = 0;
-        for (int s = 1; s < N - 1; s <<= 1) nst++;
-        double muv = 0.0, mua = 0.0;                                   // zero at the fixed end knots
         if (nst <= 6) {
-            // every multiplier of this knot up front (they were all saved by the forward pass): a step is then one lane exchange, not two LDS round trips
-            double ab[6][8], Di[4];
+            // every multiplier of this knot (they were all saved by the forward pass), requested first: a step of the solve below is then one lane exchange,
+            // not two LDS round trips, and these trips run under the Hermite adjoint.  (In front of the poll they would be 104 more live registers there.)
 #pragma unroll
             for (int st = 0; st < 6; st++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) ab[st][i] = pw[kc * pws + (st < nst ? st : 0) * 8 + i];
 #pragma unroll
             for (int i = 0; i < 4; i++) Di[i] = pw[kc * pws + nsteps * 8 + i];
+        }
+        // ---- cbar = d f / d c of this axis: penalty part + jerk energy (CPU.hpp:84-92) ----
+        cbq[3] += cj3; cbq[4] += cj4; cbq[5] += cj5;
+        // ---- Hermite adjoint of the piece (hermite_adjoint, coefficients from above); its end-of-piece parts belong to the next knot (= next lane) ----
+        double db[6] = {0, 0, 0, 0, 0, 0}, hb = 0.0;
+        if (piece) {
+            const double *cb = cbq;
+            const double pd = hk_pd3 * cb[3] - hk_pd4 * cb[4] + hk_pd5 * cb[5];
+            db[0] = cb[0] - pd;
+            db[3] = pd;
+            db[1] = cb[1] - hk_13 * cb[3] + hk_14 * cb[4] - hk_15 * cb[5];
+            db[4] = hk_43 * cb[3] + hk_44 * cb[4] - hk_15 * cb[5];
+            db[2] = 0.5 * cb[2] - hk_23 * cb[3] + hk_24 * cb[4] - hk_25 * cb[5];
+            db[5] = hk_53 * cb[3] - hk_54 * cb[4] + hk_55 * cb[5];
+            hb = cb[3] * hk_dc3 + cb[4] * hk_dc4 + cb[5] * hk_dc5;
+        }
+        const double ePu = lane_up1(db[3]), eVu = lane_up1(db[4]), eAu = lane_up1(db[5]);
+        double r0 = 0.0, r1 = 0.0, pbk = 0.0;
+        if (act) { r0 = db[1] + eVu; r1 = db[2] + eAu; pbk = db[0] + ePu; }      // right-hand side of K mu = wbar; direct d f / d p_k (both adjacent pieces)
+        FRX_STAMP_AX(26);
+        // ---- mu = K^-1 wbar with the multipliers of the forward reduction (K is symmetric), neighbours by lane shifts ----
+        double muv = 0.0, mua = 0.0;                                   // zero at the fixed end knots
+        if (nst <= 6) {
 #pragma unroll
             for (int st = 0; st < 6; st++)
                 if (st < nst) {
@@ -1505,26 +1566,51 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
             for (int st = 0; st < nst; st++) {
                 const int s = 1 << st;
                 const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
-                double ab[8];
+                double ab1[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
+                for (int i = 0; i < 8; i++) ab1[i] = pw[kc * pws + st * 8 + i];
                 const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
                 const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
-                const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);
-                const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+                const double n0 = r0 - (ab1[0] * l0 + ab1[1] * l1) - (ab1[4] * h0 + ab1[5] * h1);
+                const double n1 = r1 - (ab1[2] * l0 + ab1[3] * l1) - (ab1[6] * h0 + ab1[7] * h1);
                 r0 = n0; r1 = n1;
             }
             if (act) {
-                const double *Di = pw + kk * pws + nsteps * 8;
-                muv = Di[0] * r0 + Di[1] * r1; mua = Di[2] * r0 + Di[3] * r1;
+                const double *Dq = pw + kk * pws + nsteps * 8;
+                muv = Dq[0] * r0 + Dq[1] * r1; mua = Dq[2] * r0 + Dq[3] * r1;
             }
         }
         FRX_STAMP_AX(27);
-        // ---- through the knot system: duration term and d f / d(p_{k+1} - p_k) ----
+        // The waypoint layer's operands - this lane's vertices, variables and direction elements, the forward map's two sums - are requested HERE, where the
+        // solve's 52 multipliers are dead: their LDS round trips run under the knot adjoint and the barrier instead of behind it (in front of the
+        // poll, next to the multipliers, they cost the resident kernel's leader 190 spilled registers).
+        if (wact0) {                                                  // (<= 64 pieces: 63 waypoints on the 96 lane pairs of the axis waves - one pass)
+            nv1w = r_wnv - 1; xbw = r_wxb;
+            Vw = vs + 3 * (r_wvb - cv0) + (ro ? ro->vskew * wpt : 0);
+            xiw = xs + (xbw - x0);
+            if (cached_lds) { const double *wq = ro->wq + 4 * wpt; qn0 = wq[0]; wq1 = wq[1]; wq2 = wq[2]; wq3 = wq[3]; }
+            else if (cached0) { qn0 = r_wq0.x; wq1 = r_wq0.y; wq2 = r_wq1.x; wq3 = r_wq1.y; }
+#pragma unroll
+            for (int j = 0; j < WPF; j++) {
+                const int a = min(sub + 2 * j, nv1w - 1);
+                pxv[j] = xiw[a]; pvx[j] = Vw[3 * (a + 1)]; pvy[j] = Vw[3 * (a + 1) + 1]; pvz[j] = Vw[3 * (a + 1) + 2];
+                pdd[j] = tapped ? dsv[xbw - x0 + a] : 0.0;
+            }
+            if (cached0) {
+                const double qp1 = qn0 + 1.0, iq = 1.0 / qp1, sc = 2.0 * iq;
+                w_c2sc = 2.0 * sc; w_iq2 = iq * iq; w_sc22 = 2.0 * sc * sc;
+#pragma unroll
+                for (int j = 0; j < WPF; j++) if (sub + 2 * j < nv1w) t_xx += pxv[j] * pxv[j];
+            }
+        }
+        // ---- through the knot system (knot_adjoint_piece, rows from above): duration term and d f / d(p_{k+1} - p_k) ----
         double mu1v = lane_down1(muv), mu1a = lane_down1(mua);
         if (kk >= N - 1) { mu1v = 0.0; mu1a = 0.0; }
         double dlb = 0.0;
-        if (piece) dlb = knot_adjoint_piece(h, P1 - P0, V0, A0, V1, A1, muv, mua, mu1v, mu1a, hb);
+        if (piece) {
+            hb -= mu1v * ka_dLv + mu1a * ka_dLa + muv * ka_dRv + mua * ka_dRa;
+            dlb = (mu1v + muv) * 360.0 * ka_ih4 + (mua - mu1a) * 60.0 * ka_ih3;
+        }
         const double dlu = lane_up1(dlb);                    // + dl of the piece ending at this knot
         if (piece) KN(KV, ax, kk) = hb;
         if (act) KN(KP, ax, kk) = pbk + dlu - dlb;                   // d f / d q_k for the pair that owns the waypoint
@@ -1549,10 +1635,10 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         if (kk == 0) { if (!ro) f[b] = fval; red[0] = fval; }             // resident caller: the value travels through the mailbox, nothing to drain
         if (dp.soft) {
             if (kk < cN) {
-                const double gi = gCo[kk] * dT_dtau(xs[kk], dp.c2 != 0);
+                const double gi = gCo[kk] * dtt;
                 if (gs) gs[kk] = gi; else g[x0 + kk] = gi;
                 if (gpub && !defer_time_gpub) stg<SH>(gpub + kk, gi, gwt);
-                if (tapped) { t_dg += gi * dsv[kk]; t_xx += xs[kk] * xs[kk]; t_gg += gi * gi; }
+                if (tapped) { t_dg += gi * d_tau; t_xx += x_tau * x_tau; t_gg += gi * gi; }
             }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1577,28 +1663,52 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
         }
     } else {
         // ---- addPropCtoP + addLayerPGrad (CPU.hpp:154-161, 897-928): waypoint w (= knot w+1) on a PAIR of lanes of the axis waves ----
-        for (int w0 = 0; w0 < N - 1; w0 += 96) {
-            const int w = w0 + (t2 >> 1), sub = t2 & 1;
-            const bool wact = w < N - 1;
-            const double *V = vs, *xi = xs;
-            int nv1 = 0, xb = 0;
-            double g0 = 0.0, g1 = 0.0, g2 = 0.0, qn = 0.0;
+        // with r_a = sc xi_a, sc = 2 / (1 + |xi|^2):  d f / d xi_a = xi_a (2 sc^2 (V_a . g) - 4 gdq / (1 + |xi|^2)^2),
+        // gdq = 2 sc sum_a (V_a . g) xi_a^2  -  |xi|^2 and the weighted sum come out of ONE pass over the vertices, which the forward map of this
+        // evaluation made already (cached: in LDS for the resident caller, in dp.wq_glob between the stage kernels)
+        const int w = wpt;
+        const bool wact = wact0;
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+        if (wact) { g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1); }
+        if (cached0) {
+            const double s2 = wq1 * g0 + wq2 * g1 + wq3 * g2;
+            FRX_STAMP_AX(30);
+            const double gdq = w_c2sc * s2, kq = 4.0 * gdq * w_iq2, sc22 = w_sc22;
+            FRX_STAMP_AX(31);
             if (wact) {
-                int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
-                if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
-                nv1 = wnv - 1; xb = wxb;
-                V = vs + 3 * (wvb - cv0) + (ro ? ro->vskew * w : 0);
-                xi = xs + (xb - x0);
-                g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
+#pragma unroll
+                for (int j = 0; j < WPF; j++)                              // the vertices fetched in front of the poll
+                    if (sub + 2 * j < nv1w) {
+                        const double dgv = pvx[j] * g0 + pvy[j] * g1 + pvz[j] * g2;
+                        const double gi = pxv[j] * (sc22 * dgv - kq);
+                        if (gs) gs[xbw - x0 + sub + 2 * j] = gi; else g[xbw + sub + 2 * j] = gi;
+                        if (gpub) stg<SH>(gpub + (xbw - x0 + sub + 2 * j), gi, gwt);
+                        t_dg += gi * pdd[j]; t_gg += gi * gi;
+                    }
+                for (int a0 = sub + 2 * WPF; a0 < nv1w; a0 += 8) {         // polytopes with more than 16 vertices: the rest as before
+                    double xv[4], dgv[4], dd[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int a = min(a0 + 2 * j, nv1w - 1);
+                        xv[j] = xiw[a]; dgv[j] = Vw[3 * (a + 1)] * g0 + Vw[3 * (a + 1) + 1] * g1 + Vw[3 * (a + 1) + 2] * g2;
+                        dd[j] = tapped ? dsv[xbw - x0 + a] : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (a0 + 2 * j < nv1w) {
+                            const double gi = xv[j] * (sc22 * dgv[j] - kq);
+                            if (gs) gs[xbw - x0 + a0 + 2 * j] = gi; else g[xbw + a0 + 2 * j] = gi;
+                            if (gpub) stg<SH>(gpub + (xbw - x0 + a0 + 2 * j), gi, gwt);
+                            t_dg += gi * dd[j]; t_xx += xv[j] * xv[j]; t_gg += gi * gi;
+                        }
+                }
             }
-            // with r_a = sc xi_a, sc = 2 / (1 + |xi|^2):  d f / d xi_a = xi_a (2 sc^2 (V_a . g) - 4 gdq / (1 + |xi|^2)^2),
-            // gdq = 2 sc sum_a (V_a . g) xi_a^2  -  so |xi|^2 and the weighted sum come out of ONE pass over the vertices
-            double s2 = 0.0;
-            // the forward map of this evaluation left both sums behind: in LDS (same workgroup, resident caller) or in dp.wq_glob (stage kernels; first pass only)
-            const bool cached_lds = ro && ro->wq, cached = cached_lds || (!ro && dp.wq_glob && w0 == 0);
-            if (wact && cached_lds) { const double *wq = ro->wq + 4 * w; qn = wq[0]; s2 = wq[1] * g0 + wq[2] * g1 + wq[3] * g2; }
-            else if (wact && cached) { qn = r_wq0.x; s2 = r_wq0.y * g0 + r_wq1.x * g1 + r_wq1.y * g2; }
-            if (wact && !cached)
+        } else {
+            // (no sums left behind by a forward map - a caller without dp.wq_glob: the two-pass form of round 2)
+            const double *V = Vw, *xi = xiw;
+            const int nv1 = nv1w, xb = xbw;
+            double qn = 0.0, s2 = 0.0;
+            if (wact)
                 for (int a0 = sub; a0 < nv1; a0 += 8) {                   // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
                     double xv[4], dgv[4];
 #pragma unroll
@@ -1608,7 +1718,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
                         if (a0 + 2 * j < nv1) { const double x2 = xv[j] * xv[j]; qn += x2; s2 += dgv[j] * x2; }
                 }
             FRX_STAMP_AX(30);
-            if (!cached) { qn += dpp_mov<0xB1>(qn); s2 += dpp_mov<0xB1>(s2); }   // pair sums
+            qn += dpp_mov<0xB1>(qn); s2 += dpp_mov<0xB1>(s2);   // pair sums
             const double qp1 = qn + 1.0, iq = 1.0 / qp1, sc = 2.0 * iq;
             const double gdq = 2.0 * sc * s2, kq = 4.0 * gdq * (iq * iq), sc22 = 2.0 * sc * sc;
             FRX_STAMP_AX(31);
