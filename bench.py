@@ -272,11 +272,36 @@ def main():
         p2.initial_guess()
         t_guess = (time.perf_counter() - t_s) * 1e3
         p2.close()
-        r = prob.optimize(params["opt_rel_tol"], x0=x0)
+        one_device = bool(os.environ.get("FRX_BENCH_DEVICE")) and dist is not None
+        if one_device:
+            # Control-flow test of the N-rank job on a 1-GPU box (FRX_BENCH_DEVICE): a resident grid needs the whole chip, so the ranks' plans cannot run side
+            # by side as they do on N devices - they take turns.  What CAN be reproduced of the N-device job is its HOST side: while one rank plans, every
+            # other rank keeps ONE thread spinning (its own mailbox thread would, on a device of its own), under the same CPU quota - the regime VERDICT r4
+            # weak #6 asks about (eight ranks, 16 CPUs).  Per-rank times are reported; `value` and `plan_ms` of such a run are not measurements.
+            import tempfile
+            turn_dir = os.path.join(tempfile.gettempdir(), "frx_bench_turns_" + os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("MASTER_PORT", "0")))
+            os.makedirs(turn_dir, exist_ok=True)
+            dist.barrier()
+            for turn in range(world):
+                flag = os.path.join(turn_dir, f"done_{turn}")
+                if rank == turn:
+                    r = prob.optimize(params["opt_rel_tol"], x0=x0)
+                    open(flag, "w").close()
+                else:
+                    while not os.path.exists(flag): pass                 # busy on purpose (see above)
+                dist.barrier()
+            if rank == 0:
+                import shutil; shutil.rmtree(turn_dir, ignore_errors=True)
+        else:
+            r = prob.optimize(params["opt_rel_tol"], x0=x0)
+        per_rank = [[r["ms_total"], float(r["rounds"])]]
         if dist:                                                         # the job's plan time is the slowest rank's
-            tm = torch.tensor([r["ms_total"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            r["ms_total"] = float(tm.item())
+            mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cuda")
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            per_rank = [[float(v[0].item()), float(v[1].item())] for v in allv]
+            r["ms_total"] = max(v[0] for v in per_rank) if not one_device else sum(v[0] for v in per_rank)
+        r["per_rank"] = per_rank; r["one_device"] = one_device
         # winner selection across ranks (the only exchange in the whole job): all-gather (cost, id), broadcast coefficients
         from fast_racing_amd.dist import select_winner
         ids = np.arange(rank * B, rank * B + B)
@@ -428,6 +453,18 @@ def main():
                 "plan_path": ("resident round kernel, %d workgroups per candidate, %d clusters%s" % (r["resident"], r["clusters"], " (work queue)" if r["clusters"] < B else "")) if r["resident"] else "one launch per stage and round",
                 "plan_clusters": int(r["clusters"]),
                 "plan_us_per_round": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
+        # the host budget the plan ran under (frx_api.cpp host_cpu_share): CPUs of the process (cgroup quota / affinity), this rank's share, mailbox threads
+        import ctypes as _C
+        b_, s_, t_ = _C.c_double(), _C.c_int(), _C.c_int()
+        frx.lib().frx_debug_host_cpu_share(int(r["clusters"]) or B, (world - 1) if lib_mode else 0, _C.byref(b_), _C.byref(s_), _C.byref(t_))
+        plan.update({"plan_host_cpus": b_.value, "plan_host_cpu_share_of_this_rank": s_.value, "plan_mailbox_threads": t_.value, "local_world_size": os.environ.get("LOCAL_WORLD_SIZE")})
+        if world > 1 and not lib_mode:
+            plan["plan_ms_per_rank"] = [v[0] for v in r["per_rank"]]
+            plan["plan_us_per_round_per_rank"] = [1e3 * v[0] / max(v[1], 1.0) for v in r["per_rank"]]
+            if r["one_device"]:
+                plan["plan_us_per_round"] = plan["plan_us_per_round_per_rank"][0]
+                plan["one_device_test"] = ("all ranks on ONE device (FRX_BENCH_DEVICE): the plans take turns (a resident grid needs the whole chip) while every waiting rank keeps one host "
+                                           "thread spinning like its own mailbox thread would - the host side of the N-device job under this box's CPU quota; value and plan_ms are NOT measurements")
         if rank == 0:
             plan.update({"plan_ms_per_stage_path": r_ps["ms_total"], "plan_rounds_per_stage_path": r_ps["rounds"],
                          "plan_ms_one_candidate": r_b1["ms_total"], "plan_rounds_one_candidate": r_b1["rounds"],

@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
 # diagnostics, include/frx_debug.h: not part of the drop-in boundary
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
-    "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables",
+    "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share",
 ]
 
 _lib = None

@@ -119,6 +119,9 @@ double host_cpu_budget() {
     if (const char *e = std::getenv("FRX_HOST_CPUS")) { const double v = std::atof(e); if (v > 0.0) cpus = v; }   // (tests, experiments)
     return std::max(1.0, cpus);
 }
+int host_cpu_share();
+// mailbox service threads of a resident plan with S clusters (the caller included): one per sixteen clusters, at most four, and at most share - 1
+int mailbox_threads(int S) { return std::max(1, std::min(std::max(1, std::min(4, S / 16)), host_cpu_share() - 1)); }
 int host_cpu_share() {
     int ranks = 1;
     if (const char *e = std::getenv("FRX_LOCAL_RANKS")) ranks = std::max(1, std::atoi(e));
@@ -1098,14 +1101,11 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     // (25.2-25.4 us at 32 clusters, profiles/r04_host_threads.txt) - a scan of 16 mailboxes and the line-search step of those that answered take a few
     // microseconds of a 25 us round - and every one of them SPINS for the length of the plan: under a CPU quota (the GPU boxes of this project run the
     // process with 16 CPUs' worth) eight ranks of a node with nine spinning threads each are throttled to a crawl, eight ranks with two are not.
-    int nsrv = std::max(1, std::min(4, S / 16));
-    {   // ... and no more of them than this plan's share of the CPUs the process may use: cgroup quota and affinity mask, divided by
-        // the plans that spin next to this one - the other ranks of the node (LOCAL_WORLD_SIZE, set by torch.distributed.run; FRX_LOCAL_RANKS overrides)
-        // and the other shards of a frx_multi job in this process - minus one CPU for the rank's main (interpreter) thread.  Eight ranks under the GPU
-        // boxes' quota of 16 CPUs: the caller alone serves the mailboxes (one thread measures the same round as eight, profiles/r04_host_threads.txt).
-        const int share = frx::host_cpu_share();
-        nsrv = std::max(1, std::min(nsrv, share - 1));
-    }
+    // ... and no more of them than this plan's share of the CPUs the process may use: cgroup quota and affinity mask, divided by
+    // the plans that spin next to this one - the other ranks of the node (LOCAL_WORLD_SIZE, set by torch.distributed.run; FRX_LOCAL_RANKS overrides)
+    // and the other shards of a frx_multi job in this process - minus one CPU for the rank's main (interpreter) thread.  Eight ranks under the GPU
+    // boxes' quota of 16 CPUs: the caller alone serves the mailboxes (one thread measures the same round as eight, profiles/r04_host_threads.txt).
+    int nsrv = frx::mailbox_threads(S);
     if (const char *se = std::getenv("FRX_RESIDENT_HOST_THREADS")) nsrv = std::max(1, std::min(std::atoi(se), S));
     std::atomic<int> abort_code{0};                                                  // 1 = device gave up, 2 = host deadline
     const int scan_pause = [] { const char *e = std::getenv("FRX_RESIDENT_SCAN_PAUSE"); return e ? std::max(0, std::atoi(e)) : 0; }();   // extra pauses between two scans of a thread's mailboxes (experiments)
@@ -1489,6 +1489,15 @@ int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
     const int rows = (int)(p->trace.size() / 7);
     if (out) std::memcpy(out, p->trace.data(), sizeof(double) * 7 * (size_t)std::min(rows, std::max(cap_rows, 0)));
     return rows;
+}
+
+int frx_debug_host_cpu_share(int clusters, int extra_plans, double *budget, int *share, int *mailbox_threads) {
+    frx::concurrent_plans_hint(extra_plans);
+    if (budget) *budget = frx::host_cpu_budget();
+    if (share) *share = frx::host_cpu_share();
+    if (mailbox_threads) *mailbox_threads = frx::mailbox_threads(std::max(1, clusters));
+    frx::concurrent_plans_hint(-extra_plans);
+    return FRX_OK;
 }
 
 int frx_optimize_stats(const frx_problem *p, double *out4) {

@@ -1034,7 +1034,15 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
         }
     }
-    __syncthreads();
+    // Resident caller, <= 64 pieces, soft total time, <= 64 coarse pieces: the two workgroup barriers in front of the matrix wave order NOTHING - nothing is
+    // staged (x and the polytopes live in LDS), the durations are produced (threads i < cN) and consumed (threads k < N) by wave 0 alone, whose LDS
+    // operations complete in order, and the axis waves read Tf and the step counter only behind the barrier they share with the matrix wave.
+#if defined(FRX_FWD_SKIPB)
+    const bool skipb = ro != nullptr && nrow == 64 && nthr == 256 && dp.soft && cN <= 64;
+#else
+    const bool skipb = false;
+#endif
+    if (!skipb) __syncthreads();
     FRX_STAMP(1);
 
     // forwardT (CPU.hpp:626-676)
@@ -1053,7 +1061,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         Tc[Ms1] = 1.0 - sum;
         for (int i = 0; i <= Ms1; i++) Tc[i] *= dp.sumT;
     }
-    __syncthreads();
+    if (!skipb) __syncthreads();
     // splitToFineT (CPU.hpp:930-944)
     double hMine = 1.0;
     if (k < N) {

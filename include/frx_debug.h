@@ -64,6 +64,12 @@ int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4
  * ns[9][2][8], f1/f2[9][2][2]; graph_search.h:72-127), generated from rules instead of spelled out; for the parity test. */
 int frx_jps_tables(int *ns3, int *f13, int *f23, int *ns2, int *f12, int *f22);
 
+/* Host CPU budget of a resident plan (frx_api.cpp, host_cpu_share): *budget = CPUs this process may use (affinity mask, cut by the cgroup quota cpu.max);
+ * *share = this plan's part of them when LOCAL_WORLD_SIZE ranks of a node (FRX_LOCAL_RANKS overrides) and `extra_plans` further plans of this process
+ * (the other shards of a frx_multi job) spin next to it; *mailbox_threads = the service threads a resident plan of `clusters` clusters would start
+ * (the caller included): min(one per sixteen clusters, at most four; share - 1), at least one.  FRX_HOST_CPUS overrides the budget (tests). */
+int frx_debug_host_cpu_share(int clusters, int extra_plans, double *budget, int *share, int *mailbox_threads);
+
 #ifdef __cplusplus
 }
 #endif

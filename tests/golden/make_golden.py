@@ -61,11 +61,15 @@ def build(name):
     return out
 
 
-def build_refvs(sid=25, N=16, gates=4, kappa=8):
+# the reference's OWN vertex order and outputs: a small case, and the benchmarked size with obstacle planes (64 pieces x kappa 16, K_i = 8 ... 14)
+REFVS_CASES = {"refvs_n16_k8_obst": (25, 0, 16, 4, 8), "refvs_n64_k16_obst": (0, 3, 64, 16, 16)}
+
+
+def build_refvs(sid=25, pid=0, N=16, gates=4, kappa=8):
     """The `Candidate` overload of INTEGRATION.md 2: the caller keeps geoutils::enumerateVs on the reference side and hands the vertices over.
     The V-polytopes here are the REFERENCE's own (its Seidel LP + quickhull order, geoutils.hpp:43-149 - NOT the lexicographic order of
     frx_enumerate_vertices), so x lives in the reference's xi parameterisation; ref_* are the reference's outputs in that parameterisation."""
-    cand = sc.make_candidate(sid, N, gates, obstacles=True)
+    cand = sc.make_candidate(sid, N, gates, perturb_id=pid, obstacles=True)
     R = ob.Reference(cand, sc.ZHANGJIAJIE, override_vs=False, qd_intervals=kappa)          # its own enumerateVs
     vs = [R.vpoly(m) for m in range(2 * N - 1)]
     cand_r = sc.Candidate(cand.ini_state, cand.fin_state, cand.h_polys, vs, cand.gates)
@@ -79,7 +83,7 @@ def build_refvs(sid=25, N=16, gates=4, kappa=8):
     ro = o.optimize(1e-6, x0=x0)
     v_off = np.cumsum([0] + [v.shape[1] for v in vs]).astype(np.int32)
     differs = sum(int(v.shape != w.shape or np.abs(v - w).max() > 1e-6) for v, w in zip(vs, cand.v_polys))
-    return dict(case=np.array([sid, 0, N, gates, kappa, 1]), v_off=v_off, v_rec=np.concatenate([v.T.reshape(-1) for v in vs]), x=np.array(xs),
+    return dict(case=np.array([sid, pid, N, gates, kappa, 1]), v_off=v_off, v_rec=np.concatenate([v.T.reshape(-1) for v in vs]), x=np.array(xs),
                 ref_x0=x0, ref_f=np.array(rf), ref_g=np.array(rg), ref_T=np.array(rT), ref_C=np.array(rC),
                 opt_obj=np.array(ro["objective"]), opt_status=np.array(ro["status"]), opt_iters=np.array(ro["iters"]),
                 polytopes_in_another_order_than_the_library=np.array(differs))
@@ -115,9 +119,13 @@ if __name__ == "__main__":
     if "--corridor-only" in sys.argv:
         sys.exit(0)
     if ob.ref_gcopter() is not None:
-        d = build_refvs()
-        np.savez_compressed(os.path.join(os.path.dirname(__file__), "refvs_n16_k8_obst.npz"), **d)
-        print("refvs_n16_k8_obst: f =", d["ref_f"], "polytopes whose vertex order differs from frx_enumerate_vertices:", int(d["polytopes_in_another_order_than_the_library"]), "of", len(d["v_off"]) - 1)
+        for name, args in REFVS_CASES.items():
+            if "--refvs-new-only" in sys.argv and os.path.exists(os.path.join(os.path.dirname(__file__), name + ".npz")): continue
+            d = build_refvs(*args)
+            np.savez_compressed(os.path.join(os.path.dirname(__file__), name + ".npz"), **d)
+            print(name, ": f =", d["ref_f"], "polytopes whose vertex order differs from frx_enumerate_vertices:", int(d["polytopes_in_another_order_than_the_library"]), "of", len(d["v_off"]) - 1)
+    if "--refvs-new-only" in sys.argv:
+        sys.exit(0)
     for name in CASES:
         d = build(name)
         np.savez_compressed(os.path.join(os.path.dirname(__file__), name + ".npz"), **d)

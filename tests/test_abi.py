@@ -82,3 +82,33 @@ def test_cpp_mirror_header_compiles_and_links(frx, tmp_path):
 def test_multi_create_fails_loudly_without_device(frx, sc):
     with pytest.raises(frx.FrxError, match="no HIP device"):
         frx.MultiProblem(sc.make_batch(0, 2, 8, 2), sc.ZHANGJIAJIE, qd_intervals=8)
+
+
+def test_mailbox_threads_follow_the_cpu_share_of_the_plan(frx, monkeypatch):
+    """the mailbox threads of a resident plan spin for its whole length, so their number follows the plan's share of the CPUs the
+    process may use - cgroup quota / affinity, divided by the ranks of the node (LOCAL_WORLD_SIZE) and the shards of a frx_multi job - minus one for the
+    rank's main thread, never more than one per sixteen clusters (at most four).  FRX_HOST_CPUS stands in for the quota here."""
+    import ctypes as C
+    L = frx.lib()
+
+    def ask(clusters, extra=0):
+        b, s, t = C.c_double(), C.c_int(), C.c_int()
+        assert L.frx_debug_host_cpu_share(clusters, extra, C.byref(b), C.byref(s), C.byref(t)) == 0
+        return b.value, s.value, t.value
+
+    for var in ("FRX_LOCAL_RANKS", "LOCAL_WORLD_SIZE", "FRX_HOST_CPUS"):
+        monkeypatch.delenv(var, raising=False)
+    b, s, t = ask(32)
+    assert b >= 1.0 and s == int(b) and 1 <= t <= 2
+    monkeypatch.setenv("FRX_HOST_CPUS", "16")                       # the GPU boxes' quota
+    assert ask(32) == (16.0, 16, 2) and ask(64)[2] == 4 and ask(1)[2] == 1      # one rank: one thread per sixteen clusters, at most four
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")                     # eight ranks of a node: two CPUs each - the caller alone serves its mailboxes
+    assert ask(32) == (16.0, 2, 1)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert ask(32) == (16.0, 4, 2) and ask(64)[2] == 3
+    monkeypatch.setenv("FRX_LOCAL_RANKS", "2")                      # overrides the launcher's variable
+    assert ask(64) == (16.0, 8, 4)
+    monkeypatch.delenv("FRX_LOCAL_RANKS"); monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert ask(32, extra=7) == (16.0, 2, 1)                         # frx_multi: eight shards planning side by side in one process
+    monkeypatch.setenv("FRX_HOST_CPUS", "1")
+    assert ask(32)[1:] == (1, 1)

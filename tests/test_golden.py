@@ -91,8 +91,11 @@ def test_device_reproduces_golden(path, frx, sc):
 
 
 # ---- the `Candidate` overload with the REFERENCE's vertices: a problem in the reference's own xi parameterisation ----
-def _refvs_case(sc):
-    d = np.load(os.path.join(sys_path, "refvs_n16_k8_obst.npz"))
+REFVS = ["refvs_n16_k8_obst", "refvs_n64_k16_obst"]          # the second: the benchmarked size (64 pieces x kappa 16) with obstacle planes, K_i = 8 ... 14
+
+
+def _refvs_case(sc, name="refvs_n16_k8_obst"):
+    d = np.load(os.path.join(sys_path, name + ".npz"))
     sid, pid, N, gates, kappa, obst = (int(v) for v in d["case"])
     cand = sc.make_candidate(sid, N, gates, perturb_id=pid, obstacles=bool(obst))
     vs = [d["v_rec"][3 * d["v_off"][m]:3 * d["v_off"][m + 1]].reshape(-1, 3).T.copy() for m in range(2 * N - 1)]
@@ -100,8 +103,9 @@ def _refvs_case(sc):
     return d, sc.Candidate(cand.ini_state, cand.fin_state, cand.h_polys, vs, cand.gates), kappa
 
 
-def test_oracle_and_host_setup_in_the_references_vertex_order(sc, ob, frx):
-    d, cand, kappa = _refvs_case(sc)
+@pytest.mark.parametrize("name", REFVS)
+def test_oracle_and_host_setup_in_the_references_vertex_order(sc, ob, frx, name):
+    d, cand, kappa = _refvs_case(sc, name)
     o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa)
     assert rel(o.initial_guess(), d["ref_x0"]) < 1e-12
     for s, x in enumerate(d["x"]):
@@ -114,10 +118,11 @@ def test_oracle_and_host_setup_in_the_references_vertex_order(sc, ob, frx):
 
 
 @pytest.mark.gpu
-def test_device_plans_in_the_references_vertex_order(frx, sc):
+@pytest.mark.parametrize("name", REFVS)
+def test_device_plans_in_the_references_vertex_order(frx, sc, name):
     """frx_problem_create with the vertices geoutils::enumerateVs produced (fixture): initial guess, objective, gradient and coefficients equal the
     REFERENCE's own numbers in its parameterisation; a plan from there ends with the oracle's verdict at the oracle's objective level."""
-    d, cand, kappa = _refvs_case(sc)
+    d, cand, kappa = _refvs_case(sc, name)
     prob = frx.Problem([cand], sc.ZHANGJIAJIE, qd_intervals=kappa)
     x0 = prob.initial_guess()
     assert rel(x0, d["ref_x0"]) < 1e-12

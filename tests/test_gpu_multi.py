@@ -91,3 +91,32 @@ def test_config3_whole_eight_shards_on_one_device(frx, sc):
     assert np.array_equal(r["winner_C"], r["C"][6 * sl.start:6 * sl.stop]) and np.array_equal(r["winner_T"], r["T"][sl])
     print("config[3] whole on one device: winner", best, "failed", int(np.sum(r["status"] < 0)))
     mp.close()
+
+
+def test_bench_eight_ranks_control_flow_on_one_device():
+    """`bench.py --gpus 8` as the driver's scaling run starts it - eight ranks, one process each - with every rank on device 0 and gloo in place of RCCL
+    (FRX_BENCH_DEVICE / FRX_BENCH_BACKEND: the 1-GPU-box knobs).  Checks the control flow of the N-rank job (self-launch, timed loop, every rank's plan, the
+    winner exchange, rank-0-only legs behind the end of the process group) and the host budget: under the box's CPU quota each rank
+    serves its mailboxes with the threads its share allows, and a rank's round is not slower than a lone rank's by more than the boxes' own scatter allows."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"FRX_BENCH_DEVICE": "0", "FRX_BENCH_BACKEND": "gloo"})
+    args = ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--large-batch", "0"]
+    p8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p8.returncode == 0, p8.stderr[-3000:]
+    d8 = json.loads([l for l in p8.stdout.splitlines() if l.startswith("{")][-1])
+    env1 = {k: v for k, v in env.items() if k not in ("FRX_BENCH_DEVICE", "FRX_BENCH_BACKEND")}
+    p1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + args, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    d1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "bench_8ranks_one_device.json"), "w") as f: f.write(json.dumps(d8) + "\n" + json.dumps(d1) + "\n")
+    assert d8["n_gpus"] == 8 and "one_device_test" in d8 and d8["plan_status_ok"] == 32 and len(d8["plan_us_per_round_per_rank"]) == 8
+    assert d8["plan_path"].startswith("resident") and d1["plan_path"].startswith("resident")
+    quota = d8["plan_host_cpus"]
+    assert d8["local_world_size"] == "8" and d8["plan_host_cpu_share_of_this_rank"] == max(1, int(quota / 8)) and d8["plan_mailbox_threads"] == max(1, min(2, int(quota / 8) - 1))
+    lone = d1["plan_us_per_round"]
+    worst = max(d8["plan_us_per_round_per_rank"])
+    print(json.dumps({"us_per_round_lone_rank": lone, "us_per_round_per_rank_of_8": d8["plan_us_per_round_per_rank"], "host_cpus": quota, "mailbox_threads_per_rank": d8["plan_mailbox_threads"]}))
+    assert worst <= 1.10 * lone, (worst, lone)

@@ -150,8 +150,12 @@ def test_optimize_short_run_tracks_oracle(frx, sc, ob):
     prob.close()
 
 
-@pytest.mark.parametrize("N,gates,kappa,obst", [(32, 8, 8, False), (24, 6, 16, True), (64, 16, 16, False)])   # last: one headline candidate
-def test_lockstep_parity_along_the_whole_optimisation(frx, sc, ob, N, gates, kappa, obst):
+# (sid, pid): scenario and gate perturbation.  Rows 3-7 are the benchmarked size (VERDICT r4 missing 4): FOUR candidates of the very batch bench.py
+# plans (scenario 0, perturbations 0 .. 3, K_i = 8) and the headline geometry with obstacle planes (K_i = 8 ... 14, the n64_k16_obst fixture's candidate)
+@pytest.mark.parametrize("N,gates,kappa,obst,sid,pid", [(32, 8, 8, False, 1, 0), (24, 6, 16, True, 1, 0), (64, 16, 16, False, 1, 0),
+                                                        (64, 16, 16, False, 0, 0), (64, 16, 16, False, 0, 1), (64, 16, 16, False, 0, 2), (64, 16, 16, False, 0, 3),
+                                                        (64, 16, 16, True, 0, 3)])
+def test_lockstep_parity_along_the_whole_optimisation(frx, sc, ob, N, gates, kappa, obst, sid, pid):
     """End-to-end contract (north_star: optimised MINCO coefficients within 1e-6 relative of the CPU path on
     identical inputs), in its well-posed form.
 
@@ -162,7 +166,7 @@ def test_lockstep_parity_along_the_whole_optimisation(frx, sc, ob, N, gates, kap
     the device evaluates the same points: f and grad must agree at each of them (<= 1e-9), and the coefficients
     the device generates at the CPU's final iterate must equal the CPU's optimised coefficients (<= 1e-6;
     measured ~1e-12 with the banded kernels, <= 1e-8 with the knot form)."""
-    cand = sc.make_candidate(1, N, gates, obstacles=obst)
+    cand = sc.make_candidate(sid, N, gates, perturb_id=pid, obstacles=obst)
     o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa)           # faithful CPU path (s1 += step)
     ref = o.optimize_traced(sc.ZHANGJIAJIE["opt_rel_tol"])
     pts = ref["trace"]
