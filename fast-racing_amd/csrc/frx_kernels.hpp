@@ -1316,6 +1316,359 @@ __global__ __launch_bounds__(256) void k_forward_knot64(DevProblem dp, const dou
 // collects the line-search sums.  Before: every phase on wave 0 for all three axes in turn, eight workgroup barriers and the
 // knot arrays through LDS in between - 21 k cycles, of which 5.5 k + 6.7 k in the knot adjoint and the layers.
 // ---------------------------------------------------------------------------------------------
+// The same adjoint in the order of rounds 2-4, for the STAGE kernels (no poll for the penalty partials: everything is loaded up front and the scheduler
+// orders one straight-line body itself).  The resident form below - the partial-independent work hoisted in front of the poll by hand - measured 0.4 us
+// SLOWER as a stage kernel (8.00 against 7.62 us, build against build on one box, round 5), so each caller keeps the order that suits it; the arithmetic
+// is expression for expression the same.
+template <bool SH>
+__device__ __forceinline__ void backward_knot_wsp64_stage(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
+                                const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
+                                double *__restrict__ g, int maxCN, int maxXb, int maxVb, const double *__restrict__ pcrw, int nsteps,
+                                const LineSearchTap &tap, int b, double *sm, const double *ct_lds, const ResidentOps *ro) {
+    const int nrow = 64, nthr = 256;
+    const int k = threadIdx.x, kk = k & 63, t2 = k - 64;
+    const int wave = __builtin_amdgcn_readfirstlane(k >> 6);
+    const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
+    const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
+    const int x0 = dp.xoff[b];
+    double *rowbuf = sm;
+    double *KP = rowbuf + (size_t)36 * nrow;          // d f / d q_k per axis (for the waypoint layer)
+    double *KV = KP + 3 * (nrow + 1);                 // duration adjoint of piece k, one row per axis
+    double *KA = KV + 3 * (nrow + 1);
+    double *Tf = KA + 3 * (nrow + 1);
+    double *gT = Tf + nrow;
+    double *gCo = gT + nrow;
+    double *red = gCo + maxCN;
+    double *xs = red + 2 * (nthr >> 6) + 2;
+    double *vs = xs + maxXb;
+    double *pw = vs + maxVb;                            // [nrow][nsteps*8+5] multipliers saved by the forward pass
+    double *dsv = pw + (size_t)(nsteps * 8 + 5) * nrow; // [maxXb] search direction (only with a line-search tap)
+    double *gs = nullptr, *gpub = nullptr;
+    bool gwt = true;
+    if (ro) { xs = ro->xs; vs = ro->vs; dsv = ro->dsv; pw = ro->pw; gs = ro->gs; gpub = ro->gpub; gwt = ro->gwt; }
+    const int pws = nsteps * 8 + 5;
+    // A resident caller that reads the host's command word while this body runs (tap.early_cmd) must find thread 0's wave WITHOUT stores of
+    // its own behind that read: vmcnt retires in order and the compiler can only wait for the read with vmcnt(0), i.e. for the acknowledgement
+    // of every younger store as well - measured as 1.2 us at the end of the adjoint with four clusters on an XCD, time the leader otherwise
+    // spends on the line search before its next publication drains them anyway.  The time gradient's copy for the cluster (`gpub`) is
+    // therefore stored by wave 1 from the LDS copy, behind the last barrier.
+    const bool defer_time_gpub = gs != nullptr && gpub != nullptr && tap.early_cmd != nullptr;
+    const bool tapped = tap.d != nullptr;
+    const int tap_flags = (tapped && tap.flags) ? tap.flags[b] : 0;   // consumed by thread 0 at the very end
+    double t_dg = 0.0, t_xx = 0.0, t_gg = 0.0;          // g.d, x.x, g.g over the elements this thread writes
+    FRX_STAMP(16);
+    // ---- all global reads up front ----
+    const bool piece = kk < N;
+    const int kp = piece ? kk : 0;                      // clamped piece index: loads are unconditional, results of lanes without a piece unused
+    double h, o0 = 0.0, o1 = 0.0, c9[9], cq[6], cbq[6], r_tl[3] = {0, 0, 0};
+    int r_wnv = 1, r_wvb = 0, r_wxb = 0, r_iv = 1, r_fb = 0;
+    const int cv0 = __builtin_amdgcn_readfirstlane(dp.cvoff[b]);     // (up here with the other loads: see forward_knot_body)
+    double2 r_wq0 = make_double2(0.0, 0.0), r_wq1 = r_wq0;   // the forward map's sums of this pair's waypoint (stage kernels: through dp.wq_glob)
+    {
+        const double *ci = Cin + (size_t)(p0 + kp) * 18;
+        const double *o = out20 + (size_t)(p0 + kp) * 20;
+        h = ct_lds ? ct_lds[kp * 19 + 18] : ldg<SH>(Tin + p0 + kp);
+        const bool o_ll = SH && ro && ro->o20ll;                             // resident caller: the penalty partials arrive as granules (rk_ll_put in penalty_reduce), polled below
+        if (wave == 0) {
+            if (!o_ll) { o0 = ldg<SH>(o); o1 = ldg<SH>(o + 1); }
+            // (the coarse-interval table of mergeToCoarseGradT too: loaded behind the barrier below, these two sat BEHIND the resident
+            // caller's read of the host's command word - vmcnt retires in order - and wave 0 waited out a PCIe round trip for them)
+            if (kk < cN) { r_iv = dp.coarse_iv[c0 + kk]; r_fb = dp.coarse_fbeg[c0 + kk] - p0; }
+#pragma unroll
+            for (int q = 0; q < 9; q++) c9[q] = ct_lds ? ct_lds[kp * 19 + 9 + q] : ldg<SH>(ci + 9 + q);
+        } else {
+            const int ax = wave - 1;
+#pragma unroll
+            for (int q = 0; q < 6; q++) { if (!o_ll) cbq[q] = ldg<SH>(o + 2 + q * 3 + ax); cq[q] = ct_lds ? ct_lds[kp * 19 + q * 3 + ax] : ldg<SH>(ci + q * 3 + ax); }
+            r_tl[0] = dp.tailPVA[b * 9 + ax]; r_tl[1] = dp.tailPVA[b * 9 + 3 + ax]; r_tl[2] = dp.tailPVA[b * 9 + 6 + ax];
+            if ((t2 >> 1) < N - 1) {                                // pair t2 >> 1 = waypoint
+                const int gw = p0 - b + (t2 >> 1);
+                r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw];
+                if (!ro && dp.wq_glob) { const double2 *wq = (const double2 *)(dp.wq_glob + 4 * (size_t)gw); r_wq0 = wq[0]; r_wq1 = wq[1]; }
+            }
+        }
+    }
+    if (SH && ro && ro->o20ll) {
+        // Resident caller: the 20 partials of piece kp arrive as granules tagged with the number of this evaluation; lane kk of wave 0 polls {cost, d/dT},
+        // lane kk of an axis wave its six d/dc - the workgroups that integrate the penalty neither drain nor count in front of this read, and the leader
+        // does not wait for them before it calls this body.  Bounded: an expired wait records RK_ERR_ARRIVE (4) in the launch's status word.
+        const ll_u64 *og = ro->o20ll + 40 * (size_t)(p0 + kp);
+        const unsigned tg = ro->o20tag;
+        const ll_u64 t_end = (ll_u64)wall_clock64() + ro->spin_ticks;
+        constexpr int NG = 6;
+        ll_u64 w[NG][2];
+        const int ng = wave == 0 ? 2 : 6, gbase = wave == 0 ? 0 : 2 + (wave - 1), gstep = wave == 0 ? 1 : 3;
+        for (unsigned spins = 0;; spins++) {
+#pragma unroll
+            for (int q = 0; q < NG; q++) {
+                const ll_u64 *g2 = og + 2 * (gbase + gstep * (q < ng ? q : ng - 1));
+                w[q][0] = __hip_atomic_load(g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); w[q][1] = __hip_atomic_load(g2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool all = true;
+#pragma unroll
+            for (int q = 0; q < NG; q++) all = all && rk_ll_ok(w[q][0], w[q][1], tg);
+            if (all) break;
+            if ((spins & 31u) == 31u && (__hip_atomic_load(ro->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || (ll_u64)wall_clock64() > t_end)) {
+                unsigned expect = 0u;
+                __hip_atomic_compare_exchange_strong(ro->status, &expect, 4u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (wave == 0) { o0 = rk_ll_value(w[0][0], w[0][1]); o1 = rk_ll_value(w[1][0], w[1][1]); }
+        else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) cbq[q] = rk_ll_value(w[q][0], w[q][1]);
+        }
+    }
+    if (!ro) {
+        const int nx = dp.xoff[b + 1] - x0;
+        const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
+        stage_to_lds<4>(xs, x + x0, nx, k, nthr);
+        stage_to_lds<8>(vs, dp.vrec + 3 * (size_t)v0, nvd, k, nthr);
+        if (tapped) stage_to_lds<4>(dsv, tap.d + x0, nx, k, nthr);
+        // saved multipliers of this candidate: one contiguous block, 16-byte loads by all threads (a single batch)
+        const int ws = nsteps * 8 + 4, n2 = (N * ws) >> 1;                 // ws is even
+        const double2 *src = (const double2 *)(pcrw + (size_t)p0 * ws);
+        for (int i0 = k; i0 < n2; i0 += 8 * nthr) {
+            double2 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i2 = i0 + u * nthr; tmp[u] = src[i2 < n2 ? i2 : n2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i2 = i0 + u * nthr;
+                if (i2 < n2) {
+                    const int e = 2 * i2, kn = e / ws, ff = e - kn * ws;        // ws even: both halves belong to the same knot
+                    pw[kn * (ws + 1) + ff] = tmp[u].x; pw[kn * (ws + 1) + ff + 1] = tmp[u].y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    FRX_STAMP(17);
+    double costAcc = 0.0, gTl = 0.0;
+    unsigned long long early_word = 0, early_step = 0;
+    if (wave == 0) {
+        // ---- jerk energy + its duration gradient (CPU.hpp:507-520, 65-75) on top of the penalty partials ----
+        if (piece) {
+            Tf[kk] = h;
+            const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
+            const double *c3 = c9, *c4 = c9 + 3, *c5 = c9 + 6;
+            const double s33 = dot3(c3, c3), s43 = dot3(c4, c3), s44 = dot3(c4, c4), s53 = dot3(c5, c3), s54 = dot3(c5, c4), s55 = dot3(c5, c5);
+            costAcc = o0 + (36.0 * s33 * t1 + 144.0 * s43 * t2_ + 192.0 * s44 * t3 + 240.0 * s53 * t3 + 720.0 * s54 * t4 + 720.0 * s55 * t5);
+            gTl = o1 + (36.0 * s33 + 288.0 * s43 * t1 + 576.0 * s44 * t2_ + 720.0 * s53 * t2_ + 2880.0 * s54 * t3 + 3600.0 * s55 * t4);
+        }
+        // Every load of this wave has to have LANDED before the read over PCIe is issued, and no later instruction may wait on vmcnt: the
+        // compiler waits for a loaded register at its first use, with vmcnt(0) when a conditional load may lie in between - for the
+        // coarse-interval table that use is the merge loop behind the barrier below, and the wait took the host read's round trip with it
+        // (s_waitcnt vmcnt(0) in front of the loop in the ISA, even with the values passed through an in/out asm).  The table entry
+        // therefore travels through LDS: lane kk parks it in gCo[kk], which the same lane overwrites with its result.
+        if (kk < cN) gCo[kk] = (double)(r_iv + (r_fb << 10));
+        if (tap.early_cmd && k == 0) { early_word = __hip_atomic_load(tap.early_cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); early_step = __hip_atomic_load(tap.early_cmd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // behind the wave's first loads (see LineSearchTap)
+    } else {
+        const int ax = wave - 1;
+        const bool act = kk >= 1 && kk <= N - 1;
+        const int kc = act ? kk : 1;
+        FRX_STAMP_AX(25);
+        // ---- cbar = d f / d c of this axis: penalty part + jerk energy (CPU.hpp:84-92) ----
+        {
+            const double t1 = h, t2_ = t1 * t1, t3 = t2_ * t1, t4 = t2_ * t2_, t5 = t4 * t1;
+            cbq[3] += 72.0 * cq[3] * t1 + 144.0 * cq[4] * t2_ + 240.0 * cq[5] * t3;
+            cbq[4] += 144.0 * cq[3] * t2_ + 384.0 * cq[4] * t3 + 720.0 * cq[5] * t4;
+            cbq[5] += 240.0 * cq[3] * t3 + 720.0 * cq[4] * t4 + 1440.0 * cq[5] * t5;
+        }
+        // knot states recovered from the coefficients: p = c0, v = c1, a = 2 c2 at the piece start; the next knot's from the next lane
+        const double P0 = cq[0], V0 = cq[1], A0 = 2.0 * cq[2];
+        double P1 = lane_down1(P0), V1 = lane_down1(V0), A1 = lane_down1(A0);
+        if (kk == N - 1) { P1 = r_tl[0]; V1 = r_tl[1]; A1 = r_tl[2]; }
+        // ---- Hermite adjoint of the piece; its end-of-piece parts belong to the next knot (= next lane) ----
+        double db[6] = {0, 0, 0, 0, 0, 0}, hb = 0.0;
+        if (piece) hermite_adjoint(h, P0, V0, A0, P1, V1, A1, cbq, db, hb);
+        const double ePu = lane_up1(db[3]), eVu = lane_up1(db[4]), eAu = lane_up1(db[5]);
+        double r0 = 0.0, r1 = 0.0, pbk = 0.0;
+        if (act) { r0 = db[1] + eVu; r1 = db[2] + eAu; pbk = db[0] + ePu; }      // right-hand side of K mu = wbar; direct d f / d p_k (both adjacent pieces)
+        FRX_STAMP_AX(26);
+        // ---- mu = K^-1 wbar with the multipliers of the forward reduction (K is symmetric), neighbours by lane shifts ----
+        int nst = 0;
+        for (int s = 1; s < N - 1; s <<= 1) nst++;
+        double muv = 0.0, mua = 0.0;                                   // zero at the fixed end knots
+        if (nst <= 6) {
+            // every multiplier of this knot up front (they were all saved by the forward pass): a step is then one lane exchange, not two LDS round trips
+            double ab[6][8], Di[4];
+#pragma unroll
+            for (int st = 0; st < 6; st++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[st][i] = pw[kc * pws + (st < nst ? st : 0) * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) Di[i] = pw[kc * pws + nsteps * 8 + i];
+#pragma unroll
+            for (int st = 0; st < 6; st++)
+                if (st < nst) {
+                    const int s = 1 << st;
+                    const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                    const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+                    const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+                    const double n0 = r0 - (ab[st][0] * l0 + ab[st][1] * l1) - (ab[st][4] * h0 + ab[st][5] * h1);    // pcr_rhs_step
+                    const double n1 = r1 - (ab[st][2] * l0 + ab[st][3] * l1) - (ab[st][6] * h0 + ab[st][7] * h1);
+                    r0 = n0; r1 = n1;
+                }
+            if (act) { muv = Di[0] * r0 + Di[1] * r1; mua = Di[2] * r0 + Di[3] * r1; }
+        } else {
+            for (int st = 0; st < nst; st++) {
+                const int s = 1 << st;
+                const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
+                double ab[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ab[i] = pw[kc * pws + st * 8 + i];
+                const double l0r = __shfl_up(r0, s, 64), l1r = __shfl_up(r1, s, 64), h0r = __shfl_down(r0, s, 64), h1r = __shfl_down(r1, s, 64);
+                const double l0 = inlo ? l0r : 0.0, l1 = inlo ? l1r : 0.0, h0 = inhi ? h0r : 0.0, h1 = inhi ? h1r : 0.0;
+                const double n0 = r0 - (ab[0] * l0 + ab[1] * l1) - (ab[4] * h0 + ab[5] * h1);
+                const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
+                r0 = n0; r1 = n1;
+            }
+            if (act) {
+                const double *Di = pw + kk * pws + nsteps * 8;
+                muv = Di[0] * r0 + Di[1] * r1; mua = Di[2] * r0 + Di[3] * r1;
+            }
+        }
+        FRX_STAMP_AX(27);
+        // ---- through the knot system: duration term and d f / d(p_{k+1} - p_k) ----
+        double mu1v = lane_down1(muv), mu1a = lane_down1(mua);
+        if (kk >= N - 1) { mu1v = 0.0; mu1a = 0.0; }
+        double dlb = 0.0;
+        if (piece) dlb = knot_adjoint_piece(h, P1 - P0, V0, A0, V1, A1, muv, mua, mu1v, mu1a, hb);
+        const double dlu = lane_up1(dlb);                    // + dl of the piece ending at this knot
+        if (piece) KN(KV, ax, kk) = hb;
+        if (act) KN(KP, ax, kk) = pbk + dlu - dlb;                   // d f / d q_k for the pair that owns the waypoint
+        FRX_STAMP_AX(28);
+    }
+    __syncthreads();
+    FRX_STAMP(22);
+    if (wave == 0) {
+        // ---- duration gradient, mergeToCoarseGradT (CPU.hpp:946-959), cost (CPU.hpp:988), addLayerTGrad (CPU.hpp:816-894): all within wave 0 ----
+        if (piece) gT[kk] = gTl + ((KN(KV, 0, kk) + KN(KV, 1, kk)) + KN(KV, 2, kk)) + dp.rho;     // + rho: CPU.hpp:989
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double sumTc = 0.0;
+        if (kk < cN) {
+            const int packed = (int)gCo[kk], iv = packed & 1023, fb = packed >> 10;   // (parked above: see the note at the host read)
+            double sg = 0.0, tt = 0.0;
+            for (int a = 0; a < iv; a++) { sg += gT[fb + a]; tt += Tf[fb + a]; }
+            gCo[kk] = sg / iv;
+            sumTc = tt;
+        }
+        const double wc = wave_sum_dpp(costAcc), wtt = wave_sum_dpp(sumTc);
+        const double fval = wc + dp.rho * wtt;
+        if (kk == 0) { if (!ro) f[b] = fval; red[0] = fval; }             // resident caller: the value travels through the mailbox, nothing to drain
+        if (dp.soft) {
+            if (kk < cN) {
+                const double gi = gCo[kk] * dT_dtau(xs[kk], dp.c2 != 0);
+                if (gs) gs[kk] = gi; else g[x0 + kk] = gi;
+                if (gpub && !defer_time_gpub) stg<SH>(gpub + kk, gi, gwt);
+                if (tapped) { t_dg += gi * dsv[kk]; t_xx += xs[kk] * xs[kk]; t_gg += gi * gi; }
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (kk == 0) {
+                const int Ms1 = cN - 1;
+                const double gTail = dp.sumT * gCo[Ms1];
+                double expTauSum = 0.0, gFreeDotExpTau = 0.0;
+                for (int i = 0; i < Ms1; i++) {
+                    const double e = tau_to_T(xs[i], dp.c2 != 0);
+                    expTauSum += e;
+                    gFreeDotExpTau += e * (dp.sumT * gCo[i]);
+                }
+                const double den = expTauSum + 1.0;
+                for (int i = 0; i < Ms1; i++) {
+                    const double de = dT_dtau(xs[i], dp.c2 != 0);
+                    const double gi = (dp.sumT * gCo[i] - gTail) * de / den - (gFreeDotExpTau - gTail * expTauSum) * de / (den * den);
+                    if (gs) gs[i] = gi; else g[x0 + i] = gi;
+                    if (gpub && !defer_time_gpub) stg<SH>(gpub + i, gi, gwt);
+                    if (tapped) { t_dg += gi * dsv[i]; t_xx += xs[i] * xs[i]; t_gg += gi * gi; }
+                }
+            }
+        }
+    } else {
+        // ---- addPropCtoP + addLayerPGrad (CPU.hpp:154-161, 897-928): waypoint w (= knot w+1) on a PAIR of lanes of the axis waves ----
+        for (int w0 = 0; w0 < N - 1; w0 += 96) {
+            const int w = w0 + (t2 >> 1), sub = t2 & 1;
+            const bool wact = w < N - 1;
+            const double *V = vs, *xi = xs;
+            int nv1 = 0, xb = 0;
+            double g0 = 0.0, g1 = 0.0, g2 = 0.0, qn = 0.0;
+            if (wact) {
+                int wnv = r_wnv, wvb = r_wvb, wxb = r_wxb;
+                if (w0 > 0) { const int gw = p0 - b + w; wnv = dp.wp_nv[gw]; wvb = dp.wp_vbeg[gw]; wxb = dp.wp_xbeg[gw]; }
+                nv1 = wnv - 1; xb = wxb;
+                V = vs + 3 * (wvb - cv0) + (ro ? ro->vskew * w : 0);
+                xi = xs + (xb - x0);
+                g0 = KN(KP, 0, w + 1); g1 = KN(KP, 1, w + 1); g2 = KN(KP, 2, w + 1);
+            }
+            // with r_a = sc xi_a, sc = 2 / (1 + |xi|^2):  d f / d xi_a = xi_a (2 sc^2 (V_a . g) - 4 gdq / (1 + |xi|^2)^2),
+            // gdq = 2 sc sum_a (V_a . g) xi_a^2  -  so |xi|^2 and the weighted sum come out of ONE pass over the vertices
+            double s2 = 0.0;
+            // the forward map of this evaluation left both sums behind: in LDS (same workgroup, resident caller) or in dp.wq_glob (stage kernels; first pass only)
+            const bool cached_lds = ro && ro->wq, cached = cached_lds || (!ro && dp.wq_glob && w0 == 0);
+            if (wact && cached_lds) { const double *wq = ro->wq + 4 * w; qn = wq[0]; s2 = wq[1] * g0 + wq[2] * g1 + wq[3] * g2; }
+            else if (wact && cached) { qn = r_wq0.x; s2 = r_wq0.y * g0 + r_wq1.x * g1 + r_wq1.y * g2; }
+            if (wact && !cached)
+                for (int a0 = sub; a0 < nv1; a0 += 8) {                   // four vertices per trip, their LDS reads in flight together (clamped, not predicated)
+                    double xv[4], dgv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int a = min(a0 + 2 * j, nv1 - 1); xv[j] = xi[a]; dgv[j] = V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (a0 + 2 * j < nv1) { const double x2 = xv[j] * xv[j]; qn += x2; s2 += dgv[j] * x2; }
+                }
+            FRX_STAMP_AX(30);
+            if (!cached) { qn += dpp_mov<0xB1>(qn); s2 += dpp_mov<0xB1>(s2); }   // pair sums
+            const double qp1 = qn + 1.0, iq = 1.0 / qp1, sc = 2.0 * iq;
+            const double gdq = 2.0 * sc * s2, kq = 4.0 * gdq * (iq * iq), sc22 = 2.0 * sc * sc;
+            FRX_STAMP_AX(31);
+            if (wact)
+                for (int a0 = sub; a0 < nv1; a0 += 8) {
+                    double xv[4], dgv[4], dd[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int a = min(a0 + 2 * j, nv1 - 1);
+                        xv[j] = xi[a]; dgv[j] = V[3 * (a + 1)] * g0 + V[3 * (a + 1) + 1] * g1 + V[3 * (a + 1) + 2] * g2;
+                        dd[j] = tapped ? dsv[xb - x0 + a] : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (a0 + 2 * j < nv1) {
+                            const double gi = xv[j] * (sc22 * dgv[j] - kq);
+                            if (gs) gs[xb - x0 + a0 + 2 * j] = gi; else g[xb + a0 + 2 * j] = gi;
+                            if (gpub) stg<SH>(gpub + (xb - x0 + a0 + 2 * j), gi, gwt);
+                            t_dg += gi * dd[j]; t_xx += xv[j] * xv[j]; t_gg += gi * gi;
+                        }
+                }
+        }
+    }
+    FRX_STAMP_AX(29);
+    FRX_STAMP(23);
+    // ---- line-search tap: what lbfgs.hpp:830 (g.d) and :1296-1297 (|x|, |g|) need, reduced here instead of in a separate launch ----
+    if (tap.d != nullptr) {                                           // uniform over the grid
+        const double w0 = wave_sum_dpp(t_dg), w1 = wave_sum_dpp(t_xx), w2 = wave_sum_dpp(t_gg);
+        const int nw = nthr >> 6, w = k >> 6;
+        double *red3 = rowbuf;                                        // the row buffer is not used by this path
+        if ((k & 63) == 0) { red3[w] = w0; red3[nw + w] = w1; red3[2 * nw + w] = w2; }
+        __syncthreads();
+        if (defer_time_gpub && wave == 1 && kk < (dp.soft ? cN : cN - 1)) stg<SH>(gpub + kk, gs[kk], gwt);   // (see defer_time_gpub)
+        if (k == 0 && ((tap_flags & DV_EVAL) || tap.lds_out)) {
+            const double fval = red[0];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int i = 0; i < nw; i++) { a0 += red3[i]; a1 += red3[nw + i]; a2 += red3[2 * nw + i]; }
+            if (tap.lds_out) { tap.lds_out[0] = fval; tap.lds_out[1] = a0; tap.lds_out[2] = a1; tap.lds_out[3] = a2; if (tap.early_cmd) { tap.lds_out[7] = __longlong_as_double((long long)early_word); tap.lds_out[6] = __longlong_as_double((long long)early_step); } }
+            else { DvResult *r = tap.res + b; r->f = fval; r->dg = a0; r->xx = a1; r->gg = a2; }
+        }
+        if (k == 0 && tap.arrive) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the result above is visible before the count moves
+            if (atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
+        }
+    }
+    FRX_STAMP(24);
+}
+
 template <bool SH>
 __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
@@ -1436,7 +1789,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
     constexpr int WPF = 8;
     const int wpt = t2 >> 1, sub = t2 & 1;
     const bool wact0 = wave >= 1 && wpt < N - 1;
-    const bool cached_lds = ro && ro->wq, cached0 = cached_lds || (!ro && dp.wq_glob != nullptr);
+    const bool cached_lds = ro && ro->wq, cached0 = SH || cached_lds || (!ro && dp.wq_glob != nullptr);   // (SH: the resident caller always hands the forward map's sums over - the two-pass form below is not compiled into it)
     const double *Vw = vs, *xiw = xs;
     int nv1w = 0, xbw = 0;
     double qn0 = 0.0, wq1 = 0.0, wq2 = 0.0, wq3 = 0.0, w_c2sc = 0.0, w_iq2 = 0.0, w_sc22 = 0.0;
@@ -1783,7 +2136,8 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
                                 const LineSearchTap &tap, int b, double *sm, const double *ct_lds = nullptr, const ResidentOps *ro = nullptr) {
     const int nrow = NR > 0 ? NR : nrow_rt;
     if (NR == 64 || (NR == 0 && nrow == 64 && blockDim.x == 256)) {              // <= 64 pieces: one wave per axis
-        backward_knot_wsp64<SH>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);
+        if (SH) backward_knot_wsp64<SH>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);       // resident caller: the order built around the poll
+        else backward_knot_wsp64_stage<SH>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);
         return;
     }
     if (NR == 64) return;

@@ -1,7 +1,7 @@
 """Statistics of the resident round's critical path over ~100 rounds of cluster 0 (timeline trace, see round_timeline.py): mean / median / p90 of the
 time between consecutive milestones.   python scripts/r04/round_gaps.py [B] [phase_lo] [n_phases]"""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.abspath(os.environ["FRX_ROOT"]) if os.environ.get("FRX_ROOT") else os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # FRX_ROOT: a variant directory (scripts/r04/make_variant.sh)
 import numpy as np
 from frx_import import frx
 from fast_racing_amd import scenario as sc

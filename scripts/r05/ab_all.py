@@ -52,8 +52,12 @@ res = {r: [] for r in roots}
 for i in range(reps):
     for root in roots:
         try:
-            p = subprocess.run([sys.executable, "-c", child, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            env = dict(os.environ); env["FRX_RESIDENT_HOST_STATS"] = "1"      # per plan on stderr: clusters on one XCD, scans per mailbox thread
+            p = subprocess.run([sys.executable, "-c", child, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240, env=env)
             d = json.loads(p.stdout.strip().splitlines()[-1])
+            import re
+            d["one_xcd"] = [int(a) for a, b in re.findall(r"clusters on one XCD: (\d+) of (\d+)", p.stderr)]
+            d["us_per_scan_thread0"] = [float(x) for x in re.findall(r"mailbox thread 0: .*? = ([0-9.]+) us per scan", p.stderr)]
         except Exception as e:
             d = {"error": repr(e), "stderr": (p.stderr[-400:] if 'p' in dir() else "")}
         res[root].append(d)

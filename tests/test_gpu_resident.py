@@ -157,10 +157,10 @@ def test_resident_plans_end_like_per_stage_plans(frx, sc, ob):
     prob.close()
 
 
-@pytest.mark.parametrize("B", [1, 9])
+@pytest.mark.parametrize("B", [1, 17])
 def test_stock_kappa_48_plans_resident_like_per_stage(frx, sc, B):
     """BASELINE configs[0] geometry - 64 pieces at the STOCK QdIntervals = 48 (zhangjiajie_params.yaml; 49 samples per piece: one piece per wave-task, 64
-    tasks).  One candidate (the reference's real use: 16 workgroups, the tasks fit its 60 member waves in one pass) and nine (eight workgroups per cluster:
+    tasks).  One candidate (the reference's real use: 16 workgroups, the tasks fit its 60 member waves in one pass) and seventeen (eight workgroups per cluster:
     64 tasks on 28 waves = THREE penalty passes per evaluation, the leader's waves included): the first commands agree with the per-stage path to rounding,
     the complete plans end with the same verdicts."""
     cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(B)]
