@@ -349,7 +349,7 @@ def main():
     eval_bytes = int(alg_bytes + np.sum(16 * nx + 24 * nvert))
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
     fp64 = None
-    fc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_fp64_count_k_penalty.json", "r02_fp64_count_k_penalty.json")) if os.path.exists(f)), "")
+    fc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_fp64_count_k_penalty.json", "r04_fp64_count_k_penalty.json", "r02_fp64_count_k_penalty.json")) if os.path.exists(f)), "")
     if os.path.exists(fc):
         fj = json.load(open(fc))
         fl = fj["flops_per_sample_no_violation"]
@@ -360,7 +360,7 @@ def main():
     # read from profiles/, never measured inside this process - hence "from_profile".  FETCH_SIZE / WRITE_SIZE are converted to bytes with the
     # factors calibrated in the same call on a coalesced copy of known size (8-byte and 16-byte accesses per lane).
     traffic, traffic_src, valu, knot_traffic, calib = None, None, None, {}, None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_headline.json", "r03_pmc_headline.json")) if os.path.exists(f)), None)
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_headline.json", "r04_pmc_headline.json", "r03_pmc_headline.json")) if os.path.exists(f)), None)
     if pmc_file and args.config == "headline":
         pj = json.load(open(pmc_file))
         traffic, traffic_src, calib = pj["traffic_bytes_per_launch"], os.path.relpath(pmc_file, ROOT), {k: v["bytes_per_counted_byte"] for k, v in pj["calibration"].items()}
@@ -528,7 +528,7 @@ def main():
                      "fp64_flops_per_round": pen_flops + dir_flops, "fp64_flops_penalty": pen_flops, "fp64_flops_direction": dir_flops,
                      "fp64_frac": (pen_flops + dir_flops) / (us_round * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
                      "bound": "latency: per candidate a round is ONE dependent chain (direction -> forward map -> penalty -> adjoint) on 8 of the chip's 256 CUs"}
-        for name in ("r04_round_budget_B32.json", "r03_round_budget_B32.json"):
+        for name in ("r05_round_budget_B32.json", "r04_round_budget_B32.json", "r03_round_budget_B32.json"):
             bp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(bp) and args.config == "headline":
                 try:
