@@ -418,7 +418,7 @@ def main():
             r_ps = prob.optimize(params["opt_rel_tol"], x0=x0)
             prob.set_resident(True)
             r_q = None
-            if r["resident"] == 0 or r["clusters"] < B:
+            if r["resident"] == 0 or r["clusters"] < B or r.get("taken_over"):
                 # a batch larger than the chip holds at once (Monte-Carlo share: 512 per GPU): the resident kernel's work queue, whatever
                 # the default chose for this size - both paths on the line
                 prob.set_resident(2)
@@ -450,7 +450,9 @@ def main():
                 "plan_rounds": r["rounds"], "plan_iters_max": int(r["iters"].max()), "plan_evals_max": int(r["evals"].max()),
                 "plan_status_ok": int(np.sum(r["status"] >= 0)), "plan_objective_min": float(r["objective"].min()),
                 "plan_resident_failed": int(r["resident_failed"]), "plan_resident_retried": int(r["resident_retried"]),
-                "plan_path": ("resident round kernel, %d workgroups per candidate, %d clusters%s" % (r["resident"], r["clusters"], " (work queue)" if r["clusters"] < B else "")) if r["resident"] else "one launch per stage and round",
+                "plan_path": ("one launch per stage and round until %d candidates were left, which finished on the resident round kernel (take-over, %d workgroups per candidate)" % (r["taken_over"], r["resident"])) if r.get("taken_over") else
+                             ("resident round kernel, %d workgroups per candidate, %d clusters%s" % (r["resident"], r["clusters"], " (work queue)" if r["clusters"] < B else "")) if r["resident"] else "one launch per stage and round",
+                "plan_taken_over": int(r.get("taken_over", 0)),
                 "plan_clusters": int(r["clusters"]),
                 "plan_us_per_round": 1e3 * r["ms_total"] / max(r["rounds"], 1)}
         # the host budget the plan ran under (frx_api.cpp host_cpu_share): CPUs of the process (cgroup quota / affinity), this rank's share, mailbox threads

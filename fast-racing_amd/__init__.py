@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
 # diagnostics, include/frx_debug.h: not part of the drop-in boundary
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
-    "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share",
+    "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
 ]
 
 _lib = None
@@ -477,6 +477,12 @@ class Problem:
         """Diagnostic: re-run candidates that fail on the resident kernel on the per-stage rounds (round-2 behaviour; default off)."""
         _check(lib().frx_debug_set_resident_retry(self.h, 1 if enable else 0))
 
+    def taken_over(self) -> int:
+        """Candidates of the last plan that began as per-stage rounds and finished on the resident round kernel (frx_debug_taken_over)."""
+        n = C.c_int(0)
+        _check(lib().frx_debug_taken_over(self.h, C.byref(n)))
+        return int(n.value)
+
     def resident_predictions(self):
         """(rounds on a predicted ADVANCE, rounds on a predicted trial step, predictions redone) of the last resident plan, all candidates."""
         out = np.zeros(3, dtype=np.uint64)
@@ -542,7 +548,7 @@ class Problem:
         return dict(x=x, C=Cf.reshape(-1, 3), T=T, jerk_cost=jc, objective=obj, status=st, iters=it, evals=ev,
                     ms_total=stats[0], ms_device=stats[1], ms_host=stats[2], rounds=int(stats[3]), resident=resident, device_status=dev_status,
                     resident_failed=self.resident_counts()[0], resident_retried=self.resident_counts()[1], predictions=self.resident_predictions(),
-                    clusters=self.resident_clusters() if resident else 0)
+                    clusters=self.resident_clusters() if resident else 0, taken_over=self.taken_over())
 
     def stage_times(self, x, reps: int = 100):
         """Average microseconds of the forward, penalty and adjoint kernels at x (HIP events inside the library)."""

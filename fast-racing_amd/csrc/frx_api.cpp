@@ -30,6 +30,7 @@
 #include "frx_lbfgs.hpp"
 #include "frx_host_pool.hpp"
 #include "frx_host_setup.hpp"
+#include "frx_compact.hpp"
 
 namespace {
 
@@ -169,6 +170,10 @@ struct frx_problem {
     DevBuf<unsigned> d_rwords;
     PinBuf<unsigned long long> h_rcmd, h_rres;              // [S] x 8 words each (S clusters: one mailbox per cluster)
     int rk_B = 0, rk_S = 0, rk_G = 0, rk_NXP = 0;
+    // take-over of a per-stage batch's stragglers by the resident kernel (optimize_resident with a TakeOver): per cluster candidate index, last objective value,
+    // newest slot and pair count of its history, and the dense state rebuilt from that history (frx_compact.hpp)
+    DevBuf<int> d_rs_int; DevBuf<double> d_rs_f, d_rs_rinv, d_rs_yy, d_rs_vd;
+    int taken_over = 0;                                     // candidates of the last plan that finished on the resident kernel after per-stage rounds
     int resident_clusters = 0;                              // clusters of the last resident launch (< B: the candidates went through the work queue)
     int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident); 2 = also when the batch
                                                             // is larger than the chip holds at once, whatever its size (work queue); 0 = never
@@ -736,8 +741,23 @@ static int finish_optimize(frx_problem *p, const double *x, double *C, double *T
 // come back per candidate, through mapped host memory.
 // `only` (optional, [B]): candidates with only[b] == 0 take no part - their x, status, counters and objective are left untouched
 // (used to re-run, on this path, candidates that failed on the resident kernel).
+// Stragglers of a per-stage batch that continue on the resident round kernel.  A per-stage round costs four launches whose first is a
+// one-CU recursion over the candidate's history (~85 us per round however few candidates are left), a resident round ~25 us - and a batch waits for its
+// slowest candidate (one infeasible scenario that wanders 16 673 evaluations held 511 finished ones hostage for a second, profiles/r04_bench_montecarlo4096.json).
+// When no more than `capacity` candidates are still running, optimize_device_vectors stops and hands them over AS THEY ARE: their solver state machines
+// (the host's side of the plan: line search, stop tests, counters), their pending commands, and where their history stands on the device.
+struct TakeOver {
+    int capacity = 0;                     // in: hand over when at most this many candidates are still running (0: never)
+    long not_before = 1;                  // in: ... and this many rounds have run (FRX_MIGRATE_AT: tests force an early hand-over)
+    std::vector<int> cand;                // out: the candidates, in cluster order
+    std::vector<frx::SolverDV> sv;        // out: their solvers (pending command inside)
+    std::vector<int> newest, bound;       // out: newest slot / number of pairs of their history rows on the device
+    std::vector<double> f_last;           // out: objective value of their last evaluation
+    double ms = 0.0, ms_dev = 0.0, ms_host = 0.0; long rounds = 0;   // out: what the per-stage part took
+};
+
 static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals,
-                                   double *objective, const std::vector<char> *only = nullptr) {
+                                   double *objective, const std::vector<char> *only = nullptr, TakeOver *take = nullptr) {
     const int B = p->B, m = pm.mem_size;
     // k_lbfgs_pre geometry (frx::dv_geometry).  FRX_DV_GEOM=E,W,PF,BLK overrides (experiments).
     int E = 0, W = 0, PF = 0, BLK = 4;
@@ -843,11 +863,18 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     long rounds = 0;
     const bool tracing = std::getenv("FRX_TRACE") != nullptr;
     p->trace.clear();
+    std::vector<int> h_newest(B, 0), h_bound(B, 0);                            // where every candidate's history stands on the device (for a hand-over)
+    std::vector<double> h_flast(B, 0.0);
+    bool handed_over = false;
     const auto t0 = clk::now();
     for (;;) {
         bool any_eval = false, any_cmd = false;
-        for (int b = 0; b < B; b++) { any_eval |= (p->h_cmd.p[b].flags & frx::DV_EVAL) != 0; any_cmd |= p->h_cmd.p[b].flags != 0; }
+        int running = 0;
+        for (int b = 0; b < B; b++) { any_eval |= (p->h_cmd.p[b].flags & frx::DV_EVAL) != 0; any_cmd |= p->h_cmd.p[b].flags != 0; running += p->h_cmd.p[b].flags != 0; }
         if (!any_cmd) break;
+        if (take && take->capacity > 0 && running <= take->capacity && rounds >= take->not_before) { handed_over = true; break; }   // the rest continues on the resident kernel
+        for (int b = 0; b < B; b++)
+            if (p->h_cmd.p[b].flags & frx::DV_ADVANCE) { h_newest[b] = p->h_cmd.p[b].slot; h_bound[b] = p->h_cmd.p[b].bound; }    // the pair this round stores
         auto td = clk::now();
         HIP_TRY((hipError_t)frx::launch_lbfgs_pre(dv, p->h_cmd.p, p->h_res.p, p->stream));
         if (any_eval) {
@@ -864,6 +891,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
             const bool evaluated = (c.flags & frx::DV_EVAL) != 0;
             if (!evaluated) { c.flags = 0; continue; }                         // a RESTORE has been executed
             if (tracing && b == 0) { const frx::DvResult &r = p->h_res.p[b]; const double row[7] = {(double)c.flags, c.step, r.f, r.dg, r.dginit, r.xx, r.gg}; p->trace.insert(p->trace.end(), row, row + 7); }
+            h_flast[b] = p->h_res.p[b].f;
             if (sv[b].saw_nonfinite(p->h_res.p[b].f)) sv[b].give_up(frx::LBERR_ROUNDING); else sv[b].feed(p->h_res.p[b]);
         }
         t_host += ms_since(th);
@@ -872,15 +900,20 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     p->stats[0] = ms_since(t0); p->stats[1] = t_dev; p->stats[2] = t_host; p->stats[3] = (double)rounds;
     HIP_TRY(hipMemcpyAsync(p->h_x.p, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (handed_over) { take->ms = p->stats[0]; take->ms_dev = t_dev; take->ms_host = t_host; take->rounds = rounds; }
     for (int b = 0; b < B; b++) {
         if (only && !(*only)[b]) continue;
+        if (handed_over && p->h_cmd.p[b].flags != 0) {                          // still running: the solver, its pending command and the history's position travel
+            take->cand.push_back(b); take->sv.push_back(sv[b]); take->newest.push_back(h_newest[b]); take->bound.push_back(h_bound[b]); take->f_last.push_back(h_flast[b]);
+            continue;
+        }
         std::memcpy(x + p->xoff[b], p->h_x.p + p->xoff[b], sizeof(double) * (p->xoff[b + 1] - p->xoff[b]));
         status[b] = sv[b].status();
         if (iters) iters[b] = sv[b].iterations();
         if (evals) evals[b] = sv[b].evaluations();
         if (objective) objective[b] = sv[b].value();
     }
-    return FRX_OK;
+    return handed_over ? 2 : FRX_OK;
 }
 
 
@@ -902,16 +935,23 @@ static std::mutex &resident_device_lock(int device) {
     return *m;
 }
 
-static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals, double *objective) {
+// `take` (optional): not a plan from its start but the continuation of the candidates a per-stage batch handed over (TakeOver above): cluster k runs candidate
+// take->cand[k] from its pending command on, with the per-stage path's vectors and a dense state rebuilt from its history (frx_compact.hpp); everybody
+// else's results are left alone.
+static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double *x, int *status, int *iters, int *evals, double *objective, TakeOver *take = nullptr) {
     const int B = p->B, m = pm.mem_size;
+    const int Bsel = take ? (int)take->cand.size() : B;                              // candidates that run here
     int E = frx::ROUND_E;
     p->resident_used = 0; p->resident_status = 0; p->resident_failed = 0;
-    if (p->geo.solver != frx::SOLVER_KNOT_PCR || m < 1 || m > 128) return 1;
+    if (p->geo.solver != frx::SOLVER_KNOT_PCR || m < 1 || m > 128 || Bsel < 1) return 1;
+    if (take && (p->geo.knot_threads != 64 || m != 128 || p->dv_mem != m || !p->d_S.p)) return 1;    // the take-over instantiation: <= 64 pieces, the stock history length
     // The compact representation inverts R = S^T Y (triangular part); with fewer variables than twice the history length the pairs
     // become linearly dependent and R^-1 loses its digits (n = 1: entries grow like 2^k), where the two-loop recursion of
     // k_lbfgs_pre stays stable.  Such problems (a few pieces) are latency-trivial anyway and take the per-stage rounds.
-    for (int b = 0; b < B; b++)
+    for (int q = 0; q < Bsel; q++) {
+        const int b = take ? take->cand[q] : q;
         if (p->xoff[b + 1] - p->xoff[b] < 2 * m) return 1;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
@@ -921,13 +961,13 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         // it the last bits of a plan, depend on the size class of the batch.  FRX_RESIDENT_E=56 keeps the large chunks.
         const char *ee = std::getenv("FRX_RESIDENT_E");
         const int Es = frx::ROUND_E_SMALL, Gs = 2 + std::max(1, (p->geo.maxXb + 2 * Es - 1) / (2 * Es));
-        if (!(ee && std::atoi(ee) == frx::ROUND_E) && Gs <= 16 && (long)8 * Gs * ((B + 7) / 8) <= cus) E = Es;
+        if (!(ee && std::atoi(ee) == frx::ROUND_E) && Gs <= 16 && (long)8 * Gs * ((Bsel + 7) / 8) <= cus) E = Es;
     }
     int G = 2 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each) + dense
     const int G_min = std::max(G, 3);
     {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them
         const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
-        const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(B, 1)});
+        const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(Bsel, 1)});
         G = std::max(G, want);
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
@@ -938,12 +978,13 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     // ~sum(evaluations) / S rounds where the per-stage path - every candidate in every launch - takes max(evaluations) rounds of a
     // launch that grows with B: measured (profiles/r03_queue_sizes.jsonl) the queue wins up to a few times the chip's capacity, the
     // per-stage path beyond; resident_mode 2 / FRX_RESIDENT_QUEUE=1 force the queue, FRX_RESIDENT_QUEUE=0 forbids it.
-    int S = B;
-    const char *ce = std::getenv("FRX_RESIDENT_CLUSTERS");                            // experiments / tests: no more than this many clusters
-    if ((long)8 * G * ((B + 7) / 8) > cus) { G = G_min; S = std::min(B, 8 * (cus / (8 * G))); }
+    int S = Bsel;
+    const char *ce = take ? nullptr : std::getenv("FRX_RESIDENT_CLUSTERS");          // experiments / tests: no more than this many clusters
+    if ((long)8 * G * ((Bsel + 7) / 8) > cus) { G = G_min; S = std::min(Bsel, 8 * (cus / (8 * G))); }
     if (ce) S = std::min(S, std::max(1, std::atoi(ce)));
     if (S < 1) return 1;
-    if (S < B) {
+    if (take && S < Bsel) return 1;                                                   // a take-over has one cluster per straggler (no queue)
+    if (S < B && !take) {
         const char *qe = std::getenv("FRX_RESIDENT_QUEUE");
         const int queue_max = [] { const char *e = std::getenv("FRX_RESIDENT_QUEUE_MAX"); return e ? std::atoi(e) : 3; }();   // x capacity (measured: queue 484 ms against 498 ms per stage at 96 = 3 x 32 candidates, 626 against 514 at 128)
         const bool allowed = qe ? qe[0] != '0' : (ce || p->resident_mode == 2 || B <= queue_max * S);
@@ -975,7 +1016,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         if ((!p->d_rdbg.p || p->d_rdbg.n < log_doubles) && p->d_rdbg.alloc(log_doubles) != hipSuccess) return fail(FRX_ERR_ALLOC, "direction log does not fit the device");
         HIP_TRY(hipMemsetAsync(p->d_rdbg.p, 0, sizeof(double) * log_doubles, p->stream));
     }
-    const bool want_prof = std::getenv("FRX_RESIDENT_PROF") != nullptr;
+    const bool want_prof = !take && std::getenv("FRX_RESIDENT_PROF") != nullptr;
     if (want_prof) {
         if ((!p->d_rprof.p || p->d_rprof.n < (size_t)S * (G + 1) * 16) && p->d_rprof.alloc((size_t)S * (G + 1) * 16) != hipSuccess) return 1;
         HIP_TRY(hipMemsetAsync(p->d_rprof.p, 0, sizeof(unsigned long long) * (size_t)S * (G + 1) * 16, p->stream));
@@ -989,9 +1030,40 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     HIP_TRY(hipMemsetAsync(p->d_pubsyg.p, 0, sizeof(double) * (size_t)S * (3 * NXP + 2), p->stream));   // the point and gradient the cluster reads: zero beyond n (padding of s and y)
     std::memset(p->h_rcmd.p, 0, sizeof(unsigned long long) * 8 * S);
     std::memset(p->h_rres.p, 0, sizeof(unsigned long long) * 8 * S);
-    std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
-    HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    if (!take) {
+        std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
+        HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
+    }
     frx::RoundLaunch rl;
+    if (take) {
+        // The dense state of every straggler from its history rows: read back (1.5 MB per candidate), R = S^T Y (triangular part), its inverse, Y^T Y and D on the
+        // set-up pool's threads (frx_compact.hpp: 2 x 128 x 128 dot products of length n per candidate), uploaded as the clusters' take-over arrays.
+        const size_t HS = p->dv_hs, rowblk = (size_t)m * HS;
+        std::vector<double> hS((size_t)S * rowblk), hY((size_t)S * rowblk), rinv((size_t)S * 128 * 129), yy((size_t)S * 128 * 128), vd((size_t)S * 128);
+        for (int k = 0; k < S; k++) {
+            const int b = take->cand[k];
+            HIP_TRY(hipMemcpyAsync(hS.data() + (size_t)k * rowblk, p->d_S.p + (size_t)b * rowblk, sizeof(double) * rowblk, hipMemcpyDeviceToHost, p->stream));
+            HIP_TRY(hipMemcpyAsync(hY.data() + (size_t)k * rowblk, p->d_Y.p + (size_t)b * rowblk, sizeof(double) * rowblk, hipMemcpyDeviceToHost, p->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        frx::TaskPool::get().run(S, frx::setup_threads(S, 8000.0), [&](int k, int) {
+            const int b = take->cand[k];
+            frx::compact_from_history(m, p->xoff[b + 1] - p->xoff[b], HS, take->bound[k], take->newest[k], hS.data() + (size_t)k * rowblk, hY.data() + (size_t)k * rowblk, 129,
+                                      rinv.data() + (size_t)k * 128 * 129, yy.data() + (size_t)k * 128 * 128, vd.data() + (size_t)k * 128);
+        });
+        std::vector<int> ints((size_t)3 * S);
+        for (int k = 0; k < S; k++) { ints[k] = take->cand[k]; ints[S + k] = take->newest[k]; ints[2 * S + k] = take->bound[k]; }
+        auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
+        if (need(p->d_rs_int, ints.size()) != hipSuccess || need(p->d_rs_f, (size_t)S) != hipSuccess || need(p->d_rs_rinv, rinv.size()) != hipSuccess ||
+            need(p->d_rs_yy, yy.size()) != hipSuccess || need(p->d_rs_vd, vd.size()) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        HIP_TRY(hipMemcpy(p->d_rs_int.p, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_rs_f.p, take->f_last.data(), sizeof(double) * S, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_rs_rinv.p, rinv.data(), sizeof(double) * rinv.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_rs_yy.p, yy.data(), sizeof(double) * yy.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_rs_vd.p, vd.data(), sizeof(double) * vd.size(), hipMemcpyHostToDevice));
+        rl.rs_cand = p->d_rs_int.p; rl.rs_newest = p->d_rs_int.p + S; rl.rs_bound = p->d_rs_int.p + 2 * S;
+        rl.rs_f = p->d_rs_f.p; rl.rs_S = p->d_S.p; rl.rs_Y = p->d_Y.p; rl.rs_hs = HS; rl.rs_rinv = p->d_rs_rinv.p; rl.rs_yy = p->d_rs_yy.p; rl.rs_vd = p->d_rs_vd.p;
+    }
     rl.x = p->d_x.p; rl.g = p->d_g.p; rl.xp = p->d_xp.p; rl.gp = p->d_gp.p; rl.d = p->d_dir.p; rl.f = p->d_f.p; rl.T = p->d_T.p; rl.C = p->d_C.p; rl.out20 = p->d_out20.p;
     rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.out20ll = std::getenv("FRX_RESIDENT_NO_LL20") ? nullptr : (unsigned long long *)p->d_out20ll.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr; rl.dbg_cap = want_dbg ? p->dirlog_cap : 0; rl.dbg_cands = want_dbg ? log_cands : 0;
     rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
@@ -1062,7 +1134,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         slot_[k].ncmd++;
     };
     const bool tracing = std::getenv("FRX_TRACE") != nullptr;
-    p->trace.clear();
+    if (!take) p->trace.clear();                                                      // (a take-over continues the per-stage part's trace)
     auto record = [&](int k) {                                                       // the finished plan of slot k's candidate (the point itself is read from the device at the end)
         const int b = slot_[k].cand;
         status[b] = slot_[k].sv.status();
@@ -1082,8 +1154,13 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         slot_[k].switching = 1; slot_[k].waiting = 1;
         return true;
     };
-    for (int b = 0; b < B; b++) status[b] = 0;
-    for (int k = 0; k < S; k++) { slot_[k].cand = k; slot_[k].sv.start(p->xoff[k + 1] - p->xoff[k], pm, &slot_[k].cmd); }
+    if (!take) {
+        for (int b = 0; b < B; b++) status[b] = 0;
+        for (int k = 0; k < S; k++) { slot_[k].cand = k; slot_[k].sv.start(p->xoff[k + 1] - p->xoff[k], pm, &slot_[k].cmd); }
+    } else {
+        next_cand.store(B);                                                           // nobody is handed a further candidate
+        for (int k = 0; k < S; k++) { slot_[k].cand = take->cand[k]; slot_[k].sv = take->sv[k]; slot_[k].sv.rebind(&slot_[k].cmd); }   // the pending command comes along
+    }
     // the threads that talk to the device stay on the device's NUMA node for the length of the plan (FRX_NUMA=0: wherever the scheduler puts them);
     // the caller's own affinity is put back when the plan is over.  Looked up (cached per device) before the launch: the clusters spin from then on
     cpu_set_t numa_set, caller_set;
@@ -1326,15 +1403,18 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
     const char *lb_env = std::getenv("FRX_LBFGS");
     const bool want_device_vectors = !(lb_env && lb_env[0] == 'h') && p->lbfgs_mode != 1;
     int rc_dv = 1;
+    p->taken_over = 0;
     if (want_device_vectors) {
         // FRX_RESIDENT=0 keeps the one-launch-per-stage rounds; the default is the resident round kernel whenever the batch fits the
         // chip (one workgroup per CU, B x G of them), with the per-stage path as fallback when it does not or when the device gives up
         const char *rs_env = std::getenv("FRX_RESIDENT");
         p->resident_used = 0; p->resident_retried = 0;
         p->resident_failed = 0; p->resident_clusters = 0; for (auto &q : p->spec_counts) q = 0;      //  diagnostics of THIS plan, whichever path it takes
-        if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0) {
-            const std::vector<double> x_start(x, x + p->NX);
+        const std::vector<double> x_start(x, x + p->NX);
+        bool resident_gave_up = false;
+        if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0 && !std::getenv("FRX_TAKEOVER_AT")) {      // (FRX_TAKEOVER_AT, tests: per-stage rounds first, whatever the batch size)
             rc_dv = optimize_resident(p, *params, x, status, iters, evals, objective);
+            resident_gave_up = rc_dv != 0 && p->resident_status != 0;
             if (rc_dv < 0) return rc_dv;
             if (rc_dv != 0) std::copy(x_start.begin(), x_start.end(), x);
             else {
@@ -1384,8 +1464,45 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
             }
         }
         if (rc_dv != 0) {
-            rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective);
+            // A batch too large for the resident kernel's clusters runs as per-stage rounds - until no more candidates are left than the chip has clusters for:
+            // those continue on the resident kernel (TakeOver; FRX_TAKEOVER=0 keeps the per-stage rounds to the end).  Not when the caller switched the
+            // resident kernel or its queue off, and not when the resident kernel has just given up on this device.
+            TakeOver take;
+            {
+                const char *te = std::getenv("FRX_TAKEOVER"), *qe = std::getenv("FRX_RESIDENT_QUEUE");
+                const bool wanted = !(te && te[0] == '0') && !(rs_env && rs_env[0] == '0') && !(qe && qe[0] == '0') && p->resident_mode != 0 && !resident_gave_up;
+                hipDeviceProp_t prop;
+                if (wanted && p->geo.solver == frx::SOLVER_KNOT_PCR && p->geo.knot_threads == 64 && params->mem_size == 128 && hipGetDeviceProperties(&prop, p->device) == hipSuccess) {
+                    bool fits = true;
+                    for (int b = 0; b < p->B; b++) fits = fits && p->xoff[b + 1] - p->xoff[b] >= 2 * params->mem_size;
+                    const int G = std::max(3, 2 + std::max(1, (p->geo.maxXb + 2 * frx::ROUND_E - 1) / (2 * frx::ROUND_E)));
+                    const int cap = 8 * (prop.multiProcessorCount / (8 * G));
+                    if (fits && cap >= 1 && p->B > cap) take.capacity = cap;
+                    if (const char *at = std::getenv("FRX_TAKEOVER_AT")) { take.not_before = std::max(1L, std::atol(at)); if (fits && cap >= 1 && p->B <= cap) take.capacity = cap; }   // (tests: a small batch hands over after so many rounds)
+                }
+            }
+            rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective, nullptr, take.capacity > 0 ? &take : nullptr);
             if (rc_dv < 0) return rc_dv;
+            if (rc_dv == 2) {
+                const double ms_ps = take.ms, dev_ps = take.ms_dev, host_ps = take.ms_host;
+                const long rounds_ps = take.rounds;
+                const int rc3 = optimize_resident(p, *params, x, status, iters, evals, objective, &take);
+                if (rc3 < 0) return rc3;
+                if (rc3 == 0) {
+                    p->taken_over = (int)take.cand.size();
+                    p->stats[0] += ms_ps; p->stats[1] += dev_ps; p->stats[2] += host_ps; p->stats[3] += (double)rounds_ps;
+                } else {
+                    // the resident kernel could not take them (another process on the device, a geometry it does not cover): their vectors on the device are no
+                    // longer the per-stage path's, so they are planned again from their start points, per stage - slower, never wrong
+                    std::vector<char> again(p->B, 0);
+                    for (int c : take.cand) { again[c] = 1; std::copy(x_start.begin() + p->xoff[c], x_start.begin() + p->xoff[c + 1], x + p->xoff[c]); }
+                    const int rc4 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);
+                    if (rc4 != 0) return rc4 < 0 ? rc4 : fail(FRX_ERR_HIP, "per-stage path unavailable after a failed take-over");
+                    p->resident_used = 0;
+                    p->stats[0] += ms_ps; p->stats[1] += dev_ps; p->stats[2] += host_ps; p->stats[3] += (double)rounds_ps;
+                }
+                rc_dv = 0;
+            }
         }
     }
     if (rc_dv == 0) return finish_optimize(p, x, C, T, jerk_cost);
@@ -1491,6 +1608,16 @@ int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
     return rows;
 }
 
+int frx_debug_taken_over(const frx_problem *p, int *candidates) {
+    if (!p || !candidates) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    *candidates = p->taken_over;
+    return FRX_OK;
+}
+int frx_debug_compact_from_history(int m, int n, int hs, int bound, int newest, const double *S, const double *Y, double *rinv129, double *yy, double *vd) {
+    if (!S || !Y || !rinv129 || !yy || !vd || m < 1 || m > 128 || n < 1 || hs < n || bound < 0 || bound > m || newest < 0 || newest >= m) return fail(FRX_ERR_INVALID_ARG, "frx_debug_compact_from_history: argument out of range");
+    frx::compact_from_history(m, n, (size_t)hs, bound, newest, S, Y, 129, rinv129, yy, vd);
+    return FRX_OK;
+}
 int frx_debug_host_cpu_share(int clusters, int extra_plans, double *budget, int *share, int *mailbox_threads) {
     frx::concurrent_plans_hint(extra_plans);
     if (budget) *budget = frx::host_cpu_budget();

@@ -137,6 +137,11 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, a);
         return (int)hipGetLastError();
     };
+    a.rs.cand = r.rs_cand; a.rs.f_last = r.rs_f; a.rs.S = r.rs_S; a.rs.Y = r.rs_Y; a.rs.hs = r.rs_hs; a.rs.newest = r.rs_newest; a.rs.bound = r.rs_bound; a.rs.rinv = r.rs_rinv; a.rs.yy = r.rs_yy; a.rs.vd = r.rs_vd;
+    if (r.rs_cand) {                                                   // take-over instantiation: <= 64 pieces, no profile
+        if (!n64 || r.prof) return (int)hipErrorInvalidValue;
+        return r.E == ROUND_E ? go(k_round<ROUND_E, false, 64, true>) : go(k_round<ROUND_E_SMALL, false, 64, true>);
+    }
     if (r.E == ROUND_E) {
         if (r.prof) return n64 ? go(k_round<ROUND_E, true, 64>) : go(k_round<ROUND_E, true, 0>);
         return n64 ? go(k_round<ROUND_E, false, 64>) : go(k_round<ROUND_E, false, 0>);

@@ -98,6 +98,10 @@ struct RoundLaunch {
     int cmd_stride = 4;                                            // h_cmd: cluster k's 16-byte command at 16 * cmd_stride * k
     int fast_control = 1;                                          // see RoundArgs
     int stamp_round = 0;                                           // profiling: keep the cycle stamps of cluster 0's evaluation number stamp_round (0: of its last one)
+    // take-over of plans the per-stage rounds began (frx_round_kernel.hpp, RoundArgs::rs): device arrays, [S] each unless stated; rs_cand == nullptr: a plan from its start
+    const int *rs_cand = nullptr, *rs_newest = nullptr, *rs_bound = nullptr;
+    const double *rs_f = nullptr, *rs_S = nullptr, *rs_Y = nullptr, *rs_rinv = nullptr, *rs_yy = nullptr, *rs_vd = nullptr;   // S, Y: the per-stage history [B][m][rs_hs]; rinv [S][128][129], yy [S][128][128], vd [S][128]
+    size_t rs_hs = 0;
 };
 enum { ROUND_E = 56, ROUND_E_SMALL = 28, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)

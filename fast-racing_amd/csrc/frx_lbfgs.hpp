@@ -494,6 +494,8 @@ public:
     // with max_iterations = 0 the reference would iterate on NaNs for ever; the drivers stop a candidate after 64 consecutive
     // non-finite values with LBFGSERR_ROUNDING, keeping the last finite point's bookkeeping.
     void give_up(int code) { ret = code; phase = DONE; cmd->flags = 0; cmd->step = 0.0; }
+    // the command lives somewhere else from now on (a plan that moves from the per-stage rounds to a cluster of the resident kernel takes its pending command along)
+    void rebind(DvCommand *c) { *c = *cmd; cmd = c; }
     bool saw_nonfinite(double f) { nonfinite = (std::isnan(f) || std::isinf(f)) ? nonfinite + 1 : 0; return nonfinite >= 64; }
 
     void feed(const DvResult &r) {

@@ -121,6 +121,11 @@ struct RoundArgs {
     rk_u64 *trace; int trace_cap; unsigned trace_lo, trace_hi;      // PROF instantiation only: timeline of cluster 0 - every workgroup's thread 0 appends (segment id << 56 | wall clock) for the
                                                                     // phases trace_lo <= phase number < trace_hi, trace_cap events per workgroup ([G][trace_cap]; FRX_RESIDENT_TRACE)
     rk_u64 *prof;                            // PROF instantiation only: [B][G][16] wall-clock ticks (100 MHz) per segment, see RK_P_*; then [B][16]: histogram of the leaders' waits for a host command
+    // RESUME instantiation only (frx_api.cpp: the stragglers of a per-stage batch continue here, mid-plan): cluster k takes candidate cand[k] where the per-stage
+    // rounds left it - x, g, xp, gp, d are the handle's own vectors (a.x ... a.d), the history its [B][m][hs] rows in natural element order (k_lbfgs_pre), the
+    // dense state (R^-1 by slot with row stride RK_RS, Y^T Y [128][128], D = diag(s.y)) rebuilt by the host from the same rows - the SAME pairs, so the same
+    // algorithm: the direction is the one the per-stage path's two-loop recursion would form, to rounding.
+    struct Resume { const int *cand; const double *f_last; const double *S, *Y; size_t hs; const int *newest, *bound; const double *rinv, *yy, *vd; } rs;
 };
 // profile segments (thread 0 of every workgroup accumulates the time since its previous checkpoint into one of these)
 enum { RK_P_WAIT_HOST = 0, RK_P_VECTORS = 1, RK_P_FORWARD = 2, RK_P_WAIT_PHASE = 3, RK_P_PASS_A = 4, RK_P_WAIT_PART = 5, RK_P_DENSE_IN = 6, RK_P_SOLVE = 7,
@@ -240,7 +245,7 @@ __device__ __forceinline__ void rk_penalty_share(const RoundArgs &a, const Round
 // ============================================================================================================================
 // LEADER (workgroup 0 of a cluster)
 // ============================================================================================================================
-template <bool PROF, int NR>
+template <bool PROF, int NR, bool RESUME>
 __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, const RoundLds &L, double *sm) {
     const int k = v.k, t = v.t, lane = v.lane, wave = v.wave;
     int c = v.c, n = v.n;                                                   // the candidate this cluster works on (changes with DV_NEXT)
@@ -323,6 +328,36 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     rk_u64 pred_word = 0, seq_pending = 0;
     double f_acc = 0.0, gg0 = 0.0;
     int last_slot = -1, last_bound = 0;
+    if (RESUME) {
+        // Take-over of a plan the per-stage rounds began (RoundArgs::rs): the leader's vectors are the per-stage path's own buffers, the last objective value
+        // comes with the launch, and ONE phase INIT hands the cluster its state - the previous point and gradient (from `pub`, as in every INIT), the history
+        // rows into the members' registers, R^-1, Y^T Y and D into the dense workgroup.  Then `pub` takes the current point and its gradient: what the members
+        // form the next pair from.  The host's first command is the plan's PENDING one (a trial of a running search, an ADVANCE, a RESTORE).
+        const double *gsrc = a.g + v.xbase, *xps = a.xp + v.xbase, *gps = a.gp + v.xbase, *dsrc = a.d + v.xbase;
+        for (int i = t; i < n; i += 256) {
+            const double xpv = xps[i], gpv = gps[i];
+            g[i] = gsrc[i]; xp[i] = xpv; gp[i] = gpv; dv[i] = dsrc[i];
+            stg<true>(pub + i, xpv, wt); stg<true>(pub + a.NXP + i, gpv, wt);
+        }
+        if (t == 0) ctlD[0] = a.rs.f_last[k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rk_drain_and_meet();
+        pseq++;
+        if (t == 0) __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_INIT, FRX_RLX_AGENT);
+        rk_drain_and_meet();
+        if (t == 0) __hip_atomic_fetch_add(a.cntL + k * RK_WSTRIDE, 1u, FRX_RLX_AGENT);
+        nphase++;
+        if (t == 0) { const bool okw = rk_wait_eq(a.cntL + k * RK_WSTRIDE, (unsigned)a.G * nphase, a); if (!okw) rk_fail(a, RK_ERR_ARRIVE); ctlU[0] = okw ? 1u : 0u; }
+        __syncthreads();
+        const bool ok0 = ctlU[0] != 0u;
+        __syncthreads();
+        if (!ok0) {
+            pseq++;
+            if (t == 0) { __hip_atomic_store(&a.h_res[k].seq, ~(rk_u64)0, FRX_RLX_SYS); __hip_atomic_store(a.phase + k * RK_WSTRIDE, (pseq << 4) | (unsigned)PH_QUIT, FRX_RLX_AGENT); }
+            return;
+        }
+        for (int i = t; i < n; i += 256) { stg<true>(pub + i, x[i], wt); stg<true>(pub + a.NXP + i, g[i], wt); }   // (drained in front of the next phase word, like every publication)
+    }
     for (;;) {
         int kind = 0;
         RK_TR(40);                                                          // loop top
@@ -705,7 +740,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
 // ============================================================================================================================
 // MEMBERS (workgroups 1..G-1): history in registers, penalty share; the last one is also the dense workgroup
 // ============================================================================================================================
-template <int E, bool PROF>
+template <int E, bool PROF, bool RESUME>
 __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, const RoundLds &L, double *sm) {
     constexpr int CHT = 2 * E;
     const int k = v.k, wg = v.wg, t = v.t, lane = v.lane, wave = v.wave, m = v.m;
@@ -723,6 +758,7 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
     unsigned pseq = 0, nadv = 0, nct = 0;                                   // phases seen; direction phases and evaluation phases among them (the tags of this cluster's granules)
     int jnew = 0, bound = 0;
     bool wipe = false;                                                      // work queue: the next step is the first of a new candidate (workgroup-uniform)
+    bool resumed = false; (void)resumed;                                    // RESUME: the take-over INIT has loaded the history
     const double *zC = sm + L.zC;
     if (t < E) sm[L.zC + t] = 0.0;                                          // (ordered before its first use by the barriers of the first phases)
     for (;;) {
@@ -762,6 +798,23 @@ __device__ __forceinline__ void rk_member_loop(const RoundArgs &a, RoundView v, 
         if (kind == PH_INIT) {                                              // this workgroup's chunk of the start point and its gradient: the first pair's "previous point"
             const int e0 = hg * CHT;
             for (int i = t; i < CHT; i += 256) { xpC[i] = ldg<true>(pub + e0 + i); gpC[i] = ldg<true>(pub + a.NXP + e0 + i); }
+            if (RESUME && !resumed) {
+                // take-over (RoundArgs::rs): this thread's E elements of s_slot and y_slot from the per-stage history rows (natural element order, zero beyond n);
+                // slots without a pair stay zero.  (A second definition of the history registers: this instantiation may spill where the production one does not.)
+                resumed = true;
+                const int newest = a.rs.newest[k], bnd = a.rs.bound[k];
+                int age0 = newest - slot; if (age0 < 0) age0 += m;
+                const bool has = slot < m && age0 < bnd;
+                const size_t row = ((size_t)v.c * m + (size_t)(slot < m ? slot : 0)) * a.rs.hs;
+                const int i0 = hg * CHT + half * E;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const bool in = has && (size_t)(i0 + e) < a.rs.hs;
+                    const size_t o = row + (size_t)(in ? i0 + e : 0);
+                    const double sv = a.rs.S[o], yv = a.rs.Y[o];
+                    Sreg[e] = in ? sv : 0.0; Yreg[e] = in ? yv : 0.0;
+                }
+            }
         }
 
         // ------------------------------------------------------------------------------------------------------------------
@@ -907,7 +960,7 @@ template <int NB> __device__ __forceinline__ void rk_gather_partials(const doubl
 //   Checked on a complete headline optimisation (3500 accepted steps, cond(R) up to 1e6): the direction stays within 3e-13 of the
 //   two-loop recursion, no drift (scripts/lbfgs_inverse_stability.py).
 // ============================================================================================================================
-template <bool PROF>
+template <bool PROF, bool RESUME>
 __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundView &v, const RoundLds &L, double *sm) {
     const int k = v.k, t = v.t;
     const bool wt = v.wt;
@@ -926,6 +979,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
     for (int i = L.Rf + t; i < L.mv + 512; i += 256) sm[i] = 0.0;           // no uninitialised word is ever multiplied
     __syncthreads();
     unsigned pseq = 0, nadv = 0;
+    bool resumed = false; (void)resumed;
     // (An evaluation phase is acknowledged by thread 0 alone, inside its poll loop, while the other waves stay parked at the barrier: nothing of it concerns
     // this workgroup.  Round 4 also tried a FORWARDER here - a lane of the idle workgroup copying the host's command from the mapped mailbox into
     // device memory for the leader, to take the PCIe read and its tail out of the adjoint: the adjoint became flat (5.4 us) but the confirmation
@@ -961,6 +1015,16 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
 #pragma unroll
             for (int u = 0; u < 32; u++) { Ya[u] = 0.0; Yb[u] = 0.0; }
             for (int i = L.Rf + t; i < L.mv + 512; i += 256) sm[i] = 0.0;
+            __syncthreads();
+        }
+        if (RESUME && kind == PH_INIT && !resumed) {                         // take-over (RoundArgs::rs): R^-1 by slot, D and Y^T Y as the host rebuilt them from the per-stage history
+            resumed = true;
+            const double *ri = a.rs.rinv + (size_t)k * 128 * RK_RS;
+            for (int i = t; i < 128 * RK_RS; i += 256) Rf[i] = ri[i];
+            if (t < 128) vd[t] = a.rs.vd[(size_t)k * 128 + t];
+            const double *yy = a.rs.yy + ((size_t)k * 128 + pp) * 128 + q0;
+#pragma unroll
+            for (int u = 0; u < 32; u++) { Ya[u] = yy[u]; Yb[u] = yy[32 + u]; }
             __syncthreads();
         }
         if (kind == PH_ADV) {
@@ -1088,7 +1152,7 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
 }
 
 // NR: 64 = every candidate has <= 64 pieces (the wave-specialised bodies, nothing else compiled in), 0 = the geometry class is a run-time value
-template <int E, bool PROF, int NR>
+template <int E, bool PROF, int NR, bool RESUME = false>
 __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int CHT = 2 * E;
@@ -1101,7 +1165,7 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     v.wg = rest % a.G; v.k = lane8 + 8 * (rest / a.G);
     v.t = threadIdx.x; v.lane = v.t & 63; v.wave = v.t >> 6;
     if (v.k >= a.S) return;                                               // grid is 8 G ceil(S / 8) blocks
-    v.c = v.k;                                                            // cluster k starts on candidate k; with more candidates than clusters the host hands out the rest (DV_NEXT)
+    v.c = RESUME ? a.rs.cand[v.k] : v.k;                                  // cluster k starts on candidate k (RESUME: on the straggler it takes over); with more candidates than clusters the host hands out the rest (DV_NEXT)
     v.m = a.m;
     const RoundLds L = round_lds(a.m, CHT, a.eval_doubles);
     rk_ldsword ctlU = (rk_ldsword)(unsigned *)(sm + L.ctl);          // [0] ok / kind, [1..2] command word / slot, pair count, [3] one XCD
@@ -1143,9 +1207,9 @@ __global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
     v.wt = ctlU[3] == 0u;                                                 // write-through payload stores unless the cluster shares an XCD
     if (PROF && v.t < 16) ((rk_u64 *)(sm + L.ctl + 16))[v.t] = 0;
     __syncthreads();
-    if (v.wg == 0) rk_leader_loop<PROF, NR>(a, v, L, sm);
-    else if (v.wg == a.G - 1) rk_dense_loop<PROF>(a, v, L, sm);
-    else rk_member_loop<E, PROF>(a, v, L, sm);
+    if (v.wg == 0) rk_leader_loop<PROF, NR, RESUME>(a, v, L, sm);
+    else if (v.wg == a.G - 1) rk_dense_loop<PROF, RESUME>(a, v, L, sm);
+    else rk_member_loop<E, PROF, RESUME>(a, v, L, sm);
 }
 #undef RK_PROF
 #undef RK_TR

@@ -70,6 +70,14 @@ int frx_jps_tables(int *ns3, int *f13, int *f23, int *ns2, int *f12, int *f22);
  * (the caller included): min(one per sixteen clusters, at most four; share - 1), at least one.  FRX_HOST_CPUS overrides the budget (tests). */
 int frx_debug_host_cpu_share(int clusters, int extra_plans, double *budget, int *share, int *mailbox_threads);
 
+/* Take-over (frx_api.cpp, TakeOver): a batch too large for the resident round kernel runs as per-stage rounds until no more candidates are left than the chip has
+ * clusters for; those continue on the resident kernel with their history as it stands.  frx_debug_taken_over: how many candidates of the last plan finished
+ * that way (0: none).  frx_debug_compact_from_history: the host code that rebuilds the resident kernel's dense state for such a candidate - R^-1 by slot
+ * ([128][129]), Y^T Y ([128][128]), D = diag(s.y) ([128]) - from history rows S, Y [m][hs] (n significant doubles per row), `bound` valid pairs, the newest
+ * in slot `newest` (frx_compact.hpp); exported so that a CPU test can check it against a dense inverse.  FRX_TAKEOVER=0 switches take-overs off. */
+int frx_debug_taken_over(const frx_problem *p, int *candidates);
+int frx_debug_compact_from_history(int m, int n, int hs, int bound, int newest, const double *S, const double *Y, double *rinv129, double *yy, double *vd);
+
 #ifdef __cplusplus
 }
 #endif
