@@ -211,42 +211,71 @@ def main():
         torch.cuda.synchronize()
         for d in set(lib_devs): torch.cuda.synchronize(d)
 
-    def step():
-        prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), stream)
+    # The launch stream of the timed steps: a stream of its own (a hipGraph cannot be captured on the default stream); `stream` - the default stream - stays
+    # what the other legs of this script use.
+    bench_stream = torch.cuda.Stream()
+
+    def step(st=None):
+        prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), bench_stream.cuda_stream if st is None else st)
         for pr, xd, fd, gd, st_r in lib_shards:
             pr.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), st_r.cuda_stream)
 
     # The K timed steps are bracketed by barrier + synchronize on both sides (host wall clock of the bracket: `ms_per_step_host_wall`) and timed INSIDE the
     # bracket with HIP events recorded on the launch stream(s) - first launch to last kernel end (at K = 20 the bracket is 0.45 ms and
     # the closing synchronize + barrier, ~40 us of host work, was 10 % of it).  `value` and `ms_per_step` are the event figure, MAX over ranks and streams.
+    # The K steps go to the device as ONE hipGraph (3 K kernel nodes captured from the very calls a caller makes - frx_objective_eval_device is a pure
+    # sequence of kernel launches on the caller's stream, so it can be captured): the gaps between the three stage kernels of a step and between steps
+    # (0.3-0.4 us per launch boundary: 20.5 us per step against 19.1-19.7 as a graph, scripts/r05/graph_probe.py) are the launch path's, not the kernels'.
+    # `ms_per_step_direct_launches` is the same K steps launched one by one (FRX_BENCH_GRAPH=0 makes that the timed form; --multi lib has no graph form).
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
     for _pr, _xd, _fd, _gd, st_r in lib_shards:
         with torch.cuda.device(st_r.device): ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-    main_stream = torch.cuda.current_stream()
 
     def record(which):
-        ev[0][which].record(main_stream)
+        ev[0][which].record(bench_stream)
         for i, sh in enumerate(lib_shards): ev[1 + i][which].record(sh[4])
 
     for _ in range(args.warmup):
         step()
-    sync_all()
+    sync_all(); bench_stream.synchronize()
+    graph, graph_note = None, None
+    if not lib_mode and os.environ.get("FRX_BENCH_GRAPH", "1") != "0":
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=bench_stream):
+                for _ in range(args.steps):
+                    step(torch.cuda.current_stream().cuda_stream)
+            graph.replay(); bench_stream.synchronize()                   # untimed: the first replay uploads the graph
+        except Exception as e:                                           # a box whose runtime cannot capture: direct launches, and the line says so
+            graph, graph_note = None, "hipGraph capture failed (" + repr(e)[:120] + "): direct launches"
+    sync_all(); bench_stream.synchronize()
     if dist: dist.barrier()
     sync_all()
     t0 = time.perf_counter()
     record(0)
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        with torch.cuda.stream(bench_stream): graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     record(1)
-    sync_all()
+    sync_all(); bench_stream.synchronize()
     if dist: dist.barrier()
     sync_all()
     dt_wall = time.perf_counter() - t0
     dt = max(a.elapsed_time(b) for a, b in ev) * 1e-3
+    # the same K steps as direct launches (untimed by the contract; reported next to the graph figure)
+    e_d0, e_d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e_d0.record(bench_stream)
+    for _ in range(args.steps):
+        step()
+    e_d1.record(bench_stream)
+    sync_all(); bench_stream.synchronize()
+    dt_direct = e_d0.elapsed_time(e_d1) * 1e-3
     if dist:
-        t = torch.tensor([dt, dt_wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_wall, dt_direct], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_wall = float(t[0].item()), float(t[1].item())
+        dt, dt_wall, dt_direct = float(t[0].item()), float(t[1].item()), float(t[2].item())
     samples_per_step = prob.samples()
 
     # ---- the job's plan: every rank plans its own 32 candidates at the same time, then the only exchange of the whole job (winner selection) ----
@@ -349,6 +378,7 @@ def main():
     eval_bytes = int(alg_bytes + np.sum(16 * nx + 24 * nvert))
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
     fp64 = None
+    fp64_dyn = None                                                     # dynamic counts of the same gpurun call's counter pass (scripts/r05/gpu_pmc.sh), per launch class
     fc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_fp64_count_k_penalty.json", "r04_fp64_count_k_penalty.json", "r02_fp64_count_k_penalty.json")) if os.path.exists(f)), "")
     if os.path.exists(fc):
         fj = json.load(open(fc))
@@ -369,6 +399,15 @@ def main():
             if grids:
                 small = sorted(grids, key=lambda k: int(k.split("_")[1]))[0]
                 knot_traffic[key] = grids[small].get("traffic_bytes_per_launch_range")
+        fd = pj.get("fp64_k_penalty_lat", {})
+        if fd and "error" not in fd:
+            fcls = sorted(fd.items(), key=lambda kv: int(kv[0].split("_")[1]))
+            fp64_dyn = {"headline": fcls[0][1], "large_batch": fcls[-1][1], "source": os.path.relpath(pmc_file, ROOT),
+                        "what": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / SQ_WAVES of k_penalty_lat at the bench state (a lane is a sample): flops = ADD + MUL + TRANS + 2 FMA"}
+            if fp64:
+                fl = fcls[0][1]["flops_per_sample"]
+                fp64.update({"flops_per_sample": fl, "flops_per_sample_static_count": fp64["flops_per_sample"], "from_profile": True, "dynamic": fp64_dyn,
+                             "achieved_tflops": fl * samples_per_step / (pen_us * 1e-6) / 1e12, "frac": fl * samples_per_step / (pen_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS})
         cls = sorted(pj.get("valu_k_penalty_lat", {}).items(), key=lambda kv: int(kv[0].split("_")[1]))          # launch classes by grid size: headline, large batch
         if cls:
             valu = {"from_profile": True, "source": traffic_src, "headline_valu_busy": cls[0][1]["valu_busy_frac"], "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"],
@@ -393,7 +432,10 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / 30
         large = {"candidates": big.B, "avg_kernel_us": us, "achieved": big.algorithmic_bytes() / (us * 1e-6) / 1e9, "unit": "GB/s",
                  "frac": big.algorithmic_bytes() / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_samples_per_s": big.samples() / (us * 1e-6)}
-        if fp64: large["fp64_frac"] = fp64["flops_per_sample"] * big.samples() / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS
+        if fp64:
+            fl_big = fp64_dyn["large_batch"]["flops_per_sample"] if fp64_dyn else fp64["flops_per_sample"]
+            large["fp64_flops_per_sample"] = fl_big
+            large["fp64_frac"] = fl_big * big.samples() / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS
         big.close(); del Tb, Cb, ob_
 
     # the HBM-bound kernel of the path: the L-BFGS two-loop recursion (k_lbfgs_pre) streams every candidate's (s, y) history twice
@@ -553,6 +595,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_host_wall": dt_wall / args.steps * 1e3, "value_host_wall": world * samples_per_step * args.steps / dt_wall,
             "timing": "HIP events on the launch stream around the K steps (first launch -> last kernel end), inside the barrier + synchronize bracket whose host wall clock is ms_per_step_host_wall; max over ranks",
+            "launch": ("ONE hipGraph of the K steps (3 K kernel nodes, captured from K calls of frx_objective_eval_device)" if graph is not None else (graph_note or "K x 3 direct kernel launches")),
+            "ms_per_step_direct_launches": dt_direct / args.steps * 1e3, "value_direct_launches": world * samples_per_step * args.steps / dt_direct,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {B} candidate trajs/GPU x {N} pieces x {kappa} quadrature intervals "
                                    f"({samples_per_step} constraint samples/step/GPU), 16-gate Zhangjiajie-like corridor, K_i=8",
