@@ -36,12 +36,13 @@ with torch.cuda.stream(s):
                 for _ in range(K): prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
             g.replay(); s.synchronize()
             same = bool(torch.equal(g_dev, g_direct))
-            best = 1e9
-            for rep in range(5):
+            best = 1e9; series = []
+            for rep in range(8):
                 e0, e1 = ev(), ev()
                 e0.record(s); g.replay(); e1.record(s); s.synchronize()
-                best = min(best, e0.elapsed_time(e1) * 1e3 / K)
-            out[f"graph_K{K}_us_per_step"] = best; out[f"graph_K{K}_same_gradient"] = same
+                series.append(round(e0.elapsed_time(e1) * 1e3 / K, 3))
+                best = min(best, series[-1])
+            out[f"graph_K{K}_us_per_step"] = best; out[f"graph_K{K}_same_gradient"] = same; out[f"graph_K{K}_replays_in_order"] = series
         except Exception as e:
             out[f"graph_K{K}_error"] = repr(e)[:300]
 print(json.dumps(out))
