@@ -89,6 +89,12 @@ __device__ __forceinline__ double rk_ll_value(ll_u64 w0, ll_u64 w1) { return __l
 struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; double *gpub = nullptr; bool gwt = true;
                      const ll_u64 *o20ll = nullptr; unsigned o20tag = 0; unsigned *status = nullptr; ll_u64 spin_ticks = 0; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g; gpub (optional, global): and to this array, for the other workgroups of the cluster (write-through unless gwt is false)
 
+// What the forward map reads from the problem's index tables at its top, per candidate and per thread: offsets, this thread's piece (coarse index, interval
+// count), its pair's waypoint (vertex count, first vertex, first variable), the fixed end states of its axis.  Constant for the length of a plan: a RESIDENT
+// caller fetches them once (rk_leader_loop, load_candidate) and hands them in; fetched inside the body they cost it a scalar load and a dependent vector
+// load from L2 in front of everything else - 1 100 cycles before the first duration is formed (cycle stamps, round 5).
+struct KnotPre { int p0, N, c0, cN, x0, cv0, pc, piv, wnv, wvb, wxb; double bs[6]; };
+
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
 // `#pragma unroll 8` (one full memory latency per element and thread: 9.4k of the adjoint's 30k cycles, measured); clamped,
@@ -930,6 +936,9 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
         MR2(0, 2, kk) = make_double2(L[0], L[1]); MR2(0, 3, kk) = make_double2(L[2], L[3]);
     }
     double2 *sp = save ? (double2 *)(save + (gk0 + kk) * sstride) : nullptr;     // null: the multipliers stay in LDS (resident caller)
+    // (Round 5 tried the neighbours' (D^-1, L) straight out of their lanes' registers through the LDS crossbar - 32 ds_bpermute per step instead of four
+    // 16-byte LDS writes, a wait and eight 16-byte reads: bit-identical and SLOWER, the matrix wave done after 10.1 k cycles instead of 9.2 k, stage
+    // kernel 8.05 against 7.60 us.  profiles/NOTES.md)
     for (int it = 0; it < nst; it++) {
         const int s = 1 << it, buf = it & 1;
         const bool inlo = act && kk - s >= 1, inhi = act && kk + s <= N - 1;
@@ -985,13 +994,14 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
 // CUs share; the leader walks through forward map, adjoint and control code once per round, each time from L2).
 template <bool SH, int NR = 0>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
-                               int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr) {
+                               int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr,
+                               const KnotPre *pre = nullptr) {
     // ct_lds (optional, LDS, 19 doubles per piece: 18 coefficients + duration): a copy for the backward pass of the same workgroup
     const int nrow = NR > 0 ? NR : nrow_rt;
     const int k = threadIdx.x, nthr = NR > 0 ? 256 : (int)blockDim.x;
-    const int p0 = dp.poff[b], N = dp.poff[b + 1] - p0;
-    const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
-    const int x0 = dp.xoff[b];
+    const int p0 = pre ? pre->p0 : dp.poff[b], N = pre ? pre->N : dp.poff[b + 1] - p0;
+    const int c0 = pre ? pre->c0 : dp.coff[b], cN = pre ? pre->cN : dp.coff[b + 1] - c0;
+    const int x0 = pre ? pre->x0 : dp.xoff[b];
     double *rowbuf = sm;
     double *KP = rowbuf + (size_t)36 * nrow;          // knot positions  [3][nthr+1]
     double *KV = KP + 3 * (nrow + 1);
@@ -1009,16 +1019,19 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     int r_pc = 0, r_piv = 1, r_wnv = 1, r_wvb = 0, r_wxb = 0;
     // (first vertex of this candidate: the compiler fetches dp.* through VECTOR loads - it cannot prove that nothing in the kernel writes
     // there - and where the expression stood in the waypoint loops below, each axis wave paid a trip to L2 in the middle of its chain)
-    const int cv0 = __builtin_amdgcn_readfirstlane(dp.cvoff[b]);
+    const int cv0 = pre ? pre->cv0 : __builtin_amdgcn_readfirstlane(dp.cvoff[b]);
     double r_bs[6] = {0, 0, 0, 0, 0, 0};
-    if (k < N) { r_pc = dp.piece_coarse[p0 + k]; r_piv = dp.piece_iv[p0 + k]; }
+    if (pre) { r_pc = pre->pc; r_piv = pre->piv; }
+    else if (k < N) { r_pc = dp.piece_coarse[p0 + k]; r_piv = dp.piece_iv[p0 + k]; }
     // waypoint w is handled by the quad k >> 2 - or, when wave 0 is the free-running matrix wave (wsp64 below), by the PAIR (k - 64) >> 1
     const bool wsp64 = nrow == 64 && nthr == 256;
     const int t2 = k - 64;                                         // index among the axis waves
     const int wq = wsp64 ? (t2 >= 0 ? (t2 >> 1) : N) : (k >> 2);
-    if (wq < N - 1) { const int gw = p0 - b + wq; r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }
+    if (pre) { r_wnv = pre->wnv; r_wvb = pre->wvb; r_wxb = pre->wxb; }
+    else if (wq < N - 1) { const int gw = p0 - b + wq; r_wnv = dp.wp_nv[gw]; r_wvb = dp.wp_vbeg[gw]; r_wxb = dp.wp_xbeg[gw]; }
     const int kbs = wsp64 ? t2 : k;                                // the three threads that place the fixed end states
-    if (kbs >= 0 && kbs < 3) {
+    if (pre) { r_bs[0] = pre->bs[0]; r_bs[1] = pre->bs[1]; r_bs[2] = pre->bs[2]; r_bs[3] = pre->bs[3]; r_bs[4] = pre->bs[4]; r_bs[5] = pre->bs[5]; }
+    else if (kbs >= 0 && kbs < 3) {
 #pragma unroll
         for (int q = 0; q < 3; q++) { r_bs[q] = dp.headPVA[b * 9 + 3 * q + kbs]; r_bs[3 + q] = dp.tailPVA[b * 9 + 3 * q + kbs]; }
     }
@@ -1026,23 +1039,18 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     if (wsp64 && k == 0) *progress = 0u;
     {   // coalesced staging: every later access is an LDS access (the per-waypoint loops would otherwise serialise
         // one global-memory latency per vertex)
-        const int nx = dp.xoff[b + 1] - x0;
-        const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
-        const double *vsrc = dp.vrec + 3 * (size_t)v0;
         if (!ro) {
+            const int nx = dp.xoff[b + 1] - x0;
+            const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
+            const double *vsrc = dp.vrec + 3 * (size_t)v0;
             stage_to_lds<4>(xs, x + x0, nx, k, nthr);
             stage_to_lds<8>(vs, vsrc, nvd, k, nthr);
         }
     }
-    // Resident caller, <= 64 pieces, soft total time, <= 64 coarse pieces: the two workgroup barriers in front of the matrix wave order NOTHING - nothing is
-    // staged (x and the polytopes live in LDS), the durations are produced (threads i < cN) and consumed (threads k < N) by wave 0 alone, whose LDS
-    // operations complete in order, and the axis waves read Tf and the step counter only behind the barrier they share with the matrix wave.
-#if defined(FRX_FWD_SKIPB)
-    const bool skipb = ro != nullptr && nrow == 64 && nthr == 256 && dp.soft && cN <= 64;
-#else
-    const bool skipb = false;
-#endif
-    if (!skipb) __syncthreads();
+    // (Round 5: with a resident caller, <= 64 pieces, soft total time the two workgroup barriers in front of the matrix wave order nothing - nothing is staged,
+    // the durations are produced and consumed by wave 0 alone - and a build without them is bit-identical; it is also no faster: the duration is ready after
+    // 1.3 k cycles either way.  What that stretch WAS waiting for were the index-table loads, see KnotPre.)
+    __syncthreads();
     FRX_STAMP(1);
 
     // forwardT (CPU.hpp:626-676)
@@ -1061,7 +1069,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         Tc[Ms1] = 1.0 - sum;
         for (int i = 0; i <= Ms1; i++) Tc[i] *= dp.sumT;
     }
-    if (!skipb) __syncthreads();
+    __syncthreads();
     // splitToFineT (CPU.hpp:930-944)
     double hMine = 1.0;
     if (k < N) {

@@ -267,7 +267,23 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
     ro.wq = gp + xpad;                                                    // [nrow][4], forward map -> adjoint of the same evaluation
     ro.gpub = pub + a.NXP; ro.gwt = wt;                                   // the adjoint also stores the gradient where the history workgroups read it
     ro.vskew = 1;
+    // what the forward map would fetch from the index tables at every call (KnotPre, frx_kernels.hpp), fetched once per candidate.  Plain locals, put into the
+    // struct at the call: a struct that lives across the loop is not scalarised (it went to 104 bytes of scratch memory, like round 4's attempt with ResidentOps fields).
+    int kp_c0 = 0, kp_cN = 0, kp_cv0 = 0, kp_pc = 0, kp_piv = 1, kp_wnv = 1, kp_wvb = 0, kp_wxb = 0;
+    double kp_b0 = 0.0, kp_b1 = 0.0, kp_b2 = 0.0, kp_b3 = 0.0, kp_b4 = 0.0, kp_b5 = 0.0;
     auto load_candidate = [&]() {                                           // candidate c's constants and start point into the leader's LDS (once per plan)
+        {
+            kp_c0 = a.dp.coff[c]; kp_cN = a.dp.coff[c + 1] - kp_c0; kp_cv0 = a.dp.cvoff[c];
+            kp_pc = 0; kp_piv = 1; kp_wnv = 1; kp_wvb = 0; kp_wxb = 0;
+            if (t < v.N) { kp_pc = a.dp.piece_coarse[v.p0 + t]; kp_piv = a.dp.piece_iv[v.p0 + t]; }
+            const int t2 = t - 64, wq = t2 >= 0 ? (t2 >> 1) : v.N;         // the <= 64-piece form: waypoint of the lane PAIR (t - 64) >> 1
+            if (wq < v.N - 1) { const int gw = v.p0 - c + wq; kp_wnv = a.dp.wp_nv[gw]; kp_wvb = a.dp.wp_vbeg[gw]; kp_wxb = a.dp.wp_xbeg[gw]; }
+            kp_b0 = kp_b1 = kp_b2 = kp_b3 = kp_b4 = kp_b5 = 0.0;
+            if (t2 >= 0 && t2 < 3) {
+                kp_b0 = a.dp.headPVA[c * 9 + t2]; kp_b1 = a.dp.headPVA[c * 9 + 3 + t2]; kp_b2 = a.dp.headPVA[c * 9 + 6 + t2];
+                kp_b3 = a.dp.tailPVA[c * 9 + t2]; kp_b4 = a.dp.tailPVA[c * 9 + 3 + t2]; kp_b5 = a.dp.tailPVA[c * 9 + 6 + t2];
+            }
+        }
         const int v0 = a.dp.cvoff[c];
         const double *vsrc = a.dp.vrec + 3 * (size_t)v0;
         for (int w = t >> 2; w < v.N - 1; w += 64) {                       // a quad of lanes copies the polytope of waypoint w, w doubles further on
@@ -462,7 +478,8 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 RK_TR(41);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // x is complete in LDS (no vmcnt: the trial point's stores to `pub` drain behind the forward map)
                 RK_PROF(RK_P_VECTORS);
-                forward_knot_body<true, NR>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt, &ro);
+                const KnotPre kpre{v.p0, v.N, kp_c0, kp_cN, v.xbase, kp_cv0, kp_pc, kp_piv, kp_wnv, kp_wvb, kp_wxb, {kp_b0, kp_b1, kp_b2, kp_b3, kp_b4, kp_b5}};
+                forward_knot_body<true, NR>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, a.nrow, a.pcrw, a.nsteps, c, ev, ctl, wt, &ro, NR == 64 ? &kpre : nullptr);
                 kind = PH_CT; lstage = 2;
                 RK_PROF(RK_P_FORWARD);
             } else {

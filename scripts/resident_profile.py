@@ -1,7 +1,7 @@
 """Per-segment time of the resident round kernel (FRX_RESIDENT_PROF instantiation): leader, dense and one plain member workgroup of
 candidate 0, microseconds per round.  Usage: python scripts/resident_profile.py [B] [N] [kappa] [max_iterations]"""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ["FRX_ROOT"]) if os.environ.get("FRX_ROOT") else os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # FRX_ROOT: a variant directory
 import numpy as np
 from frx_import import frx
 from fast_racing_amd import scenario as sc
