@@ -336,6 +336,8 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     ge.lds_fwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 3) + p->maxN + p->maxCN);
     ge.lds_bwd = sizeof(double) * ((size_t)6 * p->maxN * (FRX_BAND_W + 6) + 2 * (size_t)p->maxN + p->maxCN);
     ge.lds_pen = sizeof(double) * ((size_t)ge.ppg * 19 + (size_t)ge.ppg * (p->Kmax + 1) * 4 + (size_t)64 * ge.pen_w * 21);
+    // large batches (four-wave workgroups), one sample per lane: the two-phase form of the integrator (k_penalty_lat2) - half the transpose buffer, four waves per SIMD
+    ge.lds_pen2 = (ge.pen_w == 4 && spp <= 64) ? sizeof(double) * ((size_t)ge.ppg * 19 + (size_t)ge.ppg * (p->Kmax + 1) * 4 + (size_t)64 * ge.pen_w * 11) : 0;
     ge.solver = frx::SOLVER_KNOT_PCR;
     ge.knot_threads = 64 * ((p->maxN + 63) / 64);
     {

@@ -17,6 +17,7 @@ int launch_set_limits(const LaunchGeom &g) {
     if ((e = hipFuncSetAttribute((const void *)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_penalty, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_penalty_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
+    if (g.lds_pen2 && (e = hipFuncSetAttribute((const void *)k_penalty_lat2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen2)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_forward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_backward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_forward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
@@ -37,7 +38,10 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
     static const int forced = [] { const char *e = std::getenv("FRX_PENALTY_FORM"); return !e ? 0 : e[0] == 'l' ? 1 : 2; }();
     const bool lat = forced != 2;
     const int nwg = (dp.P + g.ppg - 1) / g.ppg;
-    if (lat) hipLaunchKernelGGL(k_penalty_lat, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+    const char *tp_env = std::getenv("FRX_PENALTY_TWOPHASE");           // (read per launch: the test toggles it inside one process)
+    const bool two_phase = !(tp_env && tp_env[0] == '0');
+    if (lat && two_phase && g.lds_pen2) hipLaunchKernelGGL(k_penalty_lat2, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen2, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+    else if (lat) hipLaunchKernelGGL(k_penalty_lat, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
     else hipLaunchKernelGGL(k_penalty, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
     return (int)hipGetLastError();
 }

@@ -44,6 +44,7 @@ struct LaunchGeom {
     int maxN, maxCN, Kmax, lpp, ppw;       // lpp lanes per piece; ppw = 64 / lpp pieces per WAVE (the resident round kernel's per-wave tasks)
     int pen_w, ppg;                        // stage kernel k_penalty: waves per workgroup (1..4, chosen for lane utilisation) and pieces per workgroup = 64 pen_w / lpp
     size_t lds_fwd, lds_bwd, lds_pen;      // banded-LU kernels + penalty kernel
+    size_t lds_pen2;                       // the two-phase form of the penalty kernel (k_penalty_lat2: pen_w = 4, one sample per lane), 0 = not applicable
     int solver;                            // SOLVER_KNOT_PCR (default) | SOLVER_BANDED_LU
     int knot_threads;                      // workgroup size of the knot kernels: 64 * ceil(maxN / 64)
     size_t lds_kfwd, lds_kbwd;

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__r
 // ds_read2_b64) whatever the optimiser can or cannot prove about the pointer's address space, and fence() makes the address opaque:
 // what was read before it is not kept in registers across a phase boundary but read again.
 typedef const __attribute__((address_space(3))) double *lds_cdptr;
+#ifndef FRX_PEN_OCC
+#define FRX_PEN_OCC 3
+#endif
 struct LdsView {
     unsigned off;
     __device__ __forceinline__ explicit LdsView(const double *p) : off((unsigned)(uintptr_t)(lds_cdptr)p) {}
@@ -283,6 +286,32 @@ struct LdsView {
     __device__ __forceinline__ void fence() { asm volatile("" : "+v"(off)); }
 };
 
+// The 20 partials {cost, d/dT, d/dc[6][3]} of ONE quadrature sample (sample j of its piece, local time s1 = step j, trapezoid weight omg).
+template <bool LAT>
+__device__ __forceinline__ void penalty_sample_partials(const DevProblem &dp, LdsView &c, LdsView &hb, int K, int Kmax, double s1, double step, double omg, double invK, int j, double (&o)[20]) {
+    double adj[12], Ps, gTa;
+    penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, Kmax, adj, Ps, gTa);
+    if (!LAT) { c.fence(); FRX_PHASE(); }
+    o[0] = omg * step * Ps; o[1] = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
+    const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+    const double b0[6] = {1.0, s1, s2, s3, s4, s5};
+    const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+    const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+    const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+    // beta_m (x) a_m, m = 0..3, WITHOUT the structural zeros of the derivative bases (beta_m[k] = 0 for k < m).  Written as the full 4-term sum the
+    // compiler kept them - it may not fold 0 * x, which is NaN for a non-finite x: 18 of the 72 FMAs of a sample multiplied by a literal zero
+    // (v_fmac_f64 v, 0, v in the round-4 ISA).  Same products, same order of the remaining additions: the finite results are bit for bit the old ones.
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double acc = b0[k] * adj[d];
+            if (k >= 1) acc = acc + b1[k] * adj[3 + d];
+            if (k >= 2) acc = acc + b2[k] * adj[6 + d];
+            if (k >= 3) acc = acc + b3[k] * adj[9 + d];
+            o[2 + 3 * k + d] = acc;
+        }
+}
 // The samples of ONE lane (sample jl, jl + lpp, ... of the piece whose coefficients are at cS and corridor block at hS, duration Tp): their 20 partials
 // {cost, d/dT, d/dc[6][3]} accumulated into the lane's LDS slot `mine`.
 template <bool LAT>
@@ -296,30 +325,9 @@ __device__ __forceinline__ void penalty_lane_samples(const DevProblem &dp, const
     for (int j = jl; j <= kappa; j += lpp) {
         const double s1 = step * j;                           // sample abscissa as cc.cu:152
         const double omg = (j == 0 || j == kappa) ? 0.5 : 1.0;   // CPU.hpp:306
-        double adj[12], Ps, gTa;
-        penalty_sample<LAT>(c, s1, omg * step, dp.pc, hb, K, Kmax, adj, Ps, gTa);
-        if (!LAT) { c.fence(); FRX_PHASE(); }
-        // the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates
         double o[20];
-        o[0] = omg * step * Ps; o[1] = (invK * j) * gTa + omg * Ps * invK;   // CPU.hpp:259,342-343
-        const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-        const double b0[6] = {1.0, s1, s2, s3, s4, s5};
-        const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
-        const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
-        const double b3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
-        // beta_m (x) a_m, m = 0..3, WITHOUT the structural zeros of the derivative bases (beta_m[k] = 0 for k < m).  Written as the full 4-term sum the
-        // compiler kept them - it may not fold 0 * x, which is NaN for a non-finite x: 18 of the 72 FMAs of a sample multiplied by a literal zero
-        // (v_fmac_f64 v, 0, v in the round-4 ISA).  Same products, same order of the remaining additions: the finite results are bit for bit the old ones.
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double acc = b0[k] * adj[d];
-                if (k >= 1) acc = acc + b1[k] * adj[3 + d];
-                if (k >= 2) acc = acc + b2[k] * adj[6 + d];
-                if (k >= 3) acc = acc + b3[k] * adj[9 + d];
-                o[2 + 3 * k + d] = acc;
-            }
+        penalty_sample_partials<LAT>(dp, c, hb, K, Kmax, s1, step, omg, invK, j, o);
+        // (the 20 partials of this sample; with more than one sample per lane (kappa + 1 > 64) the lane's LDS slot accumulates)
         if (!first) {
 #pragma unroll
             for (int i = 0; i < 20; i++) o[i] += mine[i];
@@ -420,11 +428,82 @@ __global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double 
 }
 // The latency form of the same kernel (penalty_sample<LAT>: no phase boundaries, 148 VGPRs) - the default: faster than the phased form at
 // every batch size measured.
-__global__ __launch_bounds__(256, 3) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+__global__ __launch_bounds__(256, FRX_PEN_OCC) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
                                                         double *__restrict__ out20, int lpp, int ppg, int Kmax) {
     extern __shared__ double sm[];
     const int gp0 = blockIdx.x * ppg;
     penalty_body<false, true>(dp, T, C, out20, lpp, ppg, Kmax, gp0, min(ppg, dp.P - gp0), sm, threadIdx.x, true, blockDim.x);
+}
+
+// Large batches, one sample per lane (kappa + 1 <= 64), four-wave workgroups: the SAME samples and the same fixed-order sums, but the 20 partials cross the
+// LDS transpose in TWO halves of ten, so that the transpose buffer is [256][11] instead of [256][21] doubles - 29 instead of 49 KB per workgroup at
+// K = 8 - and the kernel is compiled for four waves per SIMD (128 VGPRs).  The one-phase form fits three workgroups on a CU by LDS and three waves on a SIMD by
+// registers, and its launch at 1024 candidates spends a quarter of its wave cycles waiting: more workgroups in flight hide the staging trips of one
+// another.  Bit-identical partials (each value is still summed over its piece's samples in sample order); FRX_PENALTY_TWOPHASE=0 keeps the one-phase launch.
+// Dynamic LDS (doubles): cS[ppg*18] | tS[ppg] | hS[ppg*(Kmax+1)*4] | red[blockDim.x * 11]
+__global__ __launch_bounds__(256, 4) void k_penalty_lat2(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                         double *__restrict__ out20, int lpp, int ppg, int Kmax) {
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x, nthr = blockDim.x;
+    const int gp0 = blockIdx.x * ppg, npieces = min(ppg, dp.P - gp0);
+    const int hstride = (Kmax + 1) * 4;
+    double *cS = sm, *tS = cS + ppg * 18, *hS = tS + ppg, *red = hS + (size_t)ppg * hstride;
+    const int pl = lane / lpp, jl = lane - pl * lpp;
+    const int pfl = (dp.piece_active && pl < npieces) ? dp.piece_active[gp0 + pl] : DV_EVAL;
+    {   // staging as in penalty_body (16-byte loads, every sweep's first trips in flight before the first LDS store)
+        const double2 *h2 = (const double2 *)(dp.hblk + (size_t)gp0 * hstride), *c2 = (const double2 *)(C + (size_t)gp0 * 18);
+        const int nh2 = (npieces * hstride) >> 1, nc2 = (npieces * 18) >> 1;
+        double2 hv0 = make_double2(0.0, 0.0), hv1 = hv0, cv0 = hv0;
+        double tv = 0.0;
+        if (lane < nh2) hv0 = h2[lane];
+        if (lane + nthr < nh2) hv1 = h2[lane + nthr];
+        if (lane < nc2) cv0 = c2[lane];
+        if (lane < npieces) tv = T[gp0 + lane];
+        if (lane < nh2) { hS[2 * lane] = hv0.x; hS[2 * lane + 1] = hv0.y; }
+        if (lane + nthr < nh2) { hS[2 * (lane + nthr)] = hv1.x; hS[2 * (lane + nthr) + 1] = hv1.y; }
+        if (lane < nc2) { cS[2 * lane] = cv0.x; cS[2 * lane + 1] = cv0.y; }
+        for (int i = lane + nthr; i < nc2; i += nthr) { const double2 v = c2[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }
+        if (lane < npieces) tS[lane] = tv;
+#pragma unroll 2
+        for (int i = lane + 2 * nthr; i < nh2; i += nthr) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }
+    }
+    __syncthreads();
+    const bool active = pl < npieces && (pfl & DV_EVAL);
+    double o[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) o[i] = 0.0;
+    if (active) {
+        LdsView c(cS + pl * 18), hb(hS + (size_t)pl * hstride);
+        const int K = (int)hb[3], kappa = dp.kappa;
+        const double step = tS[pl] / kappa;                                   // CPU.hpp:245
+        penalty_sample_partials<true>(dp, c, hb, K, Kmax, step * jl, step, (jl == 0 || jl == kappa) ? 0.5 : 1.0, dp.inv_kappa, jl, o);
+    }
+    double *mine = red + lane * 11;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (half) __syncthreads();                                            // the first half has been summed: its slots are free
+#pragma unroll
+        for (int i = 0; i < 10; i++) mine[i] = o[10 * half + i];
+        __syncthreads();
+        for (int idx = lane; idx < npieces * 10; idx += nthr) {
+            const int p2 = idx / 10, v = idx - p2 * 10;
+            const double *src = red + (p2 * lpp) * 11 + v;
+            double s = 0.0;
+            int l = 0;
+            for (; l + 16 <= lpp; l += 16) {                                  // (as penalty_reduce: sixteen reads in flight, one chain of additions in sample order)
+                double b[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) b[j] = src[(l + j) * 11];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; j++) s += b[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll 4
+            for (; l < lpp; l++) s += src[l * 11];
+            out20[(size_t)(gp0 + p2) * 20 + 10 * half + v] = s;
+        }
+    }
 }
 
 // (Streaming forms for large batches - persistent workgroups walking over the groups of pieces with the next group's operands in flight during the

@@ -454,6 +454,30 @@ def test_lost_round_is_reported_and_the_handle_stays_usable(frx, sc):
     p.close(); q.close()
 
 
+@pytest.mark.parametrize("obst", [False, True])
+def test_two_phase_form_of_the_large_batch_integrator_is_bit_identical(frx, sc, monkeypatch, obst):
+    """Large batches of one-sample-per-lane problems run the penalty integrator in its two-phase form (k_penalty_lat2: the 20 partials cross the LDS transpose in
+    two halves, four waves per SIMD); FRX_PENALTY_TWOPHASE=0 launches the one-phase form on the same geometry.  Same samples, same order of every sum: the
+    outputs are equal bit for bit - also with K_i up to 14 half-spaces per piece and active obstacle penalties."""
+    B0, N, gates, kappa = sc.CONFIGS["headline"]
+    base = [sc.make_candidate(0, N, gates, perturb_id=b, obstacles=obst) for b in range(B0)]
+    small = frx.Problem(base, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x = small.optimize(1e-6, max_iterations=15)["x"]                       # a state with active penalties
+    T, Cf = small.forward(x)
+    small.close()
+    rep = 10
+    big = frx.Problem(base * rep, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    Tb, Cb = np.tile(T, rep), np.tile(Cf.reshape(-1), rep)
+    two = big.penalty(Tb, Cb)
+    monkeypatch.setenv("FRX_PENALTY_TWOPHASE", "0")
+    one = big.penalty(Tb, Cb)
+    monkeypatch.delenv("FRX_PENALTY_TWOPHASE")
+    big.close()
+    assert np.any(two[0] > 0.0)
+    for a, b in zip(two, one):
+        assert np.array_equal(a, b)
+
+
 def test_penalty_of_a_large_batch_reproduces_the_small_batch(frx, sc):
     """320 candidates = the 32 headline candidates ten times over (6827 wave-tasks, more than twice the chip's 3072 wave slots: the grid
     runs in several waves of workgroups): every replica must reproduce the 32-candidate batch, which the tests above check against the
