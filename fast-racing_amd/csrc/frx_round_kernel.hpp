@@ -457,6 +457,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                     // the history workgroups take their chunks of the start point and its gradient as "previous point" (phase INIT, once
                     // per plan): the gradient is in `pub` already (adjoint), the start point is not - it was never a trial point
                     for (int i = t; i < n; i += 256) { const double gv = g[i], xv = x[i]; dv[i] = -gv; xp[i] = xv; gp[i] = gv; stg<true>(pub + i, xv, wt); }
+                    if (t == 0) { stg<true>(pub + 2 * a.NXP, 0.0, wt); stg<true>(pub + 2 * a.NXP + 1, 1.0, wt); }   // the plan's first accepted step: slot 0, one pair (see the gather)
                     kind = PH_INIT;
                 }
                 lstage = 1;
@@ -586,6 +587,13 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 }
             }
             trial_done = with_trial;
+            // The NEXT accepted step's slot and pair count follow from this one's, whenever that step comes: they go to `pub` HERE - every workgroup of the
+            // cluster has read this step's (the direction is back) - and drain with the forward map's publication.  Until round 4 they were stored behind the
+            // prediction, and the phase word of every predicted ADVANCE waited for their acknowledgement from L2 (0.3-0.4 us of every accepted round).
+            if (t == 0) {
+                const int nslot = jnew + 1 == v.m ? 0 : jnew + 1, nbound = min(v.m, bound + 1);
+                stg<true>(pub + 2 * a.NXP, (double)nslot, wt); stg<true>(pub + 2 * a.NXP + 1, (double)nbound, wt);
+            }
             if (__builtin_expect(a.dbg != nullptr, 0) && c < a.dbg_cands && nadv_l < (unsigned)a.dbg_cap) {     // direction log (tests): what came back for the pair logged by accept_step
                 const size_t rec = 4 * (size_t)a.NXP + 2;
                 double *row = a.dbg + a.B + ((size_t)c * a.dbg_cap + nadv_l) * rec;
@@ -731,7 +739,7 @@ __device__ __forceinline__ void rk_leader_loop(const RoundArgs &a, RoundView v, 
                 // The predicted ADVANCE goes to the cluster HERE, straight behind the prediction: slot and pair count, the drain of the gradient's copy,
                 // the phase word.  The members start on the direction while the leader closes the round, walks back to the top of its loop and takes
                 // the step over in its own vectors (timeline, round 4: 1.5 us lay between the prediction and the phase word).
-                if (t == 0) { stg<true>(pub + 2 * a.NXP, (double)((pred_word >> 8) & 0xFFFu), wt); stg<true>(pub + 2 * a.NXP + 1, (double)((pred_word >> 20) & 0xFFFu), wt); }
+                // (slot and pair count of this step are in `pub` since the previous step's gather - or since INIT for a plan's first step)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 rk_drain_and_meet();
                 pseq++;
