@@ -246,8 +246,9 @@ def main():
             with torch.cuda.graph(graph, stream=bench_stream):
                 for _ in range(args.steps):
                     step(torch.cuda.current_stream().cuda_stream)
-            for _ in range(GRAPH_WARM_REPLAYS):                           # untimed: the first replay uploads the graph, the second still runs 10 % slow (22.0 against
-                graph.replay()                                           # 19.6-19.8 us per step from the third on, scripts/r05/graph_probe.py): warm-up, reported as such
+            with torch.cuda.stream(bench_stream):                         # (on the stream the timed replay uses: a replay on another stream is a first replay again)
+                for _ in range(GRAPH_WARM_REPLAYS):                       # untimed: the first replay uploads the graph, the second still runs 10 % slow (22.0 against
+                    graph.replay()                                       # 19.6-19.8 us per step from the third on, scripts/r05/graph_probe.py): warm-up, reported as such
             bench_stream.synchronize()
         except Exception as e:                                           # a box whose runtime cannot capture: direct launches, and the line says so
             graph, graph_note = None, "hipGraph capture failed (" + repr(e)[:120] + "): direct launches"
@@ -267,6 +268,16 @@ def main():
     sync_all()
     dt_wall = time.perf_counter() - t0
     dt = max(a.elapsed_time(b) for a, b in ev) * 1e-3
+    # (diagnostic) the same graph replayed back to back: the timed replay above starts on an EMPTY queue, so its interval carries one graph submission (10-20 us, i.e.
+    # 0.5-1 us per step at K = 20: the first replay of every burst measures 19.9-20.6 us per step, the following ones 19.5, scripts/r05/graph_ramp_probe.py)
+    dt_b2b = None
+    if graph is not None:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        with torch.cuda.stream(bench_stream):
+            graph.replay(); evs[0].record(bench_stream)
+            for i in range(4): graph.replay(); evs[i + 1].record(bench_stream)
+        bench_stream.synchronize()
+        dt_b2b = min(evs[i].elapsed_time(evs[i + 1]) for i in range(4)) * 1e-3
     # the same K steps as direct launches (untimed by the contract; reported next to the graph figure)
     e_d0, e_d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e_d0.record(bench_stream)
@@ -600,6 +611,7 @@ def main():
             "timing": "HIP events on the launch stream around the K steps (first launch -> last kernel end), inside the barrier + synchronize bracket whose host wall clock is ms_per_step_host_wall; max over ranks",
             "launch": ("ONE hipGraph of the K steps (3 K kernel nodes, captured from K calls of frx_objective_eval_device)" if graph is not None else (graph_note or "K x 3 direct kernel launches")),
             "warmup_graph_replays": GRAPH_WARM_REPLAYS if graph is not None else 0,
+            "ms_per_step_graph_replayed_back_to_back": (dt_b2b / args.steps * 1e3) if dt_b2b else None,
             "ms_per_step_direct_launches": dt_direct / args.steps * 1e3, "value_direct_launches": world * samples_per_step * args.steps / dt_direct,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {B} candidate trajs/GPU x {N} pieces x {kappa} quadrature intervals "
