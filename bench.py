@@ -7,14 +7,17 @@
 
 A "step" is ONE batched cost/gradient evaluation x -> (f, grad f) of the headline workload
 (BASELINE.json configs[2]: 32 candidate trajectories x 64 pieces x 16 quadrature intervals,
-synthetic Zhangjiajie-like 16-gate corridor) = the three kernels k_forward, k_penalty, k_backward
-on inputs that are already resident in HBM.  value = constraint-samples/s = ranks * B*N*(kappa+1) * K / t,
+synthetic Zhangjiajie-like 16-gate corridor) = forward map, penalty integral and adjoint (one launch of k_eval_cluster at this
+batch size; three stage kernels for batches the chip does not hold at once) on inputs that are already resident in HBM.  value = constraint-samples/s = ranks * B*N*(kappa+1) * K / t,
 t = max over ranks of the barrier-bracketed wall time of the K steps.  Weak scaling: every rank
 owns its own batch of 32 candidates (different gate perturbations); the evaluation needs no
 collective — the only exchange is the final winner selection, outside the timed region.
 
 The JSON line also carries:
-  roofline      the penalty integrator k_penalty (the kernel SURVEY.md §8d prices): algorithmic bytes (sum over pieces of
+  roofline      the dominant kernel of the timed region.  Batches the chip holds at once are evaluated by ONE launch (k_eval_cluster,
+                csrc/frx_eval_kernel.hpp): SURVEY.md §8d's bytes of a full objective evaluation fused on device / its average duration; the
+                penalty integrator alone (the kernel §8d prices per piece) is roofline.penalty_integrator.  Other batches: three stage
+                launches, and the object is the penalty integrator's: algorithmic bytes (sum over pieces of
                 312 + 48 K_i) / its average duration, HIP events on the library's launch stream, measured in this run;
                 roofline.evaluation = the whole step against §8d's bytes of an evaluation (penalty bytes + 16 n + 24 sum nv per
                 candidate); the two knot kernels with their IMPLEMENTATION traffic (stage buffers, saved multipliers - not
@@ -362,6 +365,14 @@ def main():
     # the three stage kernels one at a time (HIP events on the library's launch stream, frx_eval_stage_times): the roofline object is
     # reported for the penalty integrator (the kernel SURVEY.md 8d prices); the two knot kernels get sub-objects with their implementation traffic
     stage_us = prob.stage_times(x_state, reps=max(args.steps, 100))
+    # ... and the evaluation in the form the timed steps took: ONE launch of clusters (frx::k_eval_cluster, csrc/frx_eval_kernel.hpp) when the batch fits the chip at
+    # once - then THAT kernel is the dominant (the only) kernel of the timed region and the roofline object is reported for it, against SURVEY.md 8d's bytes of a
+    # "full objective evaluation fused on device"; the penalty integrator alone (the stage kernel) moves to roofline.penalty_integrator.
+    fused_G = prob.eval_fused()
+    one_us = prob.eval_launch_time(x_state, reps=max(args.steps, 100)) if fused_G else None
+    prob.set_eval_fused(False)
+    three_us = prob.eval_launch_time(x_state, reps=max(args.steps, 100))
+    prob.set_eval_fused(True)
     # evaluation time along the optimisation (SURVEY.md 8d "kernel-only benchmark state"): the reference initial guess and the iterates
     # after 10 / 20 / 40 / 80 iterations; the headline `value` is taken at the 60-iteration state above
     states = []
@@ -403,7 +414,7 @@ def main():
     # Counter passes (rocprofv3 --pmc, one counter set per pass, scripts/r03/gpu_pmc.sh) of the gpurun call that produced the committed bench line:
     # read from profiles/, never measured inside this process - hence "from_profile".  FETCH_SIZE / WRITE_SIZE are converted to bytes with the
     # factors calibrated in the same call on a coalesced copy of known size (8-byte and 16-byte accesses per lane).
-    traffic, traffic_src, valu, knot_traffic, calib = None, None, None, {}, None
+    traffic, traffic_src, valu, knot_traffic, calib, one_traffic = None, None, None, {}, None, None
     pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_headline.json", "r04_pmc_headline.json", "r03_pmc_headline.json")) if os.path.exists(f)), None)
     if pmc_file and args.config == "headline":
         pj = json.load(open(pmc_file))
@@ -413,6 +424,7 @@ def main():
             if grids:
                 small = sorted(grids, key=lambda k: int(k.split("_")[1]))[0]
                 knot_traffic[key] = grids[small].get("traffic_bytes_per_launch_range")
+        one_traffic = pj.get("k_eval_cluster", {}).get("traffic_bytes_per_launch_range")
         fd = pj.get("fp64_k_penalty_lat", {})
         if fd and "error" not in fd:
             fcls = sorted(fd.items(), key=lambda kv: int(kv[0].split("_")[1]))
@@ -609,29 +621,50 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_host_wall": dt_wall / args.steps * 1e3, "value_host_wall": world * samples_per_step * args.steps / dt_wall,
             "timing": "HIP events on the launch stream around the K steps (first launch -> last kernel end), inside the barrier + synchronize bracket whose host wall clock is ms_per_step_host_wall; max over ranks",
-            "launch": ("ONE hipGraph of the K steps (3 K kernel nodes, captured from K calls of frx_objective_eval_device)" if graph is not None else (graph_note or "K x 3 direct kernel launches")),
+            "launch": ((f"ONE hipGraph of the K steps ({'K kernel nodes: one k_eval_cluster launch per step' if fused_G else '3 K kernel nodes'}, captured from K calls of frx_objective_eval_device)") if graph is not None
+                       else (graph_note or ("K direct launches of k_eval_cluster" if fused_G else "K x 3 direct kernel launches"))),
+            "evaluation_form": ({"kernel": "frx::k_eval_cluster", "workgroups_per_candidate": fused_G, "what": "one launch per evaluation: a cluster of workgroups per candidate (leader: forward map and adjoint; members: penalty integral), csrc/frx_eval_kernel.hpp",
+                                 "us_per_evaluation_back_to_back_launches": one_us, "us_per_evaluation_as_three_stage_launches": three_us}
+                                if fused_G else {"kernel": "three stage kernels", "us_per_evaluation_back_to_back_launches": three_us}),
             "warmup_graph_replays": GRAPH_WARM_REPLAYS if graph is not None else 0,
             "ms_per_step_graph_replayed_back_to_back": (dt_b2b / args.steps * 1e3) if dt_b2b else None,
             "ms_per_step_direct_launches": dt_direct / args.steps * 1e3, "value_direct_launches": world * samples_per_step * args.steps / dt_direct,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {B} candidate trajs/GPU x {N} pieces x {kappa} quadrature intervals "
                                    f"({samples_per_step} constraint samples/step/GPU), 16-gate Zhangjiajie-like corridor, K_i=8",
-                       "step": "one batched objective evaluation x->(f,grad): k_forward + k_penalty + k_backward, inputs resident in HBM",
+                       "step": "one batched objective evaluation x->(f,grad), inputs resident in HBM: " + ("forward map + penalty integral + adjoint in ONE launch (k_eval_cluster)" if fused_G else "k_forward + k_penalty + k_backward"),
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective",
                        "front_end": ("frx_multi_* in one process" if lib_mode else "one process per GPU (torch.distributed)") if world > 1 else "one process, one device"},
-            "roofline": {"bound": "hbm", "kernel": pen_kernel, "selected_by": "the kernel SURVEY.md 8d prices: the penalty integrator (CPU.hpp:188-408 = cuda_computer::compute)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,
-                         "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_stage_times)",
-                         "traffic": traffic, "traffic_from_profile": traffic is not None, "traffic_source": traffic_src, "counter_calibration_bytes_per_counted_byte": calib,
-                         "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6), "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6),
+            "roofline": {**({"bound": "hbm", "kernel": "frx::k_eval_cluster", "selected_by": "the dominant (only) kernel of the timed region: one launch per evaluation",
+                             "achieved": eval_bytes / (one_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eval_bytes / (one_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": eval_bytes, "algorithmic_bytes_definition": "SURVEY.md 8d, full objective evaluation fused on device: penalty bytes (sum over pieces of 312 + 48 K_i) + 16 n + 24 sum(nv) per candidate",
+                             "avg_kernel_us": one_us, "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_launch_time)",
+                             "traffic": (0.5 * (one_traffic[0] + one_traffic[1]) if one_traffic else None), "traffic_range": one_traffic, "traffic_from_profile": one_traffic is not None, "traffic_source": traffic_src if one_traffic else None,
+                             "traffic_note": "FETCH_SIZE / WRITE_SIZE of k_eval_cluster, bracketed by the 8-byte and the 16-byte calibration of the same call (its loads are a mix); includes the granules that carry (C, T) and the partials between the workgroups (2 x 16 bytes per value)",
+                             "counter_calibration_bytes_per_counted_byte": calib,
+                             "kernel_samples_per_s": samples_per_step / (one_us * 1e-6), "workgroups_per_candidate": fused_G,
+                             "bound_in_fact": "latency: per candidate one dependent chain - forward map (one wave per axis behind a matrix wave), penalty share of 24 member waves, adjoint - on 7 of 256 CUs; nothing of it streams",
+                             "penalty_integrator": {"what": "the penalty integrator alone, as a stage kernel (the kernel SURVEY.md 8d prices; it is what large batches and the optimiser's per-stage rounds launch)",
+                                                    "kernel": pen_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,
+                                                    "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_stage_times)",
+                                                    "traffic": traffic, "traffic_from_profile": traffic is not None, "traffic_source": traffic_src,
+                                                    "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6), "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)}}
+                            if fused_G else
+                            {"bound": "hbm", "kernel": pen_kernel, "selected_by": "the kernel SURVEY.md 8d prices: the penalty integrator (CPU.hpp:188-408 = cuda_computer::compute)",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,
+                             "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_stage_times)",
+                             "traffic": traffic, "traffic_from_profile": traffic is not None, "traffic_source": traffic_src, "counter_calibration_bytes_per_counted_byte": calib,
+                             "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6), "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)}),
                          "fp64": fp64, "valu": valu, "large_batch": large,
-                         "evaluation": {"what": "one whole step x -> (f, grad): forward map + penalty integrator + adjoint (three launches)",
+                         "evaluation": {"what": "one whole step x -> (f, grad) as timed (`value`): forward map + penalty integrator + adjoint, " + ("one launch" if fused_G else "three launches"),
                                         "algorithmic_bytes_per_step": eval_bytes, "definition": "SURVEY.md 8d: penalty bytes + 16 n + 24 sum(nv) per candidate",
                                         "us_per_step": dt / args.steps * 1e6, "achieved": eval_bytes / (dt / args.steps) / 1e9, "unit": "GB/s",
                                         "frac": eval_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_kernels_us": stage_us,
+                         "stage_kernels_note": "the three stage kernels of an evaluation, one at a time" + (" (not what the timed steps launched: see evaluation_form)" if fused_G else ""),
                          "knot_kernels": {k: {"kernel": {"forward": "frx::k_forward_knot64", "adjoint": "frx::k_backward_knot64"}[k] if N <= 64 else {"forward": "frx::k_forward_knot", "adjoint": "frx::k_backward_knot"}[k], "avg_kernel_us": stage_us[k],
                                               "implementation_traffic_bytes": stage_bytes[k],
                                               "implementation_traffic_note": "x, waypoint polytopes, (T, C), out20, saved reduction multipliers, g: stage buffers between the three launches, NOT algorithmic bytes",

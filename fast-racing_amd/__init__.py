@@ -71,6 +71,7 @@ ABI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
     "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
+    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_eval_launch_time", "frx_debug_profile_eval_cluster",
 ]
 
 _lib = None
@@ -114,6 +115,10 @@ def lib():
         L.frx_debug_resident_clusters.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.frx_dilate_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
         L.frx_eval_stage_times.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.frx_eval_launch_time.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.frx_debug_set_eval_fused.argtypes = [C.c_void_p, C.c_int]
+        L.frx_debug_eval_fused.argtypes = [C.c_void_p]
+        L.frx_debug_profile_eval_cluster.argtypes = [C.c_void_p, _dp, C.c_void_p]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_multi_destroy.argtypes = [C.c_void_p]
         L.frx_multi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
@@ -555,6 +560,26 @@ class Problem:
         out = np.zeros(3)
         _check(lib().frx_eval_stage_times(self.h, np.ascontiguousarray(x, dtype=np.float64), reps, out))
         return {"forward": float(out[0]), "penalty": float(out[1]), "adjoint": float(out[2])}
+
+    def eval_launch_time(self, x, reps: int = 100) -> float:
+        """Average microseconds of one evaluation at x in the form frx_objective_eval_device takes (HIP events inside the library)."""
+        out = np.zeros(1)
+        _check(lib().frx_eval_launch_time(self.h, np.ascontiguousarray(x, dtype=np.float64), reps, out))
+        return float(out[0])
+
+    def profile_eval_cluster(self, x):
+        """Shader-clock stamps of cluster 0 during one evaluation in the one-launch form (frx_debug.h: frx_debug_profile_eval_cluster)."""
+        out = np.zeros(64, np.int64)
+        _check(lib().frx_debug_profile_eval_cluster(self.h, np.ascontiguousarray(x, dtype=np.float64), out.ctypes.data))
+        return out
+
+    def set_eval_fused(self, on: bool):
+        """Diagnostic: False = evaluations as three stage launches, True = the default (one launch where it applies, frx_eval_kernel.hpp)."""
+        _check(lib().frx_debug_set_eval_fused(self.h, 1 if on else 0))
+
+    def eval_fused(self) -> int:
+        """Workgroups per candidate of the one-launch evaluation in use, 0 = one launch per stage."""
+        return int(lib().frx_debug_eval_fused(self.h))
 
     def algorithmic_bytes(self) -> int:
         """Penalty-kernel bytes per evaluation, SURVEY.md §8d: sum over pieces of 312 + 48 K_i."""

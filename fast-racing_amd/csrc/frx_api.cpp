@@ -184,6 +184,10 @@ struct frx_problem {
     int resident_used = 0;                                  // diagnostics: 1 = the last frx_optimize ran on the resident kernel
     unsigned resident_status = 0;                           // device-side error code of the last resident launch (RK_ERR_*)
     std::vector<double> trace;                              // FRX_TRACE: per command of candidate 0 {flags, step, f, dg, dginit, xx, gg}
+    // one launch per evaluation (frx_eval_kernel.hpp): granules and control words of its clusters, zeroed once; eval_fused: 1 = frx_objective_eval[_device] take it
+    // (set at create when the geometry applies and the chip holds the whole batch at once; FRX_EVAL_FUSED=0 / frx_debug_set_eval_fused turn it off)
+    DevBuf<unsigned long long> d_ev_ll; DevBuf<unsigned> d_ev_words;
+    int eval_fused = 0, eval_fused_G = 0, eval_fused_stamps = 0;
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -193,10 +197,27 @@ struct frx_problem {
 namespace {
 
 int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *st, bool backward) {
+    // a plain evaluation of a batch the chip holds at once: ONE launch (clusters of workgroups, frx_eval_kernel.hpp); the optimiser's rounds (line-search tap,
+    // skipped candidates) and the diagnostics that look at stage buffers keep the three stage kernels
+    if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps))
+        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words.p, 200000000ull /* 2 s */, st);
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
     return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st, p->tap_d, p->tap_flags, p->tap_res, p->tap_arrive, p->tap_flag, p->tap_round);
+}
+
+// The one-launch evaluation's sticky error word (a wait inside the launch expired: the candidates' f are NaN).  Read, cleared, reported; the handle then goes on
+// with the stage kernels.  The stream has been synchronised by the caller.
+int eval_cluster_status(frx_problem *p) {
+    if (!p->eval_fused) return FRX_OK;
+    unsigned st = 0;
+    unsigned *w = p->d_ev_words.p + (size_t)64 * p->B;
+    HIP_TRY(hipMemcpy(&st, w, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (st == 0) return FRX_OK;
+    HIP_TRY(hipMemset(w, 0, sizeof(unsigned)));
+    p->eval_fused = 0;
+    return fail(FRX_ERR_TIMEOUT, "one-launch evaluation: a wait between the workgroups of a cluster expired (code " + std::to_string(st) + "); this handle continues with one launch per stage");
 }
 
 } // namespace
@@ -350,6 +371,14 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         for (int s = 1; s < p->maxN - 1; s <<= 1) ge.pcr_steps++;
         ge.lds_kbwd = sizeof(double) * (36 * nt + 9 * (nt + 1) + 2 * nt + p->maxCN + 2 * 4 + 2 + 2 * maxXb + maxVb + (size_t)(ge.pcr_steps * 8 + 5) * nt);
     }
+    {   // one launch per evaluation when every cluster of the batch gets its CUs at once
+        int cus = 256;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount; }
+        const char *ef = std::getenv("FRX_EVAL_FUSED");
+        const int G = frx::eval_cluster_geometry(ge);
+        if (!G || (long long)B * G > cus || (ef && ef[0] == '0')) { ge.ev_G = 0; ge.lds_ev = 0; }
+        p->eval_fused_G = ge.ev_G; p->eval_fused = ge.ev_G ? 1 : 0;
+    }
     const size_t lds_cap = 160 * 1024;
     if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
         delete p;
@@ -397,6 +426,10 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     CR(p->d_T.alloc(p->P)); CR(p->d_C.alloc((size_t)p->P * 18)); CR(p->d_band.alloc(p->boff[B])); CR(p->d_out20.alloc((size_t)p->P * 20));
     CR(p->d_pcrw.alloc((size_t)(p->geo.pcr_steps * 8 + 4) * p->P)); p->geo.pcrw = p->d_pcrw.p;
     CR(p->d_wq.alloc((size_t)4 * p->P)); CR(hipMemset(p->d_wq.p, 0, sizeof(double) * 4 * p->P));
+    if (p->eval_fused_G) {
+        CR(p->d_ev_ll.alloc((size_t)78 * p->P)); CR(hipMemsetAsync(p->d_ev_ll.p, 0, sizeof(unsigned long long) * 78 * p->P, p->stream));
+        CR(p->d_ev_words.alloc((size_t)64 * B + 1)); CR(hipMemsetAsync(p->d_ev_words.p, 0, sizeof(unsigned) * ((size_t)64 * B + 1), p->stream));
+    }
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
 #undef CR
@@ -462,6 +495,25 @@ int frx_profile_phases(frx_problem *p, const double *x, long long *out32) {
     p->dp.stamps = nullptr;
     if (rc != FRX_OK) return rc;
     HIP_TRY(hipMemcpy(out32, p->d_stamps.p, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    return FRX_OK;
+}
+
+// Diagnostic: one evaluation at x in the one-launch form with cycle stamps of cluster 0 (forward map 0..12 and adjoint 16..31 as frx_profile_phases; 40..43 the leader's entry,
+// end of the forward map, end of the adjoint, end; 44..48 wave 0 of the first member: entry, gate seen, granules staged, samples done, partials out).
+int frx_debug_profile_eval_cluster(frx_problem *p, const double *x, long long *out64) {
+    if (!p || !x || !out64) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (!p->eval_fused) return fail(FRX_ERR_INVALID_ARG, "the one-launch evaluation does not apply to this handle");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->d_stamps.p) HIP_TRY(p->d_stamps.alloc(64));
+    HIP_TRY(hipMemset(p->d_stamps.p, 0, 64 * sizeof(long long)));
+    std::vector<double> f(p->B), g(p->NX);
+    int rc = frx_objective_eval(p, x, f.data(), g.data());          // warm
+    if (rc != FRX_OK) return rc;
+    p->dp.stamps = p->d_stamps.p; p->eval_fused_stamps = 1;
+    rc = frx_objective_eval(p, x, f.data(), g.data());
+    p->dp.stamps = nullptr; p->eval_fused_stamps = 0;
+    if (rc != FRX_OK) return rc;
+    HIP_TRY(hipMemcpy(out64, p->d_stamps.p, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return FRX_OK;
 }
 
@@ -557,7 +609,12 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
     if (!p || !x || !out3_us || reps < 1) return fail(FRX_ERR_INVALID_ARG, "null argument or reps < 1");
     HIP_TRY(hipSetDevice(p->device));
     std::vector<double> f(p->B), g(p->NX);
-    int rc = frx_objective_eval(p, x, f.data(), g.data());               // d_x, d_T, d_C, d_out20, pcrw all valid afterwards
+    int rc;
+    {   // (the stage kernels, not the one-launch form: their buffers are what the timed launches below read)
+        struct Stage { frx_problem *q; int was; ~Stage() { q->eval_fused = was; } } stage{p, p->eval_fused};
+        p->eval_fused = 0;
+        rc = frx_objective_eval(p, x, f.data(), g.data());               // d_x, d_T, d_C, d_out20, pcrw all valid afterwards
+    }
     if (rc != FRX_OK) return rc;
     HipEventPair evp; HIP_TRY(evp.create());
     const hipEvent_t e0 = evp.e0, e1 = evp.e1;
@@ -583,6 +640,33 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
     };
     for (int k = 0; k < 3; k++) if ((rc = time_it(k, out3_us[k])) != FRX_OK) break;
     return rc;
+}
+
+// Diagnostic (bench, tests): the one-launch evaluation.  set: 1 = use it where it applies (the default), 0 = always three stage launches; returns FRX_OK.
+// frx_debug_eval_fused: workgroups per candidate of the form frx_objective_eval[_device] takes right now, 0 = one launch per stage.
+int frx_debug_set_eval_fused(frx_problem *p, int enable) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    p->eval_fused = (enable && p->eval_fused_G) ? 1 : 0;
+    return FRX_OK;
+}
+int frx_debug_eval_fused(const frx_problem *p) { return (p && p->eval_fused) ? p->eval_fused_G : 0; }
+// Diagnostic (bench): average duration of one evaluation at x in the form frx_objective_eval_device takes, HIP events around `reps` back-to-back evaluations.
+int frx_eval_launch_time(frx_problem *p, const double *x, int reps, double *out_us) {
+    if (!p || !x || !out_us || reps < 1) return fail(FRX_ERR_INVALID_ARG, "null argument or reps < 1");
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<double> f(p->B), g(p->NX);
+    int rc = frx_objective_eval(p, x, f.data(), g.data());
+    if (rc != FRX_OK) return rc;
+    HipEventPair evp; HIP_TRY(evp.create());
+    for (int w = 0; w < 3; w++) HIP_TRY((hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true));
+    HIP_TRY(hipEventRecord(evp.e0, p->stream));
+    for (int r = 0; r < reps; r++) (void)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true);
+    HIP_TRY(hipEventRecord(evp.e1, p->stream));
+    HIP_TRY(hipEventSynchronize(evp.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, evp.e0, evp.e1));
+    *out_us = 1e3 * ms / reps;
+    return eval_cluster_status(p);
 }
 
 int frx_problem_totals(const frx_problem *p, int *out6) {
@@ -622,7 +706,7 @@ int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     std::memcpy(f, p->h_f.p, sizeof(double) * p->B);
     std::memcpy(g, p->h_g.p, sizeof(double) * p->NX);
-    return FRX_OK;
+    return eval_cluster_status(p);
 }
 
 // Asynchronous form of frx_objective_eval for host buffers: returns once the copies and kernels are enqueued on the handle's
@@ -647,6 +731,7 @@ int frx_wait(frx_problem *p) {
         std::memcpy(p->pending_f, p->h_f.p, sizeof(double) * p->B);
         std::memcpy(p->pending_g, p->h_g.p, sizeof(double) * p->NX);
         p->pending_f = nullptr; p->pending_g = nullptr;
+        return eval_cluster_status(p);
     }
     return FRX_OK;
 }

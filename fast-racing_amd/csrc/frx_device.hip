@@ -7,6 +7,7 @@
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
 #include "frx_round_kernel.hpp"
+#include "frx_eval_kernel.hpp"
 #include "frx_corridor_kernels.hpp"
 
 namespace frx {
@@ -22,7 +23,29 @@ int launch_set_limits(const LaunchGeom &g) {
     if ((e = hipFuncSetAttribute((const void *)k_backward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_forward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)k_backward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
+    if (g.ev_G && (e = hipFuncSetAttribute((const void *)k_eval_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_ev)) != hipSuccess) return (int)e;
     return 0;
+}
+static int eval_pen_lds(const LaunchGeom &g) { return g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21; }   // doubles per wave (penalty_body with a 64-lane group)
+int eval_cluster_geometry(LaunchGeom &g) {
+    g.ev_G = 0; g.lds_ev = 0;
+    if (g.solver != SOLVER_KNOT_PCR || g.knot_threads != 64 || g.ppw < 1) return 0;
+    const int ntasks = (g.maxN + g.ppw - 1) / g.ppw;
+    const size_t lds = sizeof(double) * (size_t)eval_cluster_lds(g.maxN * 19, g.maxXb, g.maxVb, g.maxCN, g.pcr_steps, eval_pen_lds(g)).total;
+    if (lds > (size_t)160 * 1024) return 0;
+    g.ev_G = 1 + (ntasks + 3) / 4;                                   // the members take every wave-task of the largest candidate in one pass
+    g.lds_ev = lds;
+    return g.ev_G;
+}
+int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *f, double *grad,
+                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream) {
+    if (!g.ev_G) return (int)hipErrorInvalidValue;
+    EvalClusterArgs a;
+    a.dp = dp; a.x = x; a.T = T; a.C = C; a.f = f; a.g = grad; a.out20ll = ll; a.ctll = ll + (size_t)40 * dp.P; a.words = words; a.status = words + (size_t)64 * dp.B; a.timeout_ticks = timeout_ticks;
+    a.G = g.ev_G; a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax; a.pen_lds = eval_pen_lds(g); a.maxN19 = g.maxN * 19;
+    { const char *e = std::getenv("FRX_EVAL_FUSED_WT"); a.force_wt = (e && e[0] == '1') ? 1 : 0; }
+    hipLaunchKernelGGL(k_eval_cluster, dim3(8 * g.ev_G * ((dp.B + 7) / 8)), dim3(256), g.lds_ev, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
 }
 int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *band, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)

@@ -51,6 +51,8 @@ struct LaunchGeom {
     int maxXb, maxVb;                      // per-candidate maxima: free variables, waypoint-vertex doubles (3 per vertex)
     int pcr_steps;                         // ceil(log2(maxN - 1)): reduction steps whose multipliers k_forward_knot saves
     double *pcrw;                          // [(pcr_steps*8 + 4)][P] saved multipliers + final D^-1 per knot
+    int ev_G = 0;                          // one-launch evaluation (frx_eval_kernel.hpp): workgroups per candidate, 0 = not applicable (more than 64 pieces, banded solver)
+    size_t lds_ev = 0;
 };
 
 // all return a hipError_t value as int (0 = hipSuccess); stream is a hipStream_t
@@ -62,6 +64,12 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
                     const double *tap_d = nullptr, const int *tap_flags = nullptr, void *tap_res = nullptr,
                     unsigned *tap_arrive = nullptr, volatile unsigned *tap_flag = nullptr, unsigned tap_round = 0);
 
+
+// One launch per evaluation (frx_eval_kernel.hpp): clusters of g.ev_G workgroups, one per candidate.  ll: [P][40 + 38] granule words (penalty partials, then (C, T)), words: [64 B + 1] (the last one: status), both
+// zeroed ONCE at allocation.  The caller has checked that dp.B * g.ev_G workgroups are resident at once (eval_cluster_geometry).
+int eval_cluster_geometry(LaunchGeom &g);                         // fills ev_G / lds_ev from the other fields; returns ev_G
+int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *f, double *grad,
+                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream);
 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;

@@ -1,0 +1,114 @@
+// ONE LAUNCH PER EVALUATION for batches the chip holds at once (frx_objective_eval[_device]: x -> (f, grad f), SURVEY.md 8 row a1;
+// the reference's objectiveFunc, se3gcopter_cpu.hpp:961-1000, which its CUDA path splits over a host call, one persistent kernel and a host call again,
+// cuda_computer.cu:530-547).
+//
+// The three stage kernels of an evaluation (forward map, penalty integral, adjoint) are three dependent launches: at the headline batch
+// (32 candidates x 64 pieces) each is one wave's dependent chain of 4.6-7.7 us of which 1.5-2.5 us are the launch itself - start of the grid,
+// the first trip to HBM for operands the previous kernel just had in LDS, the drain at the end (the same bodies inside the resident round kernel,
+// frx_round_kernel.hpp, take 5.2 / 3.1 / 5.2 us).  Here an evaluation is one grid of CLUSTERS, one per candidate:
+//   workgroup 0       LEADER: stages x and the polytopes once, runs the forward map, whose (C, T) leave as granules, then - while the members integrate - everything
+//                     of the adjoint that does not need the penalty partials, polls the partials, finishes the adjoint, writes f and the gradient
+//   workgroups 1..G-1 MEMBERS, every WAVE on its own: fetch the corridor blocks of its wave-task (ppw pieces), wait at the cluster's gate word, poll the task's
+//                     (C, T) granules, integrate the penalty, send the 20 partials per piece as granules and leave
+// BOTH directions travel as self-validating granules (rk_ll_put, frx_kernels.hpp): no drain, no flag behind the payload, no barrier on either side - the
+// round kernel's (C, T) hand-off (write-through stores, drain, barrier, phase word; poll, barrier, loads) measures 1.3 us + a load trip, this one a load trip.
+// Same integrand and sums as the stage kernels (f is bit-identical); the adjoint runs in the resident order of operations (backward_knot_wsp64), whose gradient
+// differs from the stage kernel's in the last bits (<= 1e-11 relative, tests/test_gpu_parity.py).
+//
+// Tags instead of zeroed buffers: the launch is captured in hipGraphs (bench.py replays one), so nothing on the host may run between two of them.  Every
+// cluster keeps the tag of its last COMPLETED evaluation in device memory (`done`); an evaluation uses tag = done + 1 for its flag and its granules, and the
+// leader stores it back as its very last action - behind the arrival of every partial, hence behind every member's read of `done` (a member without a task
+// reads nothing and leaves).  Launches on one stream do not overlap, so no workgroup ever sees a tag of the future.
+// Every spin is bounded (EvalClusterArgs::timeout_ticks); an expired wait records RK_ERR_PHASE / RK_ERR_ARRIVE in `status` and the candidate's f becomes NaN.
+// Residency: a leader waits for members of the SAME launch, so all of a cluster's workgroups have to get a CU.  Blocks are dispatched in index order and a
+// cluster's blocks are 8 apart within one group of 8 G consecutive blocks (the XCD mapping of k_round), so the resident blocks of a launch always contain
+// whole clusters, which finish and make room; the launcher only takes this path when B G <= the device's CU count (frx_device.hip).
+#pragma once
+#include "frx_round_kernel.hpp"
+
+namespace frx {
+
+struct EvalClusterArgs {
+    DevProblem dp;
+    const double *x; double *T, *C, *f, *g;
+    ll_u64 *out20ll;                         // [P][20] granules: the penalty partials, members -> leader (its own buffer: the round kernel's carries tags of its own)
+    ll_u64 *ctll;                            // [P][19] granules: coefficients and duration of every piece, leader -> members
+    unsigned *words;                         // [B][64]: cluster k's 256-byte block: word 0 = gate (tag << 4 | the leader's XCD + 1: (C, T) are out), words 8 .. 8 + G - 2 = tag << 4 | XCD + 1 of
+                                             // members 1 .. G-1 (written at their entry), word 32 = tag of the last completed evaluation
+    unsigned *status;                        // [1] sticky error word
+    rk_u64 timeout_ticks;
+    int G, maxCN, maxXb, maxVb, nsteps, lpp, ppw, Kmax, pen_lds, maxN19;
+    int force_wt;                            // 1 = every payload store write-through, as if no two workgroups shared an XCD (tests: FRX_EVAL_FUSED_WT=1)
+};
+
+// LDS of a workgroup (doubles): 2 control | leader: (C, T) copy, x, polytopes, multipliers, waypoint sums, evaluation scratch | member: 4 waves x pen_lds
+struct EvalClusterLds { int ctl, xs, vs, pw, wq, ev, total; };
+__host__ __device__ inline EvalClusterLds eval_cluster_lds(int maxN19, int maxXb, int maxVb, int maxCN, int nsteps, int pen_lds) {
+    EvalClusterLds L;
+    int o = 2;
+    L.ctl = o; o += (maxN19 + 1) & ~1;
+    L.xs = o; o += (maxXb + 1) & ~1;
+    L.vs = o; o += (maxVb + 1) & ~1;
+    L.pw = o; o += ((nsteps * 8 + 5) * 64 + 1) & ~1;
+    L.wq = o; o += 4 * 64;
+    L.ev = o;
+    const int e = 36 * 64 + 9 * 65 + 2 * 64 + maxCN + 16;   // rows | knot arrays | Tf, gT | gCo | cross-wave partials (forward_knot_body / backward_knot_wsp64 with resident operands)
+    o += (e + 1) & ~1;
+    const int member = 2 + 4 * pen_lds + 8;
+    L.total = o > member ? o : member;
+    return L;
+}
+
+__global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane8 = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int wg = rest % a.G, k = lane8 + 8 * (rest / a.G);       // (k_round's mapping: a cluster's blocks share blockIdx % 8 - one XCD, as observed)
+    if (k >= a.dp.B) return;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = k;
+    // (diagnostic, frx_debug_profile_eval_cluster: cycle stamps of cluster 0 - 40..43 the leader: entry, forward map done, adjoint done, end; 44..48 wave 0 of member 1, see penalty_wave_ll - these in ticks of the 100 MHz counter all workgroups share; 49: the leader's shader clock at entry, the origin of the bodies' own stamps 0..31)
+    if (a.dp.stamps && k == 0 && wg == 0 && t == 0) { a.dp.stamps[40] = (long long)wall_clock64(); a.dp.stamps[49] = (long long)__builtin_readcyclecounter(); }
+    unsigned *flag = a.words + (size_t)k * 64, *done = flag + 32;
+    const int p0 = a.dp.poff[c], N = a.dp.poff[c + 1] - p0;
+    const int ntasks = (N + a.ppw - 1) / a.ppw;                     // wave-tasks of this candidate: ppw pieces each; members 1 .. G-1 hold 4 (G - 1) >= ntasks waves
+    if (wg != 0 && (wg - 1) * 4 >= ntasks) return;                  // a member without a task
+    unsigned tag = __hip_atomic_load(done, FRX_RLX_AGENT) + 1u;     // (stays in a vector register: nothing waits for the load until the tag is used)
+    if (tag >= (1u << 28)) tag = 1u;
+    // Where does this workgroup run?  Payload between two workgroups of one XCD can meet in that XCD's L2 (plain stores, L1-bypassing loads); across XCDs it has
+    // to be written through to memory - measured 2.1 us of an 18.5 us evaluation.  The block -> cluster mapping above puts a cluster on one XCD on the hardware
+    // this was written on, but nothing relies on it: the members publish their XCD at entry, the leader compares before it sends (C, T), its own XCD travels in
+    // the gate word, and whoever finds a partner elsewhere (or not yet heard of) writes through.
+    unsigned my_xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc = a.force_wt ? 0u : (my_xcc & 7u) + 1u;                  // 0: "nowhere" - never equal to a partner's
+    const EvalClusterLds L = eval_cluster_lds(a.maxN19, a.maxXb, a.maxVb, a.maxCN, a.nsteps, a.pen_lds);
+    if (wg != 0) {
+        // every WAVE of a member is on its own from here (no workgroup barrier below): its task's corridor blocks, the gate, its granules, its samples, its partials
+        if (t == 0) __hip_atomic_store(flag + 8 + (wg - 1), (tag << 4) | my_xcc, FRX_RLX_AGENT);
+        const int task = (wg - 1) * 4 + wave;
+        if (task >= ntasks) return;
+        penalty_wave_ll<true>(a.dp, a.ctll, flag, tag, a.out20ll, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, min(a.ppw, N - task * a.ppw), sm + 2 + (size_t)wave * a.pen_lds, lane, a.status, a.timeout_ticks, my_xcc, (k == 0 && wg == 1 && wave == 0) ? a.dp.stamps : nullptr);
+        return;
+    }
+    // ---- leader ----
+    double *ctl = sm + L.ctl, *ev = sm + L.ev;
+    ResidentOps ro;
+    ro.xs = sm + L.xs; ro.vs = sm + L.vs; ro.dsv = sm + L.xs; ro.pw = sm + L.pw; ro.gs = nullptr; ro.vskew = 0; ro.wq = sm + L.wq; ro.gpub = nullptr; ro.gwt = true;
+    const GranuleOut go{a.ctll, tag, flag, (tag << 4) | (my_xcc ? my_xcc : 15u), a.force_wt ? nullptr : flag + 8, (ntasks + 3) / 4};   // (C, T) leave as granules; nothing is drained, no flag follows them
+    forward_knot_body<true, 64, true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro, nullptr, &go);
+    if (a.dp.stamps && k == 0 && t == 0) a.dp.stamps[41] = (long long)wall_clock64();
+    ro.o20ll = a.out20ll; ro.o20tag = tag; ro.status = a.status; ro.spin_ticks = a.timeout_ticks;
+    const LineSearchTap tap{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr};
+    backward_knot_body<true, 64>(a.dp, a.x, a.T, a.C, nullptr, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, tap, c, ev, ctl, &ro);
+    if (a.dp.stamps && k == 0 && t == 0) a.dp.stamps[42] = (long long)wall_clock64();
+    __syncthreads();
+    if (t == 0) {
+        const double fv = ev[36 * 64 + 9 * 65 + 2 * 64 + a.maxCN];  // `red[0]` of backward_knot_wsp64: the objective value (a resident caller's f does not go to global memory there)
+        const bool bad = __hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u;
+        a.f[c] = bad ? __builtin_nan("") : fv;
+        __hip_atomic_store(done, tag, FRX_RLX_AGENT);
+        if (a.dp.stamps && k == 0) a.dp.stamps[43] = (long long)wall_clock64();
+    }
+}
+
+} // namespace frx

@@ -94,6 +94,11 @@ struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; d
 // caller fetches them once (rk_leader_loop, load_candidate) and hands them in; fetched inside the body they cost it a scalar load and a dependent vector
 // load from L2 in front of everything else - 1 100 cycles before the first duration is formed (cycle stamps, round 5).
 struct KnotPre { int p0, N, c0, cN, x0, cv0, pc, piv, wnv, wvb, wxb; double bs[6]; };
+// The one-launch evaluation's way out of the forward map (frx_eval_kernel.hpp; forward_knot_body<.., RSTAGE = true>): (C, T) leave as granules tagged `tag` in ll ([P][19],
+// duration at index 18) INSTEAD of plain stores, and `gate` receives gate_val (the tag and the leader's XCD) right behind them.  mxw: nmx words in which the
+// consumers published gate_val if they run on the leader's XCD - when all did, the granules leave as plain stores (that XCD's L2 is the meeting point) instead of
+// write-through ones; null: always write-through.
+struct GranuleOut { ll_u64 *ll; unsigned tag; unsigned *gate; unsigned gate_val; const unsigned *mxw; int nmx; };
 
 // Coalesced staging global -> LDS with every load of a trip in flight before the first LDS store.  The plain loop
 // `for (i = k; i < n; i += nthr) dst[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per element even under
@@ -418,6 +423,84 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
     if (active) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, Kmax, red + lane * 21);
     __syncthreads();
     penalty_reduce<SH>(red, npieces, lpp, out20 + (size_t)gp0 * 20, lane, nthr, wt, out20ll ? out20ll + (size_t)gp0 * 40 : nullptr, ll_tag);
+}
+// One WAVE on its own (the one-launch evaluation's members, frx_eval_kernel.hpp): the pieces [gp0, gp0 + npieces) of a wave-task with `sm` = the wave's private LDS.
+// Nothing of the workgroup is involved - no barrier, the waves of a member run apart - and (C, T) are not loaded but POLLED: they arrive as granules
+// {coefficient q of piece p at ct_ll[2 (19 p + q)], duration at q = 18} tagged `tag` (GranuleOut, forward_knot_body), one or a few per lane, behind a gate
+// word that the leader sets right behind them (tag << 4 | its XCD + 1; until then the wave loads its corridor blocks and sleeps between polls of the gate).  Same samples, same
+// sums as penalty_body.  Returns false when a wait expired (status receives the code).
+template <bool LAT>
+__device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u64 *__restrict__ ct_ll, const unsigned *gate, unsigned tag, ll_u64 *__restrict__ out20ll,
+                                                int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, unsigned *status, ll_u64 spin_ticks, unsigned my_xcc, long long *stamps = nullptr) {
+#define PW_STAMP(slot) do { if (stamps && lane == 0) stamps[slot] = (long long)wall_clock64(); } while (0)   // (the 100 MHz counter all workgroups share: the shader clocks of two XCDs are unrelated)
+    PW_STAMP(44);
+    const int hstride = (Kmax + 1) * 4;
+    double *cS = sm;
+    double *tS = cS + ppw * 18;
+    double *hS = tS + ppw;
+    double *red = hS + (size_t)ppw * hstride;
+    const int pl = lane / lpp, jl = lane - pl * lpp;
+    {   // corridor blocks: constant, fetched while the leader still runs its forward map
+        const double2 *h2 = (const double2 *)(dp.hblk + (size_t)gp0 * hstride);
+        const int nh2 = (npieces * hstride) >> 1;
+        for (int i0 = lane; i0 < nh2; i0 += 4 * 64) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u; v[u] = h2[i < nh2 ? i : nh2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u; if (i < nh2) { hS[2 * i] = v[u].x; hS[2 * i + 1] = v[u].y; } }
+        }
+    }
+    const ll_u64 t_end = (ll_u64)wall_clock64() + spin_ticks;
+    bool ok = true;
+    unsigned gv = 0;
+    for (unsigned spins = 0;; spins++) {                                   // the gate: one word per cluster (every lane reads the same address: one request per wave); tag << 4 | the leader's XCD + 1
+        gv = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((gv >> 4) == tag) break;
+        if ((spins & 31u) == 31u && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || (ll_u64)wall_clock64() > t_end)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    PW_STAMP(45);
+    const int ng = npieces * 19;
+    const ll_u64 *src = ct_ll + 2 * (size_t)gp0 * 19;
+    typedef unsigned ll_v4u __attribute__((ext_vector_type(4)));
+    for (int j0 = lane; ok && j0 - lane < ng; j0 += 3 * 64) {               // three granules per lane and trip, ONE 16-byte L1-bypassing load each
+        const int ja = j0 < ng ? j0 : ng - 1, jb = j0 + 64 < ng ? j0 + 64 : ja, jc = j0 + 128 < ng ? j0 + 128 : ja;
+        const bool more = j0 - lane + 64 < ng;                               // (wave-uniform: kappa >= 16 has at most 57 granules per wave-task - one load per poll)
+        ll_v4u ra, rb, rc;
+        for (unsigned spins = 0;; spins++) {
+            if (more) asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                                   : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(src + 2 * ja), "v"(src + 2 * jb), "v"(src + 2 * jc) : "memory");
+            else { asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ra) : "v"(src + 2 * ja) : "memory"); rb = ra; rc = ra; }
+            if (ra.y == tag && ra.w == tag && rb.y == tag && rb.w == tag && rc.y == tag && rc.w == tag) break;
+            if ((spins & 31u) == 31u && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || (ll_u64)wall_clock64() > t_end)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        auto put = [&](int j, const ll_v4u &r) {
+            const int p = j / 19, q = j - 19 * p;
+            const double v = __longlong_as_double((long long)((ll_u64)r.x | ((ll_u64)r.z << 32)));
+            if (q < 18) cS[p * 18 + q] = v; else tS[p] = v;
+        };
+        if (j0 < ng) put(ja, ra);
+        if (j0 + 64 < ng) put(jb, rb);
+        if (j0 + 128 < ng) put(jc, rc);
+    }
+    ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;                          // (wave-uniform)
+    if (!ok) {
+        unsigned expect = 0u;
+        if (lane == 0) __hip_atomic_compare_exchange_strong(status, &expect, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the wave's LDS stores are in order with its LDS loads; nothing may be hoisted over them
+    PW_STAMP(46);
+    if (pl < npieces) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, Kmax, red + lane * 21);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PW_STAMP(47);
+    const bool wt = my_xcc == 0u || (gv & 15u) != my_xcc;                  // the partials leave as plain stores when the leader runs on this XCD (its L2 is the meeting point), write-through otherwise
+    penalty_reduce<true>(red, npieces, lpp, nullptr, lane, 64, wt, out20ll + (size_t)gp0 * 40, tag);
+    PW_STAMP(48);
+#undef PW_STAMP
+    return true;
 }
 // Stage kernels: a workgroup of blockDim.x = 64 W threads owns ppg = floor(64 W / lpp) consecutive pieces (LaunchGeom::pen_w, ::ppg).
 __global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
@@ -1071,10 +1154,13 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
 // NR > 0: the caller KNOWS the geometry class at compile time (nrow = NR rows, 256 threads: the resident round kernel's instantiation for <= 64 pieces):
 // the forms for the other classes are not compiled into it - k_round carried all three (146 KB of code against a 64 KB instruction cache that two
 // CUs share; the leader walks through forward map, adjoint and control code once per round, each time from L2).
-template <bool SH, int NR = 0>
+// RSTAGE: the caller is the leader of the one-launch evaluation (frx_eval_kernel.hpp).  It hands in resident operands (`ro`, not null) that THIS call fills - x and the
+// polytopes are staged into ro->xs / ro->vs here, with the index-table loads of the body in the same memory latency; it keeps them for the adjoint of the same
+// launch - and (C, T) leave as granules (`go`, GranuleOut).  None of that is compiled into the other callers.
+template <bool SH, int NR = 0, bool RSTAGE = false>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr,
-                               const KnotPre *pre = nullptr) {
+                               const KnotPre *pre = nullptr, const GranuleOut *go = nullptr) {
     // ct_lds (optional, LDS, 19 doubles per piece: 18 coefficients + duration): a copy for the backward pass of the same workgroup
     const int nrow = NR > 0 ? NR : nrow_rt;
     const int k = threadIdx.x, nthr = NR > 0 ? 256 : (int)blockDim.x;
@@ -1118,7 +1204,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     if (wsp64 && k == 0) *progress = 0u;
     {   // coalesced staging: every later access is an LDS access (the per-waypoint loops would otherwise serialise
         // one global-memory latency per vertex)
-        if (!ro) {
+        if (!ro || RSTAGE) {
             const int nx = dp.xoff[b + 1] - x0;
             const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
             const double *vsrc = dp.vrec + 3 * (size_t)v0;
@@ -1154,7 +1240,8 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     if (k < N) {
         hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
-        stg<SH>(Tout + p0 + k, hMine, wt);
+        if (RSTAGE && SH && go) rk_ll_put(go->ll + 2 * ((size_t)(p0 + k) * 19 + 18), hMine, go->tag, true);   // (early, off the critical path: write-through whatever the consumers' XCD)
+        else stg<SH>(Tout + p0 + k, hMine, wt);
         if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
     FRX_STAMP(2);
@@ -1228,6 +1315,14 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 }
             }
             FRX_STAMP_AX(10);
+            if (RSTAGE && SH && go && go->mxw && wave == 3) {
+                // Do all consumers of the granules run on this XCD?  They said so, or not yet, in go->mxw[0 .. nmx) (write-through stores at their entry, microseconds ago);
+                // this wave has the slack for the trip - its reduction below follows the matrix wave, which is two steps into its six by now.  "Not yet" counts as no.
+                unsigned vq = go->gate_val;
+                if (kk < go->nmx) vq = __hip_atomic_load(go->mxw + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool all_here = __builtin_amdgcn_ballot_w64(vq != go->gate_val) == 0ull;
+                if (kk == 0) progress[1] = all_here ? 1u : 0u;
+            }
             int nst = 0;
             for (int s = 1; s < N - 1; s <<= 1) nst++;
             for (int st = 0; st < nst; st++) {                             // pcr_rhs_step behind the matrix wave, neighbours by lane shifts
@@ -1276,13 +1371,18 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         // C leaves the workgroup as ONE coalesced sweep of 16-byte stores by all four waves.  Stored straight from the axis lanes it was 1152
         // scattered 8-byte write-through stores (lane stride 144 bytes), and draining them cost the resident kernel ~2 us per round.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool wt_ll = (RSTAGE && SH && go && go->mxw) ? progress[1] == 0u : wt;   // (granules: see the decision of wave 3 above)
         for (int i = k; i < 9 * N; i += 256) {                              // 9 pairs of doubles per piece
             const int pc = i / 9, q2 = 2 * (i - 9 * pc);
             const double v0 = cstage[pc * 19 + q2], v1 = cstage[pc * 19 + q2 + 1];
             double *dst = Cout + (size_t)(p0 + pc) * 18 + q2;
-            if (SH && wt) { stg<SH>(dst, v0, true); stg<SH>(dst + 1, v1, true); }
+            if (RSTAGE && SH && go) { ll_u64 *gl = go->ll + 2 * ((size_t)(p0 + pc) * 19 + q2); rk_ll_put(gl, v0, go->tag, wt_ll); rk_ll_put(gl + 2, v1, go->tag, wt_ll); }
+            else if (SH && wt) { stg<SH>(dst, v0, true); stg<SH>(dst + 1, v1, true); }
             else *(double2 *)dst = make_double2(v0, v1);
         }
+        // the gate of the granules' consumers: set BEHIND the sweep, not drained - it tells the members' waves that a poll of their granules is now worth its trip
+        // (polled from the start of the launch, by 49 k lanes, the granules cost more than they save: every poll is a transaction on the fabric between the XCDs)
+        if (RSTAGE && SH && go && k == 255) __hip_atomic_store(go->gate, go->gate_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         FRX_STAMP(6);
         return;
     }

@@ -50,6 +50,18 @@ int frx_debug_resident_predictions(const frx_problem *p, unsigned long long *out
 /* Diagnostic (bench): average microseconds of each stage kernel of an evaluation at x - {forward, penalty, adjoint} - over `reps`
  * back-to-back launches of one kernel at a time, HIP events on the handle's stream. */
 int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3_us);
+/* One launch per evaluation (fast-racing_amd/csrc/frx_eval_kernel.hpp): frx_objective_eval[_device] run a batch that the chip holds at once - candidates of <= 64
+ * pieces, B x (1 + ceil(ceil(N / pieces per wave) / 4)) workgroups <= the device's CU count - as ONE grid of clusters instead of three stage launches, with
+ * bit-identical results.  set(0) keeps the three launches, set(1) returns to the default; frx_debug_eval_fused = workgroups per candidate of the form in use,
+ * 0 = one launch per stage.  The environment variable FRX_EVAL_FUSED=0 turns the form off for every handle created afterwards. */
+int frx_debug_set_eval_fused(frx_problem *p, int enable);
+int frx_debug_eval_fused(const frx_problem *p);
+/* Diagnostic (bench): average microseconds of one evaluation at x in the form frx_objective_eval_device takes, over `reps` back-to-back evaluations. */
+int frx_eval_launch_time(frx_problem *p, const double *x, int reps, double *out_us);
+/* Diagnostic: one evaluation at x in the one-launch form with shader-clock stamps of candidate 0's cluster: out64[0..12] forward map and [16..31] adjoint as
+ * frx_profile_phases, [40..43] the leader's entry / end of the forward map / end of the adjoint / end, [44..48] wave 0 of the first member: entry, gate seen,
+ * granules staged, samples done, partials out. */
+int frx_debug_profile_eval_cluster(frx_problem *p, const double *x, long long *out64);
 
 /* Diagnostic: runs one evaluation at x and returns shader-clock stamps taken at the phase boundaries of candidate 0's
  * k_forward_knot (out32[0..6]) and k_backward_knot (out32[16..24]). */

@@ -44,10 +44,15 @@ for B in [int(b) for b in args.batches.split(",")]:
                    frac=round(prob.algorithmic_bytes() / us / 1e3 / 8000, 4), Gsamples=round(prob.samples() / us / 1e3, 2))
         if args.full:
             xd = torch.from_numpy(xb).cuda(); fd = torch.zeros(prob.B, dtype=torch.float64, device="cuda"); gd = torch.zeros(prob.NX, dtype=torch.float64, device="cuda")
-            for _ in range(5): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
-            e0.record()
-            for _ in range(args.reps): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
-            e1.record(); torch.cuda.synchronize()
-            row["eval_us"] = round(e0.elapsed_time(e1) * 1e3 / args.reps, 2)
+            # both forms of an evaluation where the one-launch form applies (k_eval_cluster, batches the chip holds at once): the counter passes need the stage
+            # kernels AND the cluster kernel at the headline batch
+            for form in ((False, True) if prob.eval_fused() else (False,)):
+                prob.set_eval_fused(form)
+                for _ in range(5): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
+                e0.record()
+                for _ in range(args.reps): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
+                e1.record(); torch.cuda.synchronize()
+                row["eval_one_launch_us" if form else "eval_us"] = round(e0.elapsed_time(e1) * 1e3 / args.reps, 2)
+            prob.set_eval_fused(True)
         rows.append(row); print(json.dumps(row), flush=True)
     if rep > 1: prob.close()

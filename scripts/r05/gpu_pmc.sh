@@ -49,6 +49,17 @@ for kname in ("k_penalty", "k_forward_knot", "k_backward_knot"):
         out["grid_%d" % grid] = e
     kern[kname] = out
 res["kernels"] = kern
+# the one-launch evaluation (k_eval_cluster, headline batch only): loads of 8 and 16 bytes, granule stores of 8 - bracketed by the two calibrations
+try:
+    m = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        v = [float(r["Counter_Value"]) for r in allrows(f"pmc5_{c}") if "k_eval_cluster" in r["Kernel_Name"]]
+        m[c + "_KB_raw"] = sum(v) / len(v)
+    fk, wk = m["FETCH_SIZE_KB_raw"] * 1024, m["WRITE_SIZE_KB_raw"] * 1024
+    m["traffic_bytes_per_launch_range"] = [fk * min(f8, f16) + wk * min(w8, w16), fk * max(f8, f16) + wk * max(w8, w16)]
+    res["k_eval_cluster"] = m
+except Exception as e:
+    res["k_eval_cluster"] = {"error": repr(e)}
 pen = kern["k_penalty"]
 small = sorted(pen, key=lambda k: int(k.split("_")[1]))[0]
 res["traffic_bytes_per_launch"] = pen[small]["traffic_bytes_per_launch"]      # headline launch of the penalty integrator

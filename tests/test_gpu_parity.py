@@ -100,6 +100,22 @@ def test_stagewise_parity(frx, sc, ob, B, N, gates, kappa, obst, solver):
             # a ~1e-11 residue of O(f) terms and has no significant digits of its own
             gerr = np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max()
             assert gerr <= PER_EVAL_TOL * max(np.abs(g_ref).max(), abs(f_ref)), f"grad stage {s} cand {b}"
+        # the evaluation above ran as ONE launch where that form applies (knot form, <= 64 pieces, the batch fits the chip: frx_eval_kernel.hpp); the three
+        # stage launches have to give the same objective bit for bit (same integrand, same sums) and the same gradient to the last bits (the adjoint of the
+        # one-launch form runs in the resident kernel's order of operations)
+        if solver == "knot_pcr" and prob.eval_fused():
+            assert N <= 64
+            prob.set_eval_fused(False)
+            f3, g3 = prob.objective(x)
+            prob.set_eval_fused(True)
+            assert np.array_equal(f, f3), f"one launch vs three, stage {s}"
+            for b, o in enumerate(oracles):
+                sl = slice(prob.x_off[b], prob.x_off[b + 1])
+                assert np.abs(g[sl] - g3[sl]).max() <= 1e-10 * max(np.abs(g3[sl]).max(), abs(f3[b])), f"one launch vs three, gradient, stage {s} cand {b}"
+                f_ref, g_ref = o.objective(pts[b][s])
+                assert np.abs(g3[sl] - g_ref).max() <= PER_EVAL_TOL * max(np.abs(g_ref).max(), abs(f_ref)), f"grad (three launches) stage {s} cand {b}"
+        elif solver == "knot_pcr":
+            assert N > 64, "the one-launch form applies to every small batch of <= 64 pieces"
     prob.close()
 
 
@@ -347,15 +363,90 @@ def test_baseline_configs_objective_parity(frx, sc, ob, config):
     oracles = [ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=kappa) for c in cands]
     for o in oracles: o.set_abscissa_mode(False)
     x0s = [o.initial_guess() for o in oracles]
+    assert prob.eval_fused() == {"plumbing": 17, "synthetic8": 3, "headline": 7}[config]      # workgroups per candidate of the one-launch evaluation
     for xs in (x0s, [o.optimize(1e-6, max_iterations=40, x0=x0)["x"] for o, x0 in zip(oracles, x0s)]):
-        f, g = prob.objective(np.concatenate(xs))
-        worst_f = worst_g = 0.0
-        for b, o in enumerate(oracles):
-            f_ref, g_ref = o.objective(xs[b])
-            worst_f = max(worst_f, abs(f[b] - f_ref) / abs(f_ref))
-            worst_g = max(worst_g, np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max() / max(np.abs(g_ref).max(), abs(f_ref)))
-        print(f"{config}: B={B} N={N} kappa={kappa}: worst rel err f {worst_f:.2e} grad {worst_g:.2e}")
-        assert worst_f < PER_EVAL_TOL and worst_g < PER_EVAL_TOL
+        for one_launch in (True, False):                                                     # both forms of frx_objective_eval at the benchmarked sizes
+            prob.set_eval_fused(one_launch)
+            f, g = prob.objective(np.concatenate(xs))
+            worst_f = worst_g = 0.0
+            for b, o in enumerate(oracles):
+                f_ref, g_ref = o.objective(xs[b])
+                worst_f = max(worst_f, abs(f[b] - f_ref) / abs(f_ref))
+                worst_g = max(worst_g, np.abs(g[prob.x_off[b]:prob.x_off[b + 1]] - g_ref).max() / max(np.abs(g_ref).max(), abs(f_ref)))
+            print(f"{config}: B={B} N={N} kappa={kappa}, {'one launch' if one_launch else 'three launches'}: worst rel err f {worst_f:.2e} grad {worst_g:.2e}")
+            assert worst_f < PER_EVAL_TOL and worst_g < PER_EVAL_TOL
+    prob.close()
+
+
+@pytest.mark.gpu
+def test_one_launch_evaluation_in_a_graph_and_in_its_write_through_form(frx, sc, monkeypatch):
+    """The one-launch evaluation (frx_eval_kernel.hpp) keeps no state on the host between two launches - its tags live in device memory - so a captured graph of
+    evaluations can be replayed: 25 evaluations in one hipGraph, replayed three times, leave the gradient of a direct call.  And the form it takes when a cluster's
+    workgroups do NOT share an XCD (every payload store written through to memory, FRX_EVAL_FUSED_WT=1) gives the same bits as the one it takes when they do."""
+    B, N, gates, kappa = sc.CONFIGS["headline"]
+    cands = [sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    assert prob.eval_fused() == 7
+    x = prob.initial_guess() + 1e-3 * np.sin(np.arange(prob.NX))
+    f0, g0 = prob.objective(x)
+    monkeypatch.setenv("FRX_EVAL_FUSED_WT", "1")
+    f1, g1 = prob.objective(x)
+    monkeypatch.delenv("FRX_EVAL_FUSED_WT")
+    assert np.array_equal(f0, f1) and np.array_equal(g0, g1)
+    prob.close()
+    # the graph: in a process of its own that loads torch (streams, graph capture) BEFORE the library, as bench.py does - two HIP runtimes in one process
+    # (the library's from /opt/rocm, then torch's bundled one) do not find the device
+    import subprocess, sys, json
+    code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from frx_import import frx
+from fast_racing_amd import scenario as sc
+B, N, gates, kappa = sc.CONFIGS["headline"]
+prob = frx.Problem([sc.make_candidate(0, N, gates, perturb_id=b) for b in range(B)], sc.ZHANGJIAJIE, qd_intervals=kappa)
+x = prob.initial_guess() + 1e-3 * np.sin(np.arange(prob.NX))
+f0, g0 = prob.objective(x)
+x_dev = torch.from_numpy(x).cuda(); f_dev = torch.zeros(prob.B, dtype=torch.float64, device="cuda"); g_dev = torch.zeros(prob.NX, dtype=torch.float64, device="cuda")
+s = torch.cuda.Stream(); same = []
+with torch.cuda.stream(s):
+    prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), s.cuda_stream); s.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s):
+        for _ in range(25): prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        f_dev.zero_(); g_dev.zero_(); gr.replay(); s.synchronize()
+        same.append(bool(np.array_equal(f_dev.cpu().numpy(), f0) and np.array_equal(g_dev.cpu().numpy(), g0)))
+f2, g2 = prob.objective(x)
+print(json.dumps({"fused": prob.eval_fused(), "replays_same": same, "blocking_call_behind_the_replays_same": bool(np.array_equal(f2, f0) and np.array_equal(g2, g0))}))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["fused"] == 7 and r["replays_same"] == [True, True, True] and r["blocking_call_behind_the_replays_same"], r
+
+
+@pytest.mark.gpu
+def test_one_launch_evaluation_only_for_batches_the_chip_holds(frx, sc):
+    """A leader waits for members of its own launch, so every workgroup of the grid has to get a CU: 36 candidates x 7 workgroups fit 256 CUs, 40 do not and
+    are evaluated by three stage launches; ragged batches take the cluster size of their largest candidate, smaller candidates leave members idle."""
+    cus = 256                                                                                # MI355X
+    for B in (cus // 7, cus // 7 + 1):
+        cands = [sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(B)]
+        prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+        assert prob.eval_fused() == (7 if B * 7 <= cus else 0)
+        prob.close()
+    cands = [sc.make_candidate(0, n, max(n // 4, 0), perturb_id=b) for b, n in enumerate((64, 9, 33, 2, 1, 17))]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+    assert prob.eval_fused() == 7
+    x = prob.initial_guess()
+    f1, g1 = prob.objective(x)
+    prob.set_eval_fused(False)
+    f3, g3 = prob.objective(x)
+    assert np.array_equal(f1, f3)
+    for b in range(prob.B):
+        sl = slice(prob.x_off[b], prob.x_off[b + 1])
+        assert np.abs(g1[sl] - g3[sl]).max() <= 1e-10 * max(np.abs(g3[sl]).max(), abs(f3[b]), 1e-300)
     prob.close()
 
 
