@@ -575,7 +575,7 @@ class Problem:
 
     def set_eval_fused(self, on: bool):
         """Diagnostic: False = evaluations as three stage launches, True = the default (one launch where it applies, frx_eval_kernel.hpp)."""
-        _check(lib().frx_debug_set_eval_fused(self.h, 1 if on else 0))
+        _check(lib().frx_debug_set_eval_fused(self.h, int(on)))          # (2: test mode - every wait inside the launch expires at once)
 
     def eval_fused(self) -> int:
         """Workgroups per candidate of the one-launch evaluation in use, 0 = one launch per stage."""

@@ -188,6 +188,7 @@ struct frx_problem {
     // (set at create when the geometry applies and the chip holds the whole batch at once; FRX_EVAL_FUSED=0 / frx_debug_set_eval_fused turn it off)
     DevBuf<unsigned long long> d_ev_ll; DevBuf<unsigned> d_ev_words;
     int eval_fused = 0, eval_fused_G = 0, eval_fused_stamps = 0;
+    unsigned long long eval_fused_ticks = 200000000ull;     // bound of every wait inside the launch: 2 s of the 100 MHz counter
     frx::LaunchGeom geo;
     bool banded_ok = true;
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
@@ -200,17 +201,20 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
     // a plain evaluation of a batch the chip holds at once: ONE launch (clusters of workgroups, frx_eval_kernel.hpp); the optimiser's rounds (line-search tap,
     // skipped candidates) and the diagnostics that look at stage buffers keep the three stage kernels
     if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps))
-        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words.p, 200000000ull /* 2 s */, st);
+        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words.p, p->eval_fused_ticks, st);
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
     return frx::launch_backward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_band.p, p->d_out20.p, f_dev, g_dev, st, p->tap_d, p->tap_flags, p->tap_res, p->tap_arrive, p->tap_flag, p->tap_round);
 }
 
-// The one-launch evaluation's sticky error word (a wait inside the launch expired: the candidates' f are NaN).  Read, cleared, reported; the handle then goes on
-// with the stage kernels.  The stream has been synchronised by the caller.
-int eval_cluster_status(frx_problem *p) {
+// The one-launch evaluation's sticky error word (a wait inside the launch expired: the f of the candidates concerned are NaN, so the word is only fetched when
+// an objective value is not a number).  Read, cleared, reported; the handle then goes on with the stage kernels.  The stream has been synchronised by the caller.
+int eval_cluster_status(frx_problem *p, const double *f) {
     if (!p->eval_fused) return FRX_OK;
+    bool any_nan = false;
+    for (int b = 0; b < p->B; b++) any_nan = any_nan || f[b] != f[b];
+    if (!any_nan) return FRX_OK;
     unsigned st = 0;
     unsigned *w = p->d_ev_words.p + (size_t)64 * p->B;
     HIP_TRY(hipMemcpy(&st, w, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -647,6 +651,7 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
 int frx_debug_set_eval_fused(frx_problem *p, int enable) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
     p->eval_fused = (enable && p->eval_fused_G) ? 1 : 0;
+    p->eval_fused_ticks = enable == 2 ? 1ull : 200000000ull;              // 2 (tests): every wait inside the launch expires at once - the failure path
     return FRX_OK;
 }
 int frx_debug_eval_fused(const frx_problem *p) { return (p && p->eval_fused) ? p->eval_fused_G : 0; }
@@ -666,7 +671,8 @@ int frx_eval_launch_time(frx_problem *p, const double *x, int reps, double *out_
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, evp.e0, evp.e1));
     *out_us = 1e3 * ms / reps;
-    return eval_cluster_status(p);
+    HIP_TRY(hipMemcpy(f.data(), p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost));
+    return eval_cluster_status(p, f.data());
 }
 
 int frx_problem_totals(const frx_problem *p, int *out6) {
@@ -706,7 +712,7 @@ int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     std::memcpy(f, p->h_f.p, sizeof(double) * p->B);
     std::memcpy(g, p->h_g.p, sizeof(double) * p->NX);
-    return eval_cluster_status(p);
+    return eval_cluster_status(p, f);
 }
 
 // Asynchronous form of frx_objective_eval for host buffers: returns once the copies and kernels are enqueued on the handle's
@@ -730,8 +736,9 @@ int frx_wait(frx_problem *p) {
     if (p->pending_f) {
         std::memcpy(p->pending_f, p->h_f.p, sizeof(double) * p->B);
         std::memcpy(p->pending_g, p->h_g.p, sizeof(double) * p->NX);
+        const double *fdone = p->pending_f;
         p->pending_f = nullptr; p->pending_g = nullptr;
-        return eval_cluster_status(p);
+        return eval_cluster_status(p, fdone);
     }
     return FRX_OK;
 }

@@ -131,6 +131,7 @@ size_t round_lds_bytes(const LaunchGeom &g, int m, int E) {
     if ((E != ROUND_E && E != ROUND_E_SMALL) || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
     return sizeof(double) * (size_t)round_lds(m, 2 * E, round_eval_doubles(g)).total;
 }
+static bool n64_class(const LaunchGeom &g) { static const bool generic = [] { const char *e = std::getenv("FRX_RESIDENT_NR"); return e && e[0] == '0'; }(); return g.knot_threads == 64 && !generic; }   // FRX_RESIDENT_NR=0: the generic instantiation (A/B)
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream) {
     if (r.E != ROUND_E && r.E != ROUND_E_SMALL) return (int)hipErrorInvalidValue;
     RoundArgs a;
@@ -156,7 +157,7 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     // Instantiations: history elements per thread (56: six history workgroups at the headline size; 28: twelve, for batches that leave the chip room -
     // no history register in an AGPR, both history loops half as long), with / without the profile, for <= 64 pieces per candidate (the
     // class-specific bodies only) or any geometry.
-    const bool n64 = g.knot_threads == 64 && !([] { const char *e = std::getenv("FRX_RESIDENT_NR"); return e && e[0] == '0'; }());   // FRX_RESIDENT_NR=0: the generic instantiation (A/B)
+    const bool n64 = n64_class(g);
     const dim3 grid(8 * r.G * ((r.S + 7) / 8)), block(256);
     auto go = [&](auto kernel) -> int {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
     ResidentOps ro;
     ro.xs = sm + L.xs; ro.vs = sm + L.vs; ro.dsv = sm + L.xs; ro.pw = sm + L.pw; ro.gs = nullptr; ro.vskew = 0; ro.wq = sm + L.wq; ro.gpub = nullptr; ro.gwt = true;
     const GranuleOut go{a.ctll, tag, flag, (tag << 4) | (my_xcc ? my_xcc : 15u), a.force_wt ? nullptr : flag + 8, (ntasks + 3) / 4};   // (C, T) leave as granules; nothing is drained, no flag follows them
-    forward_knot_body<true, 64, true>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro, nullptr, &go);
+    forward_knot_body<true, 64, 3>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro, nullptr, &go);
     if (a.dp.stamps && k == 0 && t == 0) a.dp.stamps[41] = (long long)wall_clock64();
     ro.o20ll = a.out20ll; ro.o20tag = tag; ro.status = a.status; ro.spin_ticks = a.timeout_ticks;
     const LineSearchTap tap{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr};

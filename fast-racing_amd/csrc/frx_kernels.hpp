@@ -94,8 +94,8 @@ struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; d
 // caller fetches them once (rk_leader_loop, load_candidate) and hands them in; fetched inside the body they cost it a scalar load and a dependent vector
 // load from L2 in front of everything else - 1 100 cycles before the first duration is formed (cycle stamps, round 5).
 struct KnotPre { int p0, N, c0, cN, x0, cv0, pc, piv, wnv, wvb, wxb; double bs[6]; };
-// The one-launch evaluation's way out of the forward map (frx_eval_kernel.hpp; forward_knot_body<.., RSTAGE = true>): (C, T) leave as granules tagged `tag` in ll ([P][19],
-// duration at index 18) INSTEAD of plain stores, and `gate` receives gate_val (the tag and the leader's XCD) right behind them.  mxw: nmx words in which the
+// The one-launch evaluation's way out of the forward map (forward_knot_body<.., MODE & 2>: frx_eval_kernel.hpp, and the resident round kernel's (C, T) hand-off): (C, T) leave as granules tagged `tag` in ll ([P][19],
+// duration at index 18) INSTEAD of plain stores, and `gate` (optional) receives gate_val (the tag and the leader's XCD) right behind them.  mxw: nmx words in which the
 // consumers published gate_val if they run on the leader's XCD - when all did, the granules leave as plain stores (that XCD's L2 is the meeting point) instead of
 // write-through ones; null: always write-through.
 struct GranuleOut { ll_u64 *ll; unsigned tag; unsigned *gate; unsigned gate_val; const unsigned *mxw; int nmx; };
@@ -431,7 +431,7 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
 // sums as penalty_body.  Returns false when a wait expired (status receives the code).
 template <bool LAT>
 __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u64 *__restrict__ ct_ll, const unsigned *gate, unsigned tag, ll_u64 *__restrict__ out20ll,
-                                                int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, unsigned *status, ll_u64 spin_ticks, unsigned my_xcc, long long *stamps = nullptr) {
+                                                int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, unsigned *status, ll_u64 spin_ticks, unsigned my_xcc, long long *stamps = nullptr, int wt_fixed = -1) {
 #define PW_STAMP(slot) do { if (stamps && lane == 0) stamps[slot] = (long long)wall_clock64(); } while (0)   // (the 100 MHz counter all workgroups share: the shader clocks of two XCDs are unrelated)
     PW_STAMP(44);
     const int hstride = (Kmax + 1) * 4;
@@ -454,6 +454,7 @@ __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u
     const ll_u64 t_end = (ll_u64)wall_clock64() + spin_ticks;
     bool ok = true;
     unsigned gv = 0;
+    if (gate)                                                              // (null: the caller has been told already - the round kernel's phase word)
     for (unsigned spins = 0;; spins++) {                                   // the gate: one word per cluster (every lane reads the same address: one request per wave); tag << 4 | the leader's XCD + 1
         gv = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((gv >> 4) == tag) break;
@@ -496,7 +497,7 @@ __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u
     if (pl < npieces) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, Kmax, red + lane * 21);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PW_STAMP(47);
-    const bool wt = my_xcc == 0u || (gv & 15u) != my_xcc;                  // the partials leave as plain stores when the leader runs on this XCD (its L2 is the meeting point), write-through otherwise
+    const bool wt = wt_fixed >= 0 ? wt_fixed != 0 : my_xcc == 0u || (gv & 15u) != my_xcc;                  // the partials leave as plain stores when the leader runs on this XCD (its L2 is the meeting point), write-through otherwise
     penalty_reduce<true>(red, npieces, lpp, nullptr, lane, 64, wt, out20ll + (size_t)gp0 * 40, tag);
     PW_STAMP(48);
 #undef PW_STAMP
@@ -1154,10 +1155,11 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
 // NR > 0: the caller KNOWS the geometry class at compile time (nrow = NR rows, 256 threads: the resident round kernel's instantiation for <= 64 pieces):
 // the forms for the other classes are not compiled into it - k_round carried all three (146 KB of code against a 64 KB instruction cache that two
 // CUs share; the leader walks through forward map, adjoint and control code once per round, each time from L2).
-// RSTAGE: the caller is the leader of the one-launch evaluation (frx_eval_kernel.hpp).  It hands in resident operands (`ro`, not null) that THIS call fills - x and the
-// polytopes are staged into ro->xs / ro->vs here, with the index-table loads of the body in the same memory latency; it keeps them for the adjoint of the same
-// launch - and (C, T) leave as granules (`go`, GranuleOut).  None of that is compiled into the other callers.
-template <bool SH, int NR = 0, bool RSTAGE = false>
+// MODE (bits; 0 for the stage kernels): 1 = the caller hands in resident operands (`ro`, not null) that THIS call fills - x and the polytopes are staged into
+// ro->xs / ro->vs here, with the index-table loads of the body in the same memory latency (the leader of the one-launch evaluation, frx_eval_kernel.hpp, keeps
+// them for the adjoint of the same launch); 2 = with `go` not null (GranuleOut) the coefficients and durations leave as granules instead of plain stores (the
+// one-launch evaluation, and the resident round kernel's <= 64-piece instantiations).  What a caller does not ask for is not compiled into it.
+template <bool SH, int NR = 0, int MODE = 0>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr,
                                const KnotPre *pre = nullptr, const GranuleOut *go = nullptr) {
@@ -1204,7 +1206,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     if (wsp64 && k == 0) *progress = 0u;
     {   // coalesced staging: every later access is an LDS access (the per-waypoint loops would otherwise serialise
         // one global-memory latency per vertex)
-        if (!ro || RSTAGE) {
+        if (!ro || (MODE & 1)) {
             const int nx = dp.xoff[b + 1] - x0;
             const int v0 = dp.cvoff[b], nvd = 3 * (dp.cvoff[b + 1] - v0);
             const double *vsrc = dp.vrec + 3 * (size_t)v0;
@@ -1240,7 +1242,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     if (k < N) {
         hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
-        if (RSTAGE && SH && go) rk_ll_put(go->ll + 2 * ((size_t)(p0 + k) * 19 + 18), hMine, go->tag, true);   // (early, off the critical path: write-through whatever the consumers' XCD)
+        if ((MODE & 2) && SH && go && go->ll) rk_ll_put(go->ll + 2 * ((size_t)(p0 + k) * 19 + 18), hMine, go->tag, go->mxw ? true : wt);   // (mxw: where the consumers run is not known yet - early, off the critical path: write-through)
         else stg<SH>(Tout + p0 + k, hMine, wt);
         if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
@@ -1315,7 +1317,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 }
             }
             FRX_STAMP_AX(10);
-            if (RSTAGE && SH && go && go->mxw && wave == 3) {
+            if ((MODE & 2) && SH && go && go->ll && go->mxw && wave == 3) {
                 // Do all consumers of the granules run on this XCD?  They said so, or not yet, in go->mxw[0 .. nmx) (write-through stores at their entry, microseconds ago);
                 // this wave has the slack for the trip - its reduction below follows the matrix wave, which is two steps into its six by now.  "Not yet" counts as no.
                 unsigned vq = go->gate_val;
@@ -1371,18 +1373,18 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         // C leaves the workgroup as ONE coalesced sweep of 16-byte stores by all four waves.  Stored straight from the axis lanes it was 1152
         // scattered 8-byte write-through stores (lane stride 144 bytes), and draining them cost the resident kernel ~2 us per round.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const bool wt_ll = (RSTAGE && SH && go && go->mxw) ? progress[1] == 0u : wt;   // (granules: see the decision of wave 3 above)
+        const bool wt_ll = ((MODE & 2) && SH && go && go->ll && go->mxw) ? progress[1] == 0u : wt;   // (granules: see the decision of wave 3 above)
         for (int i = k; i < 9 * N; i += 256) {                              // 9 pairs of doubles per piece
             const int pc = i / 9, q2 = 2 * (i - 9 * pc);
             const double v0 = cstage[pc * 19 + q2], v1 = cstage[pc * 19 + q2 + 1];
             double *dst = Cout + (size_t)(p0 + pc) * 18 + q2;
-            if (RSTAGE && SH && go) { ll_u64 *gl = go->ll + 2 * ((size_t)(p0 + pc) * 19 + q2); rk_ll_put(gl, v0, go->tag, wt_ll); rk_ll_put(gl + 2, v1, go->tag, wt_ll); }
+            if ((MODE & 2) && SH && go && go->ll) { ll_u64 *gl = go->ll + 2 * ((size_t)(p0 + pc) * 19 + q2); rk_ll_put(gl, v0, go->tag, wt_ll); rk_ll_put(gl + 2, v1, go->tag, wt_ll); }
             else if (SH && wt) { stg<SH>(dst, v0, true); stg<SH>(dst + 1, v1, true); }
             else *(double2 *)dst = make_double2(v0, v1);
         }
         // the gate of the granules' consumers: set BEHIND the sweep, not drained - it tells the members' waves that a poll of their granules is now worth its trip
         // (polled from the start of the launch, by 49 k lanes, the granules cost more than they save: every poll is a transaction on the fabric between the XCDs)
-        if (RSTAGE && SH && go && k == 255) __hip_atomic_store(go->gate, go->gate_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((MODE & 2) && SH && go && go->ll && go->gate && k == 255) __hip_atomic_store(go->gate, go->gate_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         FRX_STAMP(6);
         return;
     }

@@ -427,6 +427,28 @@ print(json.dumps({"fused": prob.eval_fused(), "replays_same": same, "blocking_ca
 
 
 @pytest.mark.gpu
+def test_one_launch_evaluation_fails_loudly_and_the_handle_stays_usable(frx, sc):
+    """Every wait inside the launch is bounded.  With the bound set to one tick (test mode) the leader's poll for the penalty partials expires: the blocking call
+    reports FRX_ERR_TIMEOUT - never a number computed from partials that did not arrive - and the handle continues with the three stage launches."""
+    cands = [sc.make_candidate(0, 32, 8, perturb_id=b) for b in range(4)]
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+    x = prob.initial_guess()
+    f_ok, g_ok = prob.objective(x)
+    assert prob.eval_fused() > 0
+    prob.set_eval_fused(2)
+    with pytest.raises(frx.FrxError) as ei:
+        prob.objective(x)
+    assert "expired" in str(ei.value)
+    assert prob.eval_fused() == 0                                                            # the handle fell back to one launch per stage
+    f3, g3 = prob.objective(x)
+    assert np.array_equal(f3, f_ok) and np.abs(g3 - g_ok).max() <= 1e-10 * np.abs(g_ok).max()
+    prob.set_eval_fused(1)                                                                   # ... and can be switched back
+    f1, g1 = prob.objective(x)
+    assert np.array_equal(f1, f_ok) and np.array_equal(g1, g_ok)
+    prob.close()
+
+
+@pytest.mark.gpu
 def test_one_launch_evaluation_only_for_batches_the_chip_holds(frx, sc):
     """A leader waits for members of its own launch, so every workgroup of the grid has to get a CU: 36 candidates x 7 workgroups fit 256 CUs, 40 do not and
     are evaluated by three stage launches; ragged batches take the cluster size of their largest candidate, smaller candidates leave members idle."""
