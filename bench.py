@@ -166,6 +166,10 @@ def main():
     # so that the N > 1 control flow can be exercised on a 1-GPU box
     if os.environ.get("FRX_BENCH_DEVICE"):
         local_rank = int(os.environ["FRX_BENCH_DEVICE"])
+        # More than four ranks on ONE device: their evaluation steps run at the same time, and the one-launch evaluation (clusters whose leader waits for members of the
+        # same launch, csrc/frx_eval_kernel.hpp) is sized for a chip of its own - five or more such grids side by side can each hold a part of their first clusters and
+        # wait for CUs the others hold (bounded: the launch fails after 2 s).  The control-flow test of such a job takes the three stage launches.
+        if world > 4: os.environ["FRX_EVAL_FUSED"] = "0"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 and not lib_mode:
