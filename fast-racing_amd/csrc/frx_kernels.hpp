@@ -94,7 +94,7 @@ struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; d
 // caller fetches them once (rk_leader_loop, load_candidate) and hands them in; fetched inside the body they cost it a scalar load and a dependent vector
 // load from L2 in front of everything else - 1 100 cycles before the first duration is formed (cycle stamps, round 5).
 struct KnotPre { int p0, N, c0, cN, x0, cv0, pc, piv, wnv, wvb, wxb; double bs[6]; };
-// The one-launch evaluation's way out of the forward map (forward_knot_body<.., MODE & 2>: frx_eval_kernel.hpp, and the resident round kernel's (C, T) hand-off): (C, T) leave as granules tagged `tag` in ll ([P][19],
+// The one-launch evaluation's way out of the forward map (forward_knot_body<.., MODE & 2>: frx_eval_kernel.hpp): (C, T) leave as granules tagged `tag` in ll ([P][19],
 // duration at index 18) INSTEAD of plain stores, and `gate` (optional) receives gate_val (the tag and the leader's XCD) right behind them.  mxw: nmx words in which the
 // consumers published gate_val if they run on the leader's XCD - when all did, the granules leave as plain stores (that XCD's L2 is the meeting point) instead of
 // write-through ones; null: always write-through.
@@ -431,7 +431,7 @@ __device__ __forceinline__ void penalty_body(const DevProblem &dp, const double 
 // sums as penalty_body.  Returns false when a wait expired (status receives the code).
 template <bool LAT>
 __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u64 *__restrict__ ct_ll, const unsigned *gate, unsigned tag, ll_u64 *__restrict__ out20ll,
-                                                int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, unsigned *status, ll_u64 spin_ticks, unsigned my_xcc, long long *stamps = nullptr, int wt_fixed = -1) {
+                                                int lpp, int ppw, int Kmax, int gp0, int npieces, double *sm, int lane, unsigned *status, ll_u64 spin_ticks, unsigned my_xcc, long long *stamps = nullptr) {
 #define PW_STAMP(slot) do { if (stamps && lane == 0) stamps[slot] = (long long)wall_clock64(); } while (0)   // (the 100 MHz counter all workgroups share: the shader clocks of two XCDs are unrelated)
     PW_STAMP(44);
     const int hstride = (Kmax + 1) * 4;
@@ -454,7 +454,6 @@ __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u
     const ll_u64 t_end = (ll_u64)wall_clock64() + spin_ticks;
     bool ok = true;
     unsigned gv = 0;
-    if (gate)                                                              // (null: the caller has been told already - the round kernel's phase word)
     for (unsigned spins = 0;; spins++) {                                   // the gate: one word per cluster (every lane reads the same address: one request per wave); tag << 4 | the leader's XCD + 1
         gv = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((gv >> 4) == tag) break;
@@ -497,7 +496,7 @@ __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u
     if (pl < npieces) penalty_lane_samples<LAT>(dp, cS + pl * 18, hS + (size_t)pl * hstride, tS[pl], jl, lpp, Kmax, red + lane * 21);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PW_STAMP(47);
-    const bool wt = wt_fixed >= 0 ? wt_fixed != 0 : my_xcc == 0u || (gv & 15u) != my_xcc;                  // the partials leave as plain stores when the leader runs on this XCD (its L2 is the meeting point), write-through otherwise
+    const bool wt = my_xcc == 0u || (gv & 15u) != my_xcc;                  // the partials leave as plain stores when the leader runs on this XCD (its L2 is the meeting point), write-through otherwise
     penalty_reduce<true>(red, npieces, lpp, nullptr, lane, 64, wt, out20ll + (size_t)gp0 * 40, tag);
     PW_STAMP(48);
 #undef PW_STAMP
@@ -1158,7 +1157,7 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
 // MODE (bits; 0 for the stage kernels): 1 = the caller hands in resident operands (`ro`, not null) that THIS call fills - x and the polytopes are staged into
 // ro->xs / ro->vs here, with the index-table loads of the body in the same memory latency (the leader of the one-launch evaluation, frx_eval_kernel.hpp, keeps
 // them for the adjoint of the same launch); 2 = with `go` not null (GranuleOut) the coefficients and durations leave as granules instead of plain stores (the
-// one-launch evaluation, and the resident round kernel's <= 64-piece instantiations).  What a caller does not ask for is not compiled into it.
+// one-launch evaluation; measured inside the resident round kernel as well - slower there than its drained phase word, profiles/NOTES.md).  What a caller does not ask for is not compiled into it.
 template <bool SH, int NR = 0, int MODE = 0>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr,

@@ -251,6 +251,10 @@ int frx_initial_guess(frx_problem *p, double *x0);
  * Replaces SE3GCOPTER::objectiveFunc (CPU.hpp:961-1000) for the whole batch: x -> (f, grad).
  * One call = steps 1-7 of SURVEY.md §3.4 for every candidate, entirely on the device.
  *   x, g : total-free-variables doubles;  f : B doubles.
+ * On the device this is ONE kernel launch (clusters of workgroups, one per candidate) when every candidate has <= 64 pieces and the chip holds the whole batch at
+ * once, three stage launches otherwise; the _device form is a pure sequence of launches on the caller's stream (capturable in a hipGraph), one evaluation in flight
+ * per handle.  Should a wait inside the one-launch form expire (a device shared with other grids: INTEGRATION.md 8) the objective values concerned are NaN and the
+ * blocking form returns FRX_ERR_TIMEOUT; the handle then continues with the three launches.
  */
 int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g);
 int frx_objective_eval_device(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *hip_stream);
