@@ -651,7 +651,7 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
 int frx_debug_set_eval_fused(frx_problem *p, int enable) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
     p->eval_fused = (enable && p->eval_fused_G) ? 1 : 0;
-    p->eval_fused_ticks = enable == 2 ? 1ull : 200000000ull;              // 2 (tests): every wait inside the launch expires at once - the failure path
+    p->eval_fused_ticks = enable == 2 ? 1ull : 200000000ull;              // 2 (tests): the value 1 tells the launcher to drop the members and bound the leader's waits at 50 us - the failure path
     return FRX_OK;
 }
 int frx_debug_eval_fused(const frx_problem *p) { return (p && p->eval_fused) ? p->eval_fused_G : 0; }

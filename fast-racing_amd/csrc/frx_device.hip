@@ -44,6 +44,8 @@ int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double 
     a.dp = dp; a.x = x; a.T = T; a.C = C; a.f = f; a.g = grad; a.out20ll = ll; a.ctll = ll + (size_t)40 * dp.P; a.words = words; a.status = words + (size_t)64 * dp.B; a.timeout_ticks = timeout_ticks;
     a.G = g.ev_G; a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax; a.pen_lds = eval_pen_lds(g); a.maxN19 = g.maxN * 19;
     { const char *e = std::getenv("FRX_EVAL_FUSED_WT"); a.force_wt = (e && e[0] == '1') ? 1 : 0; }
+    a.test_drop_members = timeout_ticks == 1ull ? 1 : 0;               // (test mode, frx_debug_set_eval_fused(p, 2): members that never arrive and a 50 us bound)
+    if (a.test_drop_members) a.timeout_ticks = 5000ull;
     hipLaunchKernelGGL(k_eval_cluster, dim3(8 * g.ev_G * ((dp.B + 7) / 8)), dim3(256), g.lds_ev, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

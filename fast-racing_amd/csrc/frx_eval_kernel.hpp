@@ -38,6 +38,7 @@ struct EvalClusterArgs {
     unsigned *status;                        // [1] sticky error word
     rk_u64 timeout_ticks;
     int G, maxCN, maxXb, maxVb, nsteps, lpp, ppw, Kmax, pen_lds, maxN19;
+    int test_drop_members;                   // tests (frx_debug_set_eval_fused(p, 2)): the members leave at once, as if they never got a CU - the leader's wait for the partials expires
     int force_wt;                            // 1 = every payload store write-through, as if no two workgroups shared an XCD (tests: FRX_EVAL_FUSED_WT=1)
 };
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
     unsigned *flag = a.words + (size_t)k * 64, *done = flag + 32;
     const int p0 = a.dp.poff[c], N = a.dp.poff[c + 1] - p0;
     const int ntasks = (N + a.ppw - 1) / a.ppw;                     // wave-tasks of this candidate: ppw pieces each; members 1 .. G-1 hold 4 (G - 1) >= ntasks waves
-    if (wg != 0 && (wg - 1) * 4 >= ntasks) return;                  // a member without a task
+    if (wg != 0 && ((wg - 1) * 4 >= ntasks || a.test_drop_members)) return;   // a member without a task
     unsigned tag = __hip_atomic_load(done, FRX_RLX_AGENT) + 1u;     // (stays in a vector register: nothing waits for the load until the tag is used)
     if (tag >= (1u << 28)) tag = 1u;
     // Where does this workgroup run?  Payload between two workgroups of one XCD can meet in that XCD's L2 (plain stores, L1-bypassing loads); across XCDs it has

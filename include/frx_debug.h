@@ -52,8 +52,8 @@ int frx_debug_resident_predictions(const frx_problem *p, unsigned long long *out
 int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3_us);
 /* One launch per evaluation (fast-racing_amd/csrc/frx_eval_kernel.hpp): frx_objective_eval[_device] run a batch that the chip holds at once - candidates of <= 64
  * pieces, B x (1 + ceil(ceil(N / pieces per wave) / 4)) workgroups <= the device's CU count - as ONE grid of clusters instead of three stage launches, with
- * the same objective bit for bit and the same gradient to <= 1e-10.  set(0) keeps the three launches, set(1) returns to the default, set(2) (tests) is set(1) with every wait inside the launch expiring at
- * once: the evaluation fails with FRX_ERR_TIMEOUT (objective values NaN) and the handle goes on with three launches; frx_debug_eval_fused = workgroups per candidate of the form in use,
+ * the same objective bit for bit and the same gradient to <= 1e-10.  set(0) keeps the three launches, set(1) returns to the default, set(2) (tests) is set(1) with members that leave at once, as if
+ * they never got a CU, and a 50 us bound on the leader's waits: the evaluation fails with FRX_ERR_TIMEOUT (objective values NaN) and the handle goes on with three launches; frx_debug_eval_fused = workgroups per candidate of the form in use,
  * 0 = one launch per stage.  The environment variable FRX_EVAL_FUSED=0 turns the form off for every handle created afterwards. */
 int frx_debug_set_eval_fused(frx_problem *p, int enable);
 int frx_debug_eval_fused(const frx_problem *p);

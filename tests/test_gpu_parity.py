@@ -428,8 +428,8 @@ print(json.dumps({"fused": prob.eval_fused(), "replays_same": same, "blocking_ca
 
 @pytest.mark.gpu
 def test_one_launch_evaluation_fails_loudly_and_the_handle_stays_usable(frx, sc):
-    """Every wait inside the launch is bounded.  With the bound set to one tick (test mode) the leader's poll for the penalty partials expires: the blocking call
-    reports FRX_ERR_TIMEOUT - never a number computed from partials that did not arrive - and the handle continues with the three stage launches."""
+    """Every wait inside the launch is bounded.  In test mode the members leave at once - as if they never got a CU - and the leader's poll for the penalty partials
+    expires after 50 us: the blocking call reports FRX_ERR_TIMEOUT - never a number computed from partials that did not arrive - and the handle continues with the three stage launches."""
     cands = [sc.make_candidate(0, 32, 8, perturb_id=b) for b in range(4)]
     prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
     x = prob.initial_guess()
