@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
@@ -12,18 +13,32 @@
 
 namespace frx {
 
+// The dynamic-LDS limit of a kernel is a property of the FUNCTION, not of a handle: handles of different geometry live side by side (tests, a planner with several
+// corridors), so the limit only ever grows - a handle created later with a smaller need must not lower it under an older handle's launches.
+static int raise_lds_limit(const void *fn, size_t bytes, size_t &held) {
+    if (bytes <= held) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) held = bytes;
+    return (int)e;
+}
 int launch_set_limits(const LaunchGeom &g) {
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void *)k_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fwd)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bwd)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_penalty, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_penalty_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen)) != hipSuccess) return (int)e;
-    if (g.lds_pen2 && (e = hipFuncSetAttribute((const void *)k_penalty_lat2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_pen2)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_forward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_backward_knot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_forward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kfwd)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute((const void *)k_backward_knot64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_kbwd)) != hipSuccess) return (int)e;
-    if (g.ev_G && (e = hipFuncSetAttribute((const void *)k_eval_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_ev)) != hipSuccess) return (int)e;
+    static std::mutex mu;
+    static size_t held_all[64][10] = {};                             // per device: a function's attributes belong to the device that is current
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    size_t *held = held_all[dev];
+    int e;
+    if ((e = raise_lds_limit((const void *)k_forward, g.lds_fwd, held[0]))) return e;
+    if ((e = raise_lds_limit((const void *)k_backward, g.lds_bwd, held[1]))) return e;
+    if ((e = raise_lds_limit((const void *)k_penalty, g.lds_pen, held[2]))) return e;
+    if ((e = raise_lds_limit((const void *)k_penalty_lat, g.lds_pen, held[3]))) return e;
+    if (g.lds_pen2 && (e = raise_lds_limit((const void *)k_penalty_lat2, g.lds_pen2, held[4]))) return e;
+    if ((e = raise_lds_limit((const void *)k_forward_knot, g.lds_kfwd, held[5]))) return e;
+    if ((e = raise_lds_limit((const void *)k_backward_knot, g.lds_kbwd, held[6]))) return e;
+    if ((e = raise_lds_limit((const void *)k_forward_knot64, g.lds_kfwd, held[7]))) return e;
+    if ((e = raise_lds_limit((const void *)k_backward_knot64, g.lds_kbwd, held[8]))) return e;
+    if (g.ev_G && (e = raise_lds_limit((const void *)k_eval_cluster, g.lds_ev, held[9]))) return e;
     return 0;
 }
 static int eval_pen_lds(const LaunchGeom &g) { return g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21; }   // doubles per wave (penalty_body with a 64-lane group)

@@ -632,3 +632,20 @@ def test_both_forms_of_the_penalty_integrator_agree(frx, sc):
         subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
         o = np.load(os.path.join(td, "out.npz"))
         assert rel(o["c"], c0) < 1e-13 and rel(o["gT"], gT0) < 1e-13 and rel(o["gC"], gC0) < 1e-13
+
+
+@pytest.mark.gpu
+def test_handles_of_different_geometry_side_by_side(frx, sc):
+    """The dynamic-LDS limit of a kernel belongs to the function, not to a handle: a handle created LATER with a smaller need must not lower it under an older
+    handle's launches (large polytopes / many pieces first, then a small problem, then the large one evaluates again - in both forms of the evaluation)."""
+    big = frx.Problem([sc.make_candidate(0, 64, 16, perturb_id=b) for b in range(2)], sc.ZHANGJIAJIE, qd_intervals=48)
+    xb = big.initial_guess()
+    fb, gb = big.objective(xb)
+    small = frx.Problem([sc.make_candidate(0, 2, 0, perturb_id=0)], sc.ZHANGJIAJIE, qd_intervals=8)
+    fs, gs = small.objective(small.initial_guess())
+    assert np.isfinite(fs).all()
+    for one_launch in (True, False):
+        big.set_eval_fused(one_launch)
+        f2, g2 = big.objective(xb)
+        assert np.array_equal(f2, fb)
+    big.close(); small.close()
