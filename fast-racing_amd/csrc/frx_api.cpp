@@ -186,7 +186,7 @@ struct frx_problem {
     std::vector<double> trace;                              // FRX_TRACE: per command of candidate 0 {flags, step, f, dg, dginit, xx, gg}
     // one launch per evaluation (frx_eval_kernel.hpp): granules and control words of its clusters, zeroed once; eval_fused: 1 = frx_objective_eval[_device] take it
     // (set at create when the geometry applies and the chip holds the whole batch at once; FRX_EVAL_FUSED=0 / frx_debug_set_eval_fused turn it off)
-    DevBuf<unsigned long long> d_ev_ll; DevBuf<unsigned> d_ev_words;
+    DevBuf<unsigned long long> d_ev_ll; unsigned *d_ev_words = nullptr;   // one allocation: [78 P] granule words, then the [64 B + 1] control words
     int eval_fused = 0, eval_fused_G = 0, eval_fused_stamps = 0;
     unsigned long long eval_fused_ticks = 200000000ull;     // bound of every wait inside the launch: 2 s of the 100 MHz counter
     frx::LaunchGeom geo;
@@ -201,7 +201,7 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
     // a plain evaluation of a batch the chip holds at once: ONE launch (clusters of workgroups, frx_eval_kernel.hpp); the optimiser's rounds (line-search tap,
     // skipped candidates) and the diagnostics that look at stage buffers keep the three stage kernels
     if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps))
-        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words.p, p->eval_fused_ticks, st);
+        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words, p->eval_fused_ticks, st);
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
@@ -216,7 +216,7 @@ int eval_cluster_status(frx_problem *p, const double *f) {
     for (int b = 0; b < p->B; b++) any_nan = any_nan || f[b] != f[b];
     if (!any_nan) return FRX_OK;
     unsigned st = 0;
-    unsigned *w = p->d_ev_words.p + (size_t)64 * p->B;
+    unsigned *w = p->d_ev_words + (size_t)64 * p->B;
     HIP_TRY(hipMemcpy(&st, w, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (st == 0) return FRX_OK;
     HIP_TRY(hipMemset(w, 0, sizeof(unsigned)));
@@ -431,8 +431,9 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     CR(p->d_pcrw.alloc((size_t)(p->geo.pcr_steps * 8 + 4) * p->P)); p->geo.pcrw = p->d_pcrw.p;
     CR(p->d_wq.alloc((size_t)4 * p->P)); CR(hipMemset(p->d_wq.p, 0, sizeof(double) * 4 * p->P));
     if (p->eval_fused_G) {
-        CR(p->d_ev_ll.alloc((size_t)78 * p->P)); CR(hipMemsetAsync(p->d_ev_ll.p, 0, sizeof(unsigned long long) * 78 * p->P, p->stream));
-        CR(p->d_ev_words.alloc((size_t)64 * B + 1)); CR(hipMemsetAsync(p->d_ev_words.p, 0, sizeof(unsigned) * ((size_t)64 * B + 1), p->stream));
+        const size_t n_ll = (size_t)78 * p->P, n_w64 = ((size_t)64 * B + 2) / 2;
+        CR(p->d_ev_ll.alloc(n_ll + n_w64)); CR(hipMemset(p->d_ev_ll.p, 0, sizeof(unsigned long long) * (n_ll + n_w64)));   // (not on the handle's stream: the first evaluation may come on the caller's)
+        p->d_ev_words = (unsigned *)(p->d_ev_ll.p + n_ll);
     }
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
