@@ -1060,9 +1060,12 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     }
     int G = 2 + std::max(1, (p->geo.maxXb + 2 * E - 1) / (2 * E));                   // leader + history workgroups (2 E elements of every pair each) + dense
     const int G_min = std::max(G, 3);
-    {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over G - 1 of them
+    {   // more workgroups per candidate when the chip has room: the penalty integrand of a candidate is spread over the history workgroups, four wave-tasks each, and
+        // the leader - last in line - should get none: it has the adjoint to prepare.  Until round 5 the formula counted the leader as a worker and stopped at 16: the
+        // reference's own operating point (ONE candidate, kappa = 48: 64 wave-tasks) ran its penalty share in two passes on 60 waves.  With 18 workgroups (16 x 4 waves,
+        // one pass, leader free) a round takes 24.4 instead of 26.4 us, bit-identical plans (scripts/r05/plumbing_g_probe.py: 17 -> 25.6, 20 -> 24.5, 24 -> 25.7).
         const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
-        const int want = std::min({(tasks + 3) / 4 + 1, 16, cus / std::max(Bsel, 1)});
+        const int want = std::min({(tasks + 3) / 4 + 2, 18, cus / std::max(Bsel, 1)});
         G = std::max(G, want);
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
