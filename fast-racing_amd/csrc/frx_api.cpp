@@ -1065,7 +1065,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         // reference's own operating point (ONE candidate, kappa = 48: 64 wave-tasks) ran its penalty share in two passes on 60 waves.  With 18 workgroups (16 x 4 waves,
         // one pass, leader free) a round takes 24.4 instead of 26.4 us, bit-identical plans (scripts/r05/plumbing_g_probe.py: 17 -> 25.6, 20 -> 24.5, 24 -> 25.7).
         const int tasks = (p->geo.maxN + p->geo.ppw - 1) / p->geo.ppw;
-        const int want = std::min({(tasks + 3) / 4 + 2, 18, cus / std::max(Bsel, 1)});
+        const int want = std::min({(tasks + 3) / 4 + 2, 18, cus / std::max(Bsel, 1), cus / (8 * ((Bsel + 7) / 8))});   // (the last bound: the grid is 8 G ceil(B / 8) blocks - a wish that does not fit is not made)
         G = std::max(G, want);
     }
     if (const char *ge = std::getenv("FRX_RESIDENT_G")) G = std::max(G, std::atoi(ge));
