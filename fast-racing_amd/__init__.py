@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "frx_objective_eval", "frx_objective_eval_device", "frx_penalty_eval", "frx_penalty_eval_device", "frx_forward",
     "frx_optimize", "frx_optimize_stats", "frx_lbfgs_minimize_batch",
     "frx_problem_create_from_h", "frx_enumerate_vertices", "frx_traj_to_msg", "frx_msg_sample", "frx_line_segment_dilate", "frx_corridor_generate", "frx_traj_max_rates", "frx_objective_eval_async", "frx_wait",
-    "frx_problem_set_resident", "frx_optimize_path",
+    "frx_problem_set_resident", "frx_optimize_path", "frx_penalty_problem_create", "frx_eval_status",
     "frx_dilate_batch", "frx_multi_create", "frx_multi_destroy", "frx_multi_info", "frx_multi_layout", "frx_multi_initial_guess", "frx_multi_optimize", "frx_multi_last_exchange",
     "frx_map_mark_cloud", "frx_map_is_blocked", "frx_grid_search", "frx_jps_plan", "frx_route_plan",
 ]
@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
     "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
-    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_eval_launch_time", "frx_debug_profile_eval_cluster",
+    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at",
 ]
 
 _lib = None
@@ -481,6 +481,14 @@ class Problem:
     def set_resident_retry(self, enable: bool):
         """Diagnostic: re-run candidates that fail on the resident kernel on the per-stage rounds (round-2 behaviour; default off)."""
         _check(lib().frx_debug_set_resident_retry(self.h, 1 if enable else 0))
+
+    def set_takeover_at(self, rounds: int):
+        """Tests (frx_debug_set_takeover_at): rounds > 0 = every plan starts as per-stage rounds and hands its candidates to the resident kernel after so many."""
+        _check(lib().frx_debug_set_takeover_at(self.h, C.c_long(int(rounds))))
+
+    def eval_status(self):
+        """frx_eval_status: has a wait inside a one-launch evaluation expired since the last check?  Raises FrxError (FRX_ERR_TIMEOUT) if so; the caller's stream must be synchronised."""
+        _check(lib().frx_eval_status(self.h))
 
     def taken_over(self) -> int:
         """Candidates of the last plan that began as per-stage rounds and finished on the resident round kernel (frx_debug_taken_over)."""

@@ -21,6 +21,7 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/frx.h"
@@ -123,13 +124,25 @@ double host_cpu_budget() {
 int host_cpu_share();
 // mailbox service threads of a resident plan with S clusters (the caller included): one per sixteen clusters, at most four, and at most share - 1
 int mailbox_threads(int S) { return std::max(1, std::min(std::max(1, std::min(4, S / 16)), host_cpu_share() - 1)); }
-int host_cpu_share() {
+//  The budget is divided by the node's ranks only when they SHARE it: a launcher that pins every rank to its own CPU subset (the affinity mask is
+// smaller than the online set) has made the division already - dividing again left large batches with one mailbox thread where S / 16 were measured to help.
+// FRX_LOCAL_RANKS states the divisor explicitly and is always honoured.
+static int share_of(int extra_plans) {
     int ranks = 1;
     if (const char *e = std::getenv("FRX_LOCAL_RANKS")) ranks = std::max(1, std::atoi(e));
-    else if (const char *e2 = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(e2));
-    const int plans = ranks * (1 + std::max(0, g_extra_plans.load(std::memory_order_relaxed)));
+    else if (const char *e2 = std::getenv("LOCAL_WORLD_SIZE")) {
+        ranks = std::max(1, std::atoi(e2));
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        const long online = sysconf(_SC_NPROCESSORS_ONLN);
+        if (ranks > 1 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && online > 0 && (long)CPU_COUNT(&allowed) * ranks <= online) ranks = 1;   // pinned per rank
+    }
+    const int plans = ranks * (1 + std::max(0, extra_plans));
     return std::max(1, (int)(host_cpu_budget() / plans));
 }
+int host_cpu_share() { return share_of(g_extra_plans.load(std::memory_order_relaxed)); }
+int mailbox_threads_for(int S, int extra_plans) { return std::max(1, std::min(std::max(1, std::min(4, S / 16)), share_of(extra_plans) - 1)); }
+int host_cpu_share_for(int extra_plans) { return share_of(extra_plans); }
 } // namespace frx
 
 struct frx_problem {
@@ -174,6 +187,7 @@ struct frx_problem {
     // newest slot and pair count of its history, and the dense state rebuilt from that history (frx_compact.hpp)
     DevBuf<int> d_rs_int; DevBuf<double> d_rs_f, d_rs_rinv, d_rs_yy, d_rs_vd;
     int taken_over = 0;                                     // candidates of the last plan that finished on the resident kernel after per-stage rounds
+    long takeover_at = 0;                                   // tests (frx_debug_set_takeover_at): > 0 = every plan starts as per-stage rounds and hands over after this many, whatever the batch size
     int resident_clusters = 0;                              // clusters of the last resident launch (< B: the candidates went through the work queue)
     int resident_mode = 1;                                  // 1 = use the resident kernel when it applies (frx_problem_set_resident); 2 = also when the batch
                                                             // is larger than the chip holds at once, whatever its size (work queue); 0 = never
@@ -188,9 +202,12 @@ struct frx_problem {
     // (set at create when the geometry applies and the chip holds the whole batch at once; FRX_EVAL_FUSED=0 / frx_debug_set_eval_fused turn it off)
     DevBuf<unsigned long long> d_ev_ll; unsigned *d_ev_words = nullptr;   // one allocation: [78 P] granule words, then the [64 B + 1] control words
     int eval_fused = 0, eval_fused_G = 0, eval_fused_stamps = 0;
-    unsigned long long eval_fused_ticks = 200000000ull;     // bound of every wait inside the launch: 2 s of the 100 MHz counter
+    unsigned long long eval_fused_ticks = 25000000ull;      // bound of every wait inside the launch, ticks of the 100 MHz counter: 250 ms (a healthy evaluation takes ~20 us; FRX_EVAL_TIMEOUT_MS)
+    PinBuf<unsigned> h_ev_status;                           // mapped host word: the code of an expired wait, written by the leader that saw it - launch_eval reads it without a synchronisation
+    unsigned eval_fused_code = 0;                           // the code that retired the one-launch form on this handle (0: none)
     frx::LaunchGeom geo;
     bool banded_ok = true;
+    bool penalty_only = false;              // frx_penalty_problem_create: the inner boundary alone (no variables, no waypoint polytopes: only frx_penalty_eval[_device] apply)
     int lbfgs_mode = 0;                     // 0 = device vectors (default), 1 = host vectors
     double stats[4] = {0, 0, 0, 0};
 };
@@ -200,8 +217,12 @@ namespace {
 int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *st, bool backward) {
     // a plain evaluation of a batch the chip holds at once: ONE launch (clusters of workgroups, frx_eval_kernel.hpp); the optimiser's rounds (line-search tap,
     // skipped candidates) and the diagnostics that look at stage buffers keep the three stage kernels
+    //  A wait inside an earlier one-launch evaluation expired: its leader left the code in mapped host memory, and from the first launch that sees it the
+    // handle takes the stage kernels by itself - also on the capturable _device form and inside the host-vector L-BFGS, which have no status check of their own.
+    // No HIP call here (the caller may be capturing): the device's sticky word is cleared at the next host-synchronous point (eval_cluster_status).
+    if (p->eval_fused && p->h_ev_status.p && *(volatile unsigned *)p->h_ev_status.p != 0u) { p->eval_fused_code = *(volatile unsigned *)p->h_ev_status.p; p->eval_fused = 0; }
     if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps))
-        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words, p->eval_fused_ticks, st);
+        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words, p->eval_fused_ticks, st, p->h_ev_status.p);
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
@@ -210,17 +231,22 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
 
 // The one-launch evaluation's sticky error word (a wait inside the launch expired: the f of the candidates concerned are NaN, so the word is only fetched when
 // an objective value is not a number).  Read, cleared, reported; the handle then goes on with the stage kernels.  The stream has been synchronised by the caller.
+// f == nullptr (frx_eval_status: the caller of the capturable form asks): the word is fetched whatever the objective values say.
 int eval_cluster_status(frx_problem *p, const double *f) {
-    if (!p->eval_fused) return FRX_OK;
-    bool any_nan = false;
-    for (int b = 0; b < p->B; b++) any_nan = any_nan || f[b] != f[b];
+    if (!p->eval_fused_G || !p->d_ev_words) return FRX_OK;
+    const unsigned seen = p->h_ev_status.p ? *(volatile unsigned *)p->h_ev_status.p : 0u;
+    if (!p->eval_fused && !p->eval_fused_code && !seen) return FRX_OK;                  // switched off by the caller, never failed
+    bool any_nan = f == nullptr || seen != 0u || p->eval_fused_code != 0u;
+    for (int b = 0; f && b < p->B; b++) any_nan = any_nan || f[b] != f[b];
     if (!any_nan) return FRX_OK;
     unsigned st = 0;
     unsigned *w = p->d_ev_words + (size_t)64 * p->B;
     HIP_TRY(hipMemcpy(&st, w, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (st == 0) return FRX_OK;
+    if (st == 0 && seen == 0u && p->eval_fused_code == 0u) return FRX_OK;
+    if (st == 0) st = seen ? seen : p->eval_fused_code;
     HIP_TRY(hipMemset(w, 0, sizeof(unsigned)));
-    p->eval_fused = 0;
+    if (p->h_ev_status.p) *(volatile unsigned *)p->h_ev_status.p = 0u;
+    p->eval_fused = 0; p->eval_fused_code = 0;
     return fail(FRX_ERR_TIMEOUT, "one-launch evaluation: a wait between the workgroups of a cluster expired (code " + std::to_string(st) + "); this handle continues with one launch per stage");
 }
 
@@ -380,8 +406,15 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount; }
         const char *ef = std::getenv("FRX_EVAL_FUSED");
         const int G = frx::eval_cluster_geometry(ge);
-        if (!G || (long long)B * G > cus || (ef && ef[0] == '0')) { ge.ev_G = 0; ge.lds_ev = 0; }
+        //  ranks of one node that SHARE a device (more local ranks than devices): their grids would compete for the CUs a cluster's leader assumes - off
+        // unless asked for (FRX_EVAL_FUSED=1); a lone process, or one rank per device, takes the form
+        int ranks = 1;
+        if (const char *e = std::getenv("FRX_LOCAL_RANKS")) ranks = std::max(1, std::atoi(e));
+        else if (const char *e2 = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(e2));
+        const bool shared_device = ranks > ndev && !(ef && ef[0] == '1');
+        if (!G || (long long)B * G > cus || (ef && ef[0] == '0') || shared_device) { ge.ev_G = 0; ge.lds_ev = 0; }
         p->eval_fused_G = ge.ev_G; p->eval_fused = ge.ev_G ? 1 : 0;
+        if (const char *tm = std::getenv("FRX_EVAL_TIMEOUT_MS")) { const double v = std::atof(tm); if (v > 0.0) p->eval_fused_ticks = (unsigned long long)(v * 1e5); }
     }
     const size_t lds_cap = 160 * 1024;
     if (ge.knot_threads > 256 || ge.lds_kbwd > lds_cap) {
@@ -410,6 +443,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     const double ms_host_build = ms_since(t_create0);
     CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     CR((hipError_t)frx::launch_set_limits(p->geo));
+    if (p->geo.ev_G && frx::eval_cluster_blocks_per_cu(p->geo.lds_ev) < 1) { p->geo.ev_G = 0; p->geo.lds_ev = 0; p->eval_fused_G = 0; p->eval_fused = 0; }   // (the runtime's own occupancy answer: a CU must hold a workgroup of the cluster kernel)
     CR(p->d_cvoff.upload(cvoff)); CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
     CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse)); CR(p->d_piece_iv.upload(piece_iv));
     CR(p->d_coarse_iv.upload(coarse_iv)); CR(p->d_coarse_fbeg.upload(coarse_fbeg));
@@ -434,6 +468,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         const size_t n_ll = (size_t)78 * p->P, n_w64 = ((size_t)64 * B + 2) / 2;
         CR(p->d_ev_ll.alloc(n_ll + n_w64)); CR(hipMemset(p->d_ev_ll.p, 0, sizeof(unsigned long long) * (n_ll + n_w64)));   // (not on the handle's stream: the first evaluation may come on the caller's)
         p->d_ev_words = (unsigned *)(p->d_ev_ll.p + n_ll);
+        CR(p->h_ev_status.alloc(16));
     }
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
@@ -467,6 +502,43 @@ void frx_problem_destroy(frx_problem *p) {
     (void)hipSetDevice(p->device);
     if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
     delete p;
+}
+
+// The inner boundary on its own (include/frx.h): what cuda_computer::compute receives per call (cc.cuh:118-134) - idxHs, cfgHs, the ellipsoid, margin, limits
+// and weights - is everything the penalty integrator needs; the waypoint polytopes, end states and variables of the outer boundary do not exist on that side
+// of the reference (MINCO_S3 knows none of them).  The handle is an ordinary one whose candidates have one coarse piece per fine piece (gridRes = inf) and
+// two-vertex placeholder polytopes that no entry point of a penalty-only handle ever reads.
+int frx_penalty_problem_create(const frx_config *cfg, int device, int B, const int *piece_n, const int *piece_poly, const int *h_off, const double *h_rec,
+                               frx_problem **out) {
+    if (!cfg || !piece_n || !piece_poly || !h_off || !h_rec || !out || B <= 0) return fail(FRX_ERR_INVALID_ARG, "frx_penalty_problem_create: null argument or B <= 0");
+    *out = nullptr;
+    size_t P = 0;
+    for (int b = 0; b < B; b++) { if (piece_n[b] < 1) return fail(FRX_ERR_INVALID_ARG, "piece_n[b] < 1"); P += (size_t)piece_n[b]; }
+    std::vector<int> hoff2(P + 1, 0), voff(1, 0);
+    std::vector<double> hrec2, vrec, states((size_t)9 * B, 0.0);
+    for (size_t gp = 0; gp < P; gp++) {
+        const int m = piece_poly[gp];
+        if (m < 0) return fail(FRX_ERR_INVALID_ARG, "piece_poly: negative polytope index");
+        const int hb = h_off[m], K = h_off[m + 1] - hb;
+        if (K < 1) return fail(FRX_ERR_INVALID_ARG, "an H-polytope has no half-spaces");
+        hrec2.insert(hrec2.end(), h_rec + 6 * (size_t)hb, h_rec + 6 * (size_t)(hb + K));
+        hoff2[gp + 1] = hoff2[gp] + K;
+    }
+    for (int b = 0; b < B; b++)
+        for (int q = 0; q < 2 * piece_n[b] - 1; q++) {
+            const double v2[6] = {0.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+            vrec.insert(vrec.end(), v2, v2 + 6);
+            voff.push_back(voff.back() + 2);
+        }
+    frx_config c2 = *cfg;
+    c2.grid_res = INFINITY;                                                 // one fine piece per polytope entry: idxHs is already expanded
+    if (!(c2.rho > 0.0)) { c2.rho = 1.0; }                                  // (soft total time: the time layer is never evaluated on this handle, and it needs no TotalT)
+    frx_problem *p = nullptr;
+    const int rc = frx_problem_create(&c2, device, B, piece_n, states.data(), states.data(), hoff2.data(), hrec2.data(), voff.data(), vrec.data(), &p);
+    if (rc != FRX_OK) return rc;
+    p->penalty_only = true;
+    *out = p;
+    return FRX_OK;
 }
 
 int frx_problem_set_lbfgs_mode(frx_problem *p, int mode) {
@@ -651,8 +723,9 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
 // frx_debug_eval_fused: workgroups per candidate of the form frx_objective_eval[_device] takes right now, 0 = one launch per stage.
 int frx_debug_set_eval_fused(frx_problem *p, int enable) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (enable && p->eval_fused_G && (p->eval_fused_code || (p->h_ev_status.p && *(volatile unsigned *)p->h_ev_status.p))) (void)eval_cluster_status(p, nullptr);   // a retired form comes back clean
     p->eval_fused = (enable && p->eval_fused_G) ? 1 : 0;
-    p->eval_fused_ticks = enable == 2 ? 1ull : 200000000ull;              // 2 (tests): the value 1 tells the launcher to drop the members and bound the leader's waits at 50 us - the failure path
+    p->eval_fused_ticks = enable == 2 ? 1ull : 25000000ull;               // 2 (tests): the value 1 tells the launcher to drop the members and bound the leader's waits at 50 us - the failure path
     return FRX_OK;
 }
 int frx_debug_eval_fused(const frx_problem *p) { return (p && p->eval_fused) ? p->eval_fused_G : 0; }
@@ -692,18 +765,27 @@ int frx_problem_layout(const frx_problem *p, int *piece_off, int *coarse_off, in
 
 int frx_initial_guess(frx_problem *p, double *x0) {
     if (!p || !x0) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->penalty_only) return fail(FRX_ERR_INVALID_ARG, "this handle serves frx_penalty_eval[_device] only (frx_penalty_problem_create)");
     frx::initial_guess_batch(p->cfg, p->softT, p->cand, p->xoff.data(), x0);     // one flat task list over (candidate, waypoint)
     return FRX_OK;
 }
 
 int frx_objective_eval_device(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *hip_stream) {
     if (!p || !x_dev || !f_dev || !g_dev) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->penalty_only) return fail(FRX_ERR_INVALID_ARG, "this handle serves frx_penalty_eval[_device] only (frx_penalty_problem_create)");
     HIP_TRY((hipError_t)launch_eval(p, x_dev, f_dev, g_dev, hip_stream, true));
     return FRX_OK;
 }
 
+int frx_eval_status(frx_problem *p) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    return eval_cluster_status(p, nullptr);
+}
+
 int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g) {
     if (!p || !x || !f || !g) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->penalty_only) return fail(FRX_ERR_INVALID_ARG, "this handle serves frx_penalty_eval[_device] only (frx_penalty_problem_create)");
     HIP_TRY(hipSetDevice(p->device));
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
@@ -720,6 +802,7 @@ int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g) {
 // stream; frx_wait() completes it and fills f, g (which must stay valid until then).  One evaluation in flight per handle.
 int frx_objective_eval_async(frx_problem *p, const double *x, double *f, double *g) {
     if (!p || !x || !f || !g) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->penalty_only) return fail(FRX_ERR_INVALID_ARG, "this handle serves frx_penalty_eval[_device] only (frx_penalty_problem_create)");
     if (p->pending_f) return fail(FRX_ERR_INVALID_ARG, "an asynchronous evaluation is already in flight on this handle (call frx_wait)");
     HIP_TRY(hipSetDevice(p->device));
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
@@ -777,6 +860,7 @@ int frx_penalty_eval(frx_problem *p, const double *T, const double *C, double *c
 
 int frx_forward(frx_problem *p, const double *x, double *T, double *C) {
     if (!p || !x) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->penalty_only) return fail(FRX_ERR_INVALID_ARG, "this handle serves frx_penalty_eval[_device] only (frx_penalty_problem_create)");
     HIP_TRY(hipSetDevice(p->device));
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
@@ -1396,7 +1480,9 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     long rounds = 0;
     for (int k = 0; k < S; k++) rounds = std::max(rounds, slot_[k].ncmd);                 // commands of the busiest cluster (S < B: over all the candidates it took)
     p->stats[0] = ms_since(t0); p->stats[1] = p->stats[0] - t_host; p->stats[2] = t_host; p->stats[3] = (double)rounds;
-    HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
+    if (!take) HIP_TRY(hipMemcpy(x, p->d_x.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost));
+    else                                                                              //  a take-over's result: the stragglers' points only - everybody else's x is final already
+        for (int b : take->cand) HIP_TRY(hipMemcpy(x + p->xoff[b], p->d_x.p + p->xoff[b], sizeof(double) * (size_t)(p->xoff[b + 1] - p->xoff[b]), hipMemcpyDeviceToHost));
     if (rl.trace) {
         std::vector<unsigned long long> tr((size_t)G * trace_cap);
         HIP_TRY(hipMemcpy(tr.data(), d_trace.p, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
@@ -1417,8 +1503,10 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
         if (!p->d_stamps.p) { HIP_TRY(p->d_stamps.alloc(64)); HIP_TRY(hipMemset(p->d_stamps.p, 0, 64 * sizeof(long long))); }
         HIP_TRY(hipMemcpy(p->rprof.data() + (size_t)S * (G + 1) * 16, p->d_stamps.p + (rl.stamp_round > 0 ? 32 : 0), 32 * sizeof(long long), hipMemcpyDeviceToHost));   // the last evaluation's stamps, or those of evaluation FRX_RESIDENT_STAMP_ROUND
     }
-    for (int b = 0; b < B; b++)
+    for (int q = 0; q < Bsel; q++) {                                                  // (a take-over counts its own candidates, not the per-stage part's failures)
+        const int b = take ? take->cand[q] : q;
         if (status[b] < 0 && status[b] != frx::LBERR_MAXIMUMITERATION) p->resident_failed++;
+    }
     p->resident_used = G; p->resident_clusters = S;
     return FRX_OK;
 }
@@ -1495,6 +1583,7 @@ extern "C" {
 int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, double *C, double *T, double *jerk_cost,
                  double *objective, int *status, int *iters, int *evals) {
     if (!p || !params || !x || !status) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    if (p->penalty_only) return fail(FRX_ERR_INVALID_ARG, "this handle serves frx_penalty_eval[_device] only (frx_penalty_problem_create)");
     HIP_TRY(hipSetDevice(p->device));
     // FRX_LBFGS=host keeps every vector on the host (bit-identical to the reference solver given identical f, g);
     // the default keeps the vectors on the device and only the line-search decisions on the host.
@@ -1509,8 +1598,46 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
         p->resident_used = 0; p->resident_retried = 0;
         p->resident_failed = 0; p->resident_clusters = 0; for (auto &q : p->spec_counts) q = 0;      //  diagnostics of THIS plan, whichever path it takes
         const std::vector<double> x_start(x, x + p->NX);
+        // Candidates whose resident plan ended with LBFGSERR_INCREASEGRADIENT are planned again on the per-stage rounds (see below, where the resident plan returns).
+        // `scope` (optional): only these candidates are looked at - the stragglers of a take-over, whose dense state was rebuilt on the host by plain back-substitution
+        // over up to 128 pairs (the long-running, worst-conditioned candidates of a batch; without this their g.d >= 0 would be final on that path alone).
+        // The resident result of a candidate that is planned again is kept: when the per-stage path cannot run (rc2 > 0: its buffers do not fit) or fails
+        // on it as well, it keeps the resident verdict, point and objective instead of ending at its start point.
+        const char *rt_env = std::getenv("FRX_RESIDENT_RETRY");
+        const int retry_mode = rt_env ? (rt_env[0] == '0' ? 0 : rt_env[0] == 't' ? 2 : 1) : (p->resident_retry != 0 ? 1 : 2);   // 2 = targeted (default)
+        auto wants_retry = [&](int st) { return st < 0 && st != frx::LBERR_MAXIMUMITERATION && (retry_mode == 1 || (retry_mode == 2 && st == frx::LBERR_INCREASEGRADIENT)); };
+        auto retry_increase_gradient = [&](const std::vector<int> *scope) -> int {
+            std::vector<char> again(p->B, 0);
+            int n_again = 0;
+            if (scope) { for (int b : *scope) if (wants_retry(status[b])) { again[b] = 1; n_again++; } }
+            else for (int b = 0; b < p->B; b++) if (wants_retry(status[b])) { again[b] = 1; n_again++; }
+            if (n_again == 0) return 0;
+            const std::vector<double> x_res(x, x + p->NX);
+            std::vector<int> st_res(status, status + p->B), it_res, ev_res;
+            std::vector<double> obj_res;
+            if (iters) it_res.assign(iters, iters + p->B);
+            if (evals) ev_res.assign(evals, evals + p->B);
+            if (objective) obj_res.assign(objective, objective + p->B);
+            for (int b = 0; b < p->B; b++) if (again[b]) std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]);
+            const int used = p->resident_used, taken = p->taken_over;
+            const double t_res[4] = {p->stats[0], p->stats[1], p->stats[2], p->stats[3]};
+            const int rc2 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);
+            if (rc2 < 0) return rc2;
+            if (rc2 != 0) {
+                std::copy(x_res.begin(), x_res.end(), x);
+                std::copy(st_res.begin(), st_res.end(), status);
+                if (iters) std::copy(it_res.begin(), it_res.end(), iters);
+                if (evals) std::copy(ev_res.begin(), ev_res.end(), evals);
+                if (objective) std::copy(obj_res.begin(), obj_res.end(), objective);
+                n_again = 0;
+            }
+            p->resident_used = used; p->taken_over = taken; p->resident_retried += n_again;
+            if (rc2 == 0) p->stats[0] += t_res[0]; else p->stats[0] = t_res[0];
+            if (scope) { for (int q = 1; q < 4; q++) p->stats[q] = (rc2 == 0 ? p->stats[q] : 0.0) + t_res[q]; }
+            return 0;
+        };
         bool resident_gave_up = false;
-        if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0 && !std::getenv("FRX_TAKEOVER_AT")) {      // (FRX_TAKEOVER_AT, tests: per-stage rounds first, whatever the batch size)
+        if (!(rs_env && rs_env[0] == '0') && p->resident_mode != 0 && p->takeover_at <= 0) {      // (frx_debug_set_takeover_at, tests: per-stage rounds first, whatever the batch size)
             rc_dv = optimize_resident(p, *params, x, status, iters, evals, objective);
             resident_gave_up = rc_dv != 0 && p->resident_status != 0;
             if (rc_dv < 0) return rc_dv;
@@ -1526,39 +1653,8 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
                 // planned again on the per-stage rounds, whose direction kernel IS the two-loop recursion.  Line searches that give up
                 // (-1005, -1007: infeasible corridors, the CPU oracle's verdict as well) are final.  frx_debug_set_resident_retry(p, 1) /
                 // FRX_RESIDENT_RETRY=1 re-run every failed candidate (diagnostic), FRX_RESIDENT_RETRY=0 none.
-                const char *rt_env = std::getenv("FRX_RESIDENT_RETRY");
-                const int retry_mode = rt_env ? (rt_env[0] == '0' ? 0 : rt_env[0] == 't' ? 2 : 1) : (p->resident_retry != 0 ? 1 : 2);   // 2 = targeted (default)
-                auto wants_retry = [&](int st) { return st < 0 && st != frx::LBERR_MAXIMUMITERATION && (retry_mode == 1 || (retry_mode == 2 && st == frx::LBERR_INCREASEGRADIENT)); };
-                int n_retry = 0;
-                for (int b = 0; b < p->B; b++) n_retry += wants_retry(status[b]) ? 1 : 0;
-                const bool retry = n_retry > 0;
-                if (retry) {
-                    //  the resident kernel's result of the candidates that are planned again is kept: when the per-stage path cannot run
-                    // (rc2 > 0: its buffers do not fit), they keep the resident verdict, point and objective instead of ending at their start point
-                    std::vector<char> again(p->B, 0);
-                    int n_again = 0;
-                    const std::vector<double> x_res(x, x + p->NX);
-                    std::vector<int> st_res(status, status + p->B), it_res, ev_res;
-                    std::vector<double> obj_res;
-                    if (iters) it_res.assign(iters, iters + p->B);
-                    if (evals) ev_res.assign(evals, evals + p->B);
-                    if (objective) obj_res.assign(objective, objective + p->B);
-                    for (int b = 0; b < p->B; b++) if (wants_retry(status[b])) { again[b] = 1; n_again++; std::copy(x_start.begin() + p->xoff[b], x_start.begin() + p->xoff[b + 1], x + p->xoff[b]); }
-                    const int used = p->resident_used;
-                    const double t_res = p->stats[0];
-                    const int rc2 = optimize_device_vectors(p, *params, x, status, iters, evals, objective, &again);
-                    if (rc2 < 0) return rc2;
-                    if (rc2 != 0) {
-                        std::copy(x_res.begin(), x_res.end(), x);
-                        std::copy(st_res.begin(), st_res.end(), status);
-                        if (iters) std::copy(it_res.begin(), it_res.end(), iters);
-                        if (evals) std::copy(ev_res.begin(), ev_res.end(), evals);
-                        if (objective) std::copy(obj_res.begin(), obj_res.end(), objective);
-                        n_again = 0;
-                    }
-                    p->resident_used = used; p->resident_retried = n_again;
-                    if (rc2 == 0) p->stats[0] += t_res; else p->stats[0] = t_res;
-                }
+                const int rc_retry = retry_increase_gradient(nullptr);
+                if (rc_retry < 0) return rc_retry;
             }
         }
         if (rc_dv != 0) {
@@ -1576,7 +1672,7 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
                     const int G = std::max(3, 2 + std::max(1, (p->geo.maxXb + 2 * frx::ROUND_E - 1) / (2 * frx::ROUND_E)));
                     const int cap = 8 * (prop.multiProcessorCount / (8 * G));
                     if (fits && cap >= 1 && p->B > cap) take.capacity = cap;
-                    if (const char *at = std::getenv("FRX_TAKEOVER_AT")) { take.not_before = std::max(1L, std::atol(at)); if (fits && cap >= 1 && p->B <= cap) take.capacity = cap; }   // (tests: a small batch hands over after so many rounds)
+                    if (p->takeover_at > 0) { take.not_before = p->takeover_at; if (fits && cap >= 1 && p->B <= cap) take.capacity = cap; }   // (tests: a small batch hands over after so many rounds)
                 }
             }
             rc_dv = optimize_device_vectors(p, *params, x, status, iters, evals, objective, nullptr, take.capacity > 0 ? &take : nullptr);
@@ -1589,6 +1685,8 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
                 if (rc3 == 0) {
                     p->taken_over = (int)take.cand.size();
                     p->stats[0] += ms_ps; p->stats[1] += dev_ps; p->stats[2] += host_ps; p->stats[3] += (double)rounds_ps;
+                    const int rc_retry = retry_increase_gradient(&take.cand);             //  the stragglers get the resident path's targeted second chance
+                    if (rc_retry < 0) return rc_retry;
                 } else {
                     // the resident kernel could not take them (another process on the device, a geometry it does not cover): their vectors on the device are no
                     // longer the per-stage path's, so they are planned again from their start points, per stage - slower, never wrong
@@ -1623,16 +1721,22 @@ int frx_optimize(frx_problem *p, const frx_lbfgs_params *params, double *x, doub
     };
     auto eval_all = [&](int, const int *) -> int {
         hipError_t e;
-        if (zero_copy) {
-            if ((e = (hipError_t)launch_eval(p, p->h_x.p, p->h_f.p, p->h_g.p, p->stream, true)) != hipSuccess) goto bad;
-            if ((e = wait_stream()) != hipSuccess) goto bad;
-            return FRX_OK;
+        //  an expired wait of the one-launch form must not end the plan as a silent LBFGSERR_ROUNDING (NaN objectives): the evaluation is repeated
+        // once with the stage kernels, which the handle keeps from then on (eval_cluster_status retires the form)
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const bool fused = p->eval_fused != 0;
+            if (zero_copy) {
+                if ((e = (hipError_t)launch_eval(p, p->h_x.p, p->h_f.p, p->h_g.p, p->stream, true)) != hipSuccess) goto bad;
+                if ((e = wait_stream()) != hipSuccess) goto bad;
+            } else {
+                if ((e = hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream)) != hipSuccess) goto bad;
+                if ((e = (hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true)) != hipSuccess) goto bad;
+                if ((e = hipMemcpyAsync(p->h_f.p, p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;
+                if ((e = hipMemcpyAsync(p->h_g.p, p->d_g.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;
+                if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) goto bad;
+            }
+            if (!fused || eval_cluster_status(p, p->h_f.p) == FRX_OK) return FRX_OK;
         }
-        if ((e = hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream)) != hipSuccess) goto bad;
-        if ((e = (hipError_t)launch_eval(p, p->d_x.p, p->d_f.p, p->d_g.p, p->stream, true)) != hipSuccess) goto bad;
-        if ((e = hipMemcpyAsync(p->h_f.p, p->d_f.p, sizeof(double) * p->B, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;
-        if ((e = hipMemcpyAsync(p->h_g.p, p->d_g.p, sizeof(double) * p->NX, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) goto bad;
-        if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) goto bad;
         return FRX_OK;
     bad:
         hip_rc = fail(FRX_ERR_HIP, std::string("device evaluation failed: ") + hipGetErrorString(e));
@@ -1706,6 +1810,11 @@ int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
     return rows;
 }
 
+int frx_debug_set_takeover_at(frx_problem *p, long rounds) {
+    if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    p->takeover_at = rounds > 0 ? rounds : 0;
+    return FRX_OK;
+}
 int frx_debug_taken_over(const frx_problem *p, int *candidates) {
     if (!p || !candidates) return fail(FRX_ERR_INVALID_ARG, "null argument");
     *candidates = p->taken_over;
@@ -1717,11 +1826,10 @@ int frx_debug_compact_from_history(int m, int n, int hs, int bound, int newest, 
     return FRX_OK;
 }
 int frx_debug_host_cpu_share(int clusters, int extra_plans, double *budget, int *share, int *mailbox_threads) {
-    frx::concurrent_plans_hint(extra_plans);
+    // (computed from the arguments - the process-wide count of concurrent plans is not touched while real plans may be running)
     if (budget) *budget = frx::host_cpu_budget();
-    if (share) *share = frx::host_cpu_share();
-    if (mailbox_threads) *mailbox_threads = frx::mailbox_threads(std::max(1, clusters));
-    frx::concurrent_plans_hint(-extra_plans);
+    if (share) *share = frx::host_cpu_share_for(extra_plans);
+    if (mailbox_threads) *mailbox_threads = frx::mailbox_threads_for(std::max(1, clusters), extra_plans);
     return FRX_OK;
 }
 

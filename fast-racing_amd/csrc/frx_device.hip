@@ -52,10 +52,16 @@ int eval_cluster_geometry(LaunchGeom &g) {
     g.lds_ev = lds;
     return g.ev_G;
 }
+int eval_cluster_blocks_per_cu(size_t lds_bytes) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_eval_cluster, 256, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *f, double *grad,
-                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream) {
+                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream, unsigned *status_host) {
     if (!g.ev_G) return (int)hipErrorInvalidValue;
     EvalClusterArgs a;
+    a.status_host = status_host;
     a.dp = dp; a.x = x; a.T = T; a.C = C; a.f = f; a.g = grad; a.out20ll = ll; a.ctll = ll + (size_t)40 * dp.P; a.words = words; a.status = words + (size_t)64 * dp.B; a.timeout_ticks = timeout_ticks;
     a.G = g.ev_G; a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax; a.pen_lds = eval_pen_lds(g); a.maxN19 = g.maxN * 19;
     { const char *e = std::getenv("FRX_EVAL_FUSED_WT"); a.force_wt = (e && e[0] == '1') ? 1 : 0; }

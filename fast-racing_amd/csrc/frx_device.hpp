@@ -68,8 +68,11 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
 // One launch per evaluation (frx_eval_kernel.hpp): clusters of g.ev_G workgroups, one per candidate.  ll: [P][40 + 38] granule words (penalty partials, then (C, T)), words: [64 B + 1] (the last one: status), both
 // zeroed ONCE at allocation.  The caller has checked that dp.B * g.ev_G workgroups are resident at once (eval_cluster_geometry).
 int eval_cluster_geometry(LaunchGeom &g);                         // fills ev_G / lds_ev from the other fields; returns ev_G
+// status_host: one word of mapped host memory that receives the code of an expired wait (the device's own sticky word stays the authority inside the launch).
 int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *f, double *grad,
-                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream);
+                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream, unsigned *status_host = nullptr);
+// workgroups of k_eval_cluster a CU holds with lds_bytes of dynamic LDS (occupancy query of the runtime; 0 on error)
+int eval_cluster_blocks_per_cu(size_t lds_bytes);
 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;

@@ -36,6 +36,7 @@ struct EvalClusterArgs {
     unsigned *words;                         // [B][64]: cluster k's 256-byte block: word 0 = gate (tag << 4 | the leader's XCD + 1: (C, T) are out), words 8 .. 8 + G - 2 = tag << 4 | XCD + 1 of
                                              // members 1 .. G-1 (written at their entry), word 32 = tag of the last completed evaluation
     unsigned *status;                        // [1] sticky error word
+    unsigned *status_host;                   // optional, mapped host memory: the code of an expired wait, where the launcher sees it without a synchronisation (frx_api.cpp: launch_eval)
     rk_u64 timeout_ticks;
     int G, maxCN, maxXb, maxVb, nsteps, lpp, ppw, Kmax, pen_lds, maxN19;
     int test_drop_members;                   // tests (frx_debug_set_eval_fused(p, 2)): the members leave at once, as if they never got a CU - the leader's wait for the partials expires
@@ -73,6 +74,12 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
     const int p0 = a.dp.poff[c], N = a.dp.poff[c + 1] - p0;
     const int ntasks = (N + a.ppw - 1) / a.ppw;                     // wave-tasks of this candidate: ppw pieces each; members 1 .. G-1 hold 4 (G - 1) >= ntasks waves
     if (wg != 0 && ((wg - 1) * 4 >= ntasks || a.test_drop_members)) return;   // a member without a task
+    // A wait of an EARLIER launch expired and nobody has cleared the word yet (the capturable form has no host-synchronous point of its own: replays of a captured
+    // graph go on until the caller polls frx_eval_status): nothing is evaluated, nothing spins; the objective values say so.
+    if (__builtin_expect(__hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u, 0)) {
+        if (wg == 0 && threadIdx.x == 0) a.f[k] = __builtin_nan("");
+        return;
+    }
     unsigned tag = __hip_atomic_load(done, FRX_RLX_AGENT) + 1u;     // (stays in a vector register: nothing waits for the load until the tag is used)
     if (tag >= (1u << 28)) tag = 1u;
     // Where does this workgroup run?  Payload between two workgroups of one XCD can meet in that XCD's L2 (plain stores, L1-bypassing loads); across XCDs it has
@@ -105,8 +112,10 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
     __syncthreads();
     if (t == 0) {
         const double fv = ev[36 * 64 + 9 * 65 + 2 * 64 + a.maxCN];  // `red[0]` of backward_knot_wsp64: the objective value (a resident caller's f does not go to global memory there)
-        const bool bad = __hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u;
+        const unsigned code = __hip_atomic_load(a.status, FRX_RLX_AGENT);
+        const bool bad = code != 0u;
         a.f[c] = bad ? __builtin_nan("") : fv;
+        if (bad && a.status_host) __hip_atomic_store(a.status_host, code, FRX_RLX_SYS);
         __hip_atomic_store(done, tag, FRX_RLX_AGENT);
         if (a.dp.stamps && k == 0) a.dp.stamps[43] = (long long)wall_clock64();
     }

@@ -258,6 +258,11 @@ int frx_initial_guess(frx_problem *p, double *x0);
  */
 int frx_objective_eval(frx_problem *p, const double *x, double *f, double *g);
 int frx_objective_eval_device(frx_problem *p, const double *x_dev, double *f_dev, double *g_dev, void *hip_stream);
+/* The _device form has no host-synchronous point of its own.  After the caller has synchronised its stream: FRX_OK, or FRX_ERR_TIMEOUT when a wait inside a
+ * one-launch evaluation expired since the last check (objective values NaN from that evaluation on; the word is cleared and the handle continues with three
+ * launches per evaluation).  Direct calls notice by themselves - the first frx_objective_eval_device after the failure became visible takes the three launches -
+ * but a captured hipGraph replays what was captured: a caller that replays graphs polls this (or the NaN objective values). */
+int frx_eval_status(frx_problem *p);
 
 /*
  * Replaces cuda_computer::compute (cc.cuh:118-134, cc.cu:469-563) = MINCO_S3::addTimeIntPenalty
@@ -270,6 +275,19 @@ int frx_objective_eval_device(frx_problem *p, const double *x_dev, double *f_dev
  */
 int frx_penalty_eval(frx_problem *p, const double *T, const double *C, double *cost, double *gdT, double *gdC);
 int frx_penalty_eval_device(frx_problem *p, const double *T_dev, const double *C_dev, double *out_dev, void *hip_stream);
+/*
+ * The inner boundary ON ITS OWN: a handle built from exactly what cuda_computer::compute receives on every call (cc.cuh:118-134, call site GPU.hpp:219-227) -
+ * idxHs, cfgHs, ellipsoid, safeMargin, the limits, the weights ci, cons = cfg->qd_intervals for every piece (GPU.hpp:963-964) - for a caller that keeps the
+ * reference's MINCO_S3 / SE3GCOPTER on the host and swaps only `class cuda_computer` (oracle/frx_dropin/cuda_computer.cuh is that class; the reference's
+ * se3gcopter_gpu.hpp compiles against it unmodified, tests/test_reference_gpu_header.py).  Polytopes and parameters go up ONCE here instead of through mapped
+ * memory on every call (cc.cu:492-527).
+ *   piece_n[B]             pieces per candidate
+ *   piece_poly[sum pieces] index m of every piece's polytope in the CSR below (= idxHs)
+ *   h_off, h_rec           CSR of the H-polytopes, 6 doubles per half-space (outer normal, point) = one column of cfgHs[m]
+ * Such a handle serves frx_penalty_eval and frx_penalty_eval_device; every entry point that needs variables or waypoint polytopes returns FRX_ERR_INVALID_ARG.
+ */
+int frx_penalty_problem_create(const frx_config *cfg, int device, int B, const int *piece_n, const int *piece_poly,
+                               const int *h_off, const double *h_rec, frx_problem **out);
 
 /* x -> piece durations T (total fine pieces) and coefficients C (x 18): forwardT/forwardP + MINCO_S3::generate
  * (CPU.hpp:1258-1262, 425-505).  Either output may be NULL. */

@@ -89,6 +89,10 @@ int frx_debug_host_cpu_share(int clusters, int extra_plans, double *budget, int 
  * ([128][129]), Y^T Y ([128][128]), D = diag(s.y) ([128]) - from history rows S, Y [m][hs] (n significant doubles per row), `bound` valid pairs, the newest
  * in slot `newest` (frx_compact.hpp); exported so that a CPU test can check it against a dense inverse.  FRX_TAKEOVER=0 switches take-overs off. */
 int frx_debug_taken_over(const frx_problem *p, int *candidates);
+/* Tests: rounds > 0 makes every later plan on the handle start as per-stage rounds and hand ALL its running candidates to the resident kernel after that many
+ * rounds, whatever the batch size (a small batch would otherwise never take this path); 0 returns to the library's own rule.  (Until round 5 an environment
+ * variable read inside frx_optimize did this - and silently switched the resident path off in any process that inherited it.) */
+int frx_debug_set_takeover_at(frx_problem *p, long rounds);
 int frx_debug_compact_from_history(int m, int n, int hs, int bound, int newest, const double *S, const double *Y, double *rinv129, double *yy, double *vd);
 
 #ifdef __cplusplus

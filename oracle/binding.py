@@ -135,13 +135,56 @@ def ref_gcopter():
     return _ref_gcopter
 
 
-class Reference:
-    """The reference's SE3GCOPTER itself (compiled from /root/reference against the Eigen shim)."""
+_ref_gcopter_gpu = None
 
-    def __init__(self, cand, params: dict, override_vs: bool = True, **override):
-        R = ref_gcopter()
+
+class _Renamed:
+    """libref_gcopter_gpu.so exports refgpu_*; this view answers to the ref_* names Reference uses."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        return getattr(self._lib, "refgpu_" + name[4:] if name.startswith("ref_") else name)
+
+
+def ref_gcopter_gpu():
+    """oracle/_ref/libref_gcopter_gpu.so = the reference's GPU-flavoured header (se3gcopter_gpu.hpp) compiled UNMODIFIED where it lies, its `class cuda_computer`
+    supplied by oracle/frx_dropin/cuda_computer.cuh, i.e. by libfrx.so (needs a HIP device at run time: the library has no CPU fallback); None if absent."""
+    global _ref_gcopter_gpu
+    if _ref_gcopter_gpu is None:
+        path = os.path.join(HERE, "_ref", "libref_gcopter_gpu.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.refgpu_create.restype = C.c_void_p
+        R.refgpu_create.argtypes = [C.POINTER(Config), _dp, _dp, C.c_int, _ip, _dp, _ip, _dp, C.c_int]
+        R.refgpu_destroy.argtypes = [C.c_void_p]
+        R.refgpu_dims.argtypes = [C.c_void_p, _ip]
+        R.refgpu_vpoly.restype = C.c_int
+        R.refgpu_vpoly.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        R.refgpu_initial_guess.argtypes = [C.c_void_p, _dp]
+        R.refgpu_objective.restype = C.c_double
+        R.refgpu_objective.argtypes = [C.c_void_p, _dp, _dp]
+        R.refgpu_forward.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        R.refgpu_penalty.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        R.refgpu_optimize.restype = C.c_double
+        R.refgpu_optimize.argtypes = [C.c_void_p, C.c_double, _dp, _dp]
+        R.refgpu_compute_calls.restype = C.c_long
+        R.refgpu_compute_calls.argtypes = [C.c_void_p]
+        R.refgpu_kill_kernel.argtypes = [C.c_void_p]
+        _ref_gcopter_gpu = _Renamed(R)
+    return _ref_gcopter_gpu
+
+
+class Reference:
+    """The reference's SE3GCOPTER itself (compiled from /root/reference against the Eigen shim).  gpu_flavour: se3gcopter_gpu.hpp with the libfrx-backed
+    drop-in for its cuda_computer (ref_gcopter_gpu above) instead of se3gcopter_cpu.hpp."""
+
+    def __init__(self, cand, params: dict, override_vs: bool = True, gpu_flavour: bool = False, **override):
+        R = ref_gcopter_gpu() if gpu_flavour else ref_gcopter()
         if R is None:
-            raise RuntimeError("oracle/_ref/libref_gcopter.so not built")
+            raise RuntimeError("oracle/_ref/libref_gcopter%s.so not built" % ("_gpu" if gpu_flavour else ""))
         self.R = R
         self.cfg = Config.from_params(params, **override)
         h_off, h_rec, v_off, v_rec = cand.packed()
@@ -186,6 +229,14 @@ class Reference:
         Cf = np.zeros(18 * self.fine_n); T = np.zeros(self.fine_n)
         jc = self.R.ref_optimize(self.h, rel_cost_tol, Cf, T)
         return dict(jerk_cost=jc, C=Cf.reshape(-1, 3), T=T)
+
+    def compute_calls(self):
+        """GPU flavour: calls of cuda_computer::compute served so far."""
+        return int(self.R.refgpu_compute_calls(self.h))
+
+    def kill_kernel(self):
+        """GPU flavour: SE3GCOPTER::kill_kernel (se3gcopter_gpu.hpp:907-909)."""
+        self.R.refgpu_kill_kernel(self.h)
 
 
 def use_reference_lbfgs(enable: bool) -> bool:

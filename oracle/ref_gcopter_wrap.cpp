@@ -26,9 +26,18 @@ inline std::set<double> solvePolynomial(const Eigen::VectorXd &, double, double,
 inline int countRoots(const Eigen::VectorXd &, double, double) { return 0; }
 } // namespace RootFinder
 
+// REF_FLAVOUR_GPU (ref_gcopter_gpu_wrap.cpp): the reference's GPU header instead - se3gcopter_gpu.hpp, unmodified, whose `#include <cuda_computer.cuh>` finds
+// oracle/frx_dropin/cuda_computer.cuh (the drop-in backed by libfrx.so) - with the same exports under the names refgpu_*.
 #define private public          // test access to SE3GCOPTER / MINCO_S3 internals (objectiveFunc, cfgVs, jerkOpt)
+#ifdef REF_FLAVOUR_GPU
+#include "se3gcopter_gpu.hpp"
+#define REFN(name) refgpu_##name
+#else
 #include "se3gcopter_cpu.hpp"
+#define REFN(name) ref_##name
+#endif
 #undef private
+#define REF_EXPORT __attribute__((visibility("default")))
 
 namespace {
 struct Cfg {                     // same layout as orc::Config / frx_config
@@ -51,7 +60,7 @@ extern "C" {
 // (extractVs -> geoutils::enumerateVs).  With override_vs != 0 the caller's vertex lists replace them afterwards (same
 // [v0, v_r - v0] re-basing, se3gcopter_cpu.hpp:1049), so that the hot path can be compared on IDENTICAL inputs: the vertex
 // order of enumerateVs depends on an LP with a process-global random permutation.
-void *ref_create(const Cfg *cf, const double *ini, const double *fin, int coarseN, const int *hOff, const double *hRec,
+REF_EXPORT void *REFN(create)(const Cfg *cf, const double *ini, const double *fin, int coarseN, const int *hOff, const double *hRec,
                  const int *vOff, const double *vRec, int override_vs) {
     SE3GCOPTER *g = new SE3GCOPTER();
     std::vector<Eigen::MatrixXd> hPolys;
@@ -75,13 +84,13 @@ void *ref_create(const Cfg *cf, const double *ini, const double *fin, int coarse
     }
     return g;
 }
-void ref_destroy(void *h) { delete (SE3GCOPTER *)h; }
-void ref_dims(void *h, int *out4) {
+REF_EXPORT void REFN(destroy)(void *h) { delete (SE3GCOPTER *)h; }
+REF_EXPORT void REFN(dims)(void *h, int *out4) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     out4[0] = g->coarseN; out4[1] = g->fineN; out4[2] = g->dimFreeT; out4[3] = g->dimFreeP;
 }
 // number of vertices / the vertices (absolute coordinates) of the reference's own V-polytope m (for the f1 row)
-int ref_vpoly(void *h, int m, double *out, int cap) {
+REF_EXPORT int REFN(vpoly)(void *h, int m, double *out, int cap) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     const Eigen::MatrixXd &V = g->cfgVs[m];
     const int nv = V.cols();
@@ -90,7 +99,7 @@ int ref_vpoly(void *h, int m, double *out, int cap) {
     return nv;
 }
 // first half of optimize(): setInitial + backwardT + backwardP (se3gcopter_cpu.hpp:1237-1240)
-void ref_initial_guess(void *h, double *x) {
+REF_EXPORT void REFN(initial_guess)(void *h, double *x) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     Eigen::Map<Eigen::VectorXd> t(x, g->dimFreeT), p(x + g->dimFreeT, g->dimFreeP);
     g->setInitial(g->cfgVs, g->intervals, g->coarseT, g->innerP);
@@ -98,12 +107,12 @@ void ref_initial_guess(void *h, double *x) {
     SE3GCOPTER::backwardP(g->innerP, g->idxVs, g->cfgVs, p);
 }
 // the L-BFGS callback itself (se3gcopter_cpu.hpp:961-1000)
-double ref_objective(void *h, const double *x, double *grad) {
+REF_EXPORT double REFN(objective)(void *h, const double *x, double *grad) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     return SE3GCOPTER::objectiveFunc(g, x, grad, g->dimFreeT + g->dimFreeP);
 }
 // x -> fine T, coefficients (6N x 3 row-major): forwardT/P + generate (se3gcopter_cpu.hpp:1258-1262)
-void ref_forward(void *h, const double *x, double *T, double *C) {
+REF_EXPORT void REFN(forward)(void *h, const double *x, double *T, double *C) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     Eigen::Map<const Eigen::VectorXd> t(x, g->dimFreeT), p(x + g->dimFreeT, g->dimFreeP);
     SE3GCOPTER::forwardT(t, g->coarseT, g->softT, g->sumT, g->c2dfm);
@@ -115,7 +124,7 @@ void ref_forward(void *h, const double *x, double *T, double *C) {
     for (int r = 0; r < 6 * N; r++) for (int c = 0; c < 3; c++) C[r * 3 + c] = g->jerkOpt.b(r, c);
 }
 // addTimeIntPenalty alone on given (T, C) (se3gcopter_cpu.hpp:188-408), accumulating like cuda_computer::compute
-void ref_penalty(void *h, const double *T, const double *C, double *cost, double *gdT, double *gdC) {
+REF_EXPORT void REFN(penalty)(void *h, const double *T, const double *C, double *cost, double *gdT, double *gdC) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     const int N = g->fineN;
     g->jerkOpt.T1.resize(N);
@@ -133,7 +142,7 @@ void ref_penalty(void *h, const double *T, const double *C, double *cost, double
     for (int r = 0; r < 6 * N; r++) for (int c = 0; c < 3; c++) gdC[r * 3 + c] = gC(r, c);
 }
 // the whole SE3GCOPTER::optimize (se3gcopter_cpu.hpp:1230-1268); returns the jerk cost like the reference
-double ref_optimize(void *h, double relCostTol, double *C, double *T) {
+REF_EXPORT double REFN(optimize)(void *h, double relCostTol, double *C, double *T) {
     SE3GCOPTER *g = (SE3GCOPTER *)h;
     Trajectory traj;
     const double jc = g->optimize(traj, relCostTol);
@@ -142,4 +151,9 @@ double ref_optimize(void *h, double relCostTol, double *C, double *T) {
     for (int r = 0; r < 6 * N; r++) for (int c = 0; c < 3; c++) C[r * 3 + c] = g->jerkOpt.b(r, c);
     return jc;
 }
+#ifdef REF_FLAVOUR_GPU
+// calls of cuda_computer::compute served so far (the reference's GPU header makes TWO per evaluation, se3gcopter_gpu.hpp:219-227), and kill_kernel (:907-909)
+REF_EXPORT long refgpu_compute_calls(void *h) { return ((SE3GCOPTER *)h)->jerkOpt.paraller.n_compute; }
+REF_EXPORT void refgpu_kill_kernel(void *h) { ((SE3GCOPTER *)h)->kill_kernel(); }
+#endif
 }

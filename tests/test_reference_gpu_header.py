@@ -1,0 +1,91 @@
+"""the reference's OWN GPU-flavoured optimiser - se3gcopter_gpu.hpp, compiled unmodified where it lies (oracle/ref_gcopter_gpu_wrap.cpp)
+- runs on the MI355X through the drop-in for its `class cuda_computer` (oracle/frx_dropin/cuda_computer.cuh -> frx_penalty_problem_create / frx_penalty_eval):
+the inner boundary exercised from the reference's own call site (se3gcopter_gpu.hpp:219-227) instead of from ctypes.
+
+The GPU header calls compute() TWICE per evaluation (se3gcopter_gpu.hpp:219-227): with an accumulating compute() the penalty and its
+gradients are doubled.  That is asserted here, not hidden: the GPU flavour on the device equals the reference's CPU flavour (libref_gcopter.so) with the
+penalty taken twice, i.e. with PenaltyPVTB doubled.
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+
+def _need(ob, gpu):
+    if ob.ref_gcopter() is None or ob.ref_gcopter_gpu() is None:
+        pytest.skip("oracle/_ref/libref_gcopter[_gpu].so not built (needs /root/reference at build time)")
+    if gpu and not has_gpu():
+        pytest.skip("no HIP device")
+
+
+def test_gpu_flavour_library_loads_next_to_the_cpu_flavour(ob):
+    """Both flavours define SE3GCOPTER / MINCO_S3 with different layouts; hidden visibility keeps them apart in one process (CPU: load + symbols only)."""
+    _need(ob, gpu=False)
+    G = ob.ref_gcopter_gpu()
+    for name in ("ref_create", "ref_destroy", "ref_dims", "ref_initial_guess", "ref_objective", "ref_forward", "ref_penalty", "ref_optimize", "refgpu_compute_calls", "refgpu_kill_kernel"):
+        assert getattr(G, name) is not None
+
+
+def test_penalty_only_handle_rejects_the_outer_boundary(frx, sc):
+    """frx_penalty_problem_create: argument checks (no device needed for those)."""
+    import ctypes as C
+    L = frx.lib()
+    cfg = frx.FrxConfig.from_params(sc.ZHANGJIAJIE)
+    h = C.c_void_p()
+    one = np.array([1], dtype=np.int32); z = np.zeros(6); off = np.array([0, 1], dtype=np.int32)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    assert L.frx_penalty_problem_create(C.byref(cfg), 0, 0, ptr(one), ptr(one), ptr(off), ptr(z), C.byref(h)) == -1
+    bad = np.array([-1], dtype=np.int32)
+    assert L.frx_penalty_problem_create(C.byref(cfg), 0, 1, ptr(one), ptr(bad), ptr(off), ptr(z), C.byref(h)) == -1
+    assert b"polytope index" in L.frx_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,gates,kappa,obst", [(12, 3, 48, False), (16, 4, 16, True), (64, 16, 48, False)])
+def test_reference_gpu_header_runs_the_hip_integrator_through_its_own_call_site(frx, sc, ob, N, gates, kappa, obst):
+    _need(ob, gpu=True)
+    cand = sc.make_candidate(31 + N, N, gates, obstacles=obst)
+    cpu = ob.Reference(cand, sc.ZHANGJIAJIE, override_vs=True, qd_intervals=kappa)
+    dbl = ob.Reference(cand, sc.ZHANGJIAJIE, override_vs=True, qd_intervals=kappa, penalty_pvtb=tuple(2.0 * w for w in sc.ZHANGJIAJIE["penalty_pvtb"]))
+    gpu = ob.Reference(cand, sc.ZHANGJIAJIE, override_vs=True, gpu_flavour=True, qd_intervals=kappa)
+    assert (gpu.fine_n, gpu.dim_t, gpu.dim_p) == (cpu.fine_n, cpu.dim_t, cpu.dim_p)
+    x0 = cpu.initial_guess()
+    assert np.array_equal(gpu.initial_guess(), x0)                          # host code of the same header family
+    o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    xs = [x0, o.optimize(1e-6, max_iterations=15, x0=x0)["x"], o.optimize(1e-6, max_iterations=120, x0=x0)["x"]]
+    calls = gpu.compute_calls()
+    for x in xs:
+        # (1) the inner boundary alone, per call: MINCO_S3::addTimeIntPenalty of the GPU header = two compute() calls on the device = twice the CPU header's penalty
+        T, Cf = cpu.forward(x)
+        c1, t1, g1 = cpu.penalty(T, Cf)
+        c2, t2, g2 = gpu.penalty(T, Cf)
+        assert gpu.compute_calls() == calls + 2
+        calls += 2
+        assert abs(c2 - 2.0 * c1) <= 1e-9 * abs(2.0 * c1) + 1e-300
+        assert np.abs(t2 - 2.0 * t1).max() <= 1e-9 * max(np.abs(2.0 * t1).max(), 1e-300)
+        assert np.abs(g2 - 2.0 * g1).max() <= 1e-9 * max(np.abs(2.0 * g1).max(), 1e-300)
+        # (2) the reference's whole L-BFGS callback (objectiveFunc of se3gcopter_gpu.hpp, host code around the device call) against the CPU header with doubled weights
+        f_d, g_d = dbl.objective(x)
+        f_g, g_g = gpu.objective(x)
+        calls += 2
+        assert gpu.compute_calls() == calls
+        assert abs(f_g - f_d) <= 1e-9 * abs(f_d)
+        assert np.abs(g_g - g_d).max() <= 1e-9 * np.abs(g_d).max()
+        f_c, _ = cpu.objective(x)
+        if c1 > 1e-6 * abs(f_c):
+            assert abs(f_g - f_c) > 0.5 * c1                                # the doubled penalty is really there
+    # (3) SE3GCOPTER::optimize of the GPU header, start to end, on the device - thousands of compute() calls through the reference's own L-BFGS
+    if N <= 16:
+        r_g = gpu.optimize(sc.ZHANGJIAJIE["opt_rel_tol"])
+        r_d = dbl.optimize(sc.ZHANGJIAJIE["opt_rel_tol"])
+        assert np.isfinite(r_g["jerk_cost"]) and np.all(np.isfinite(r_g["C"])) and gpu.compute_calls() > calls + 100
+        # independent runs of the reference's stop rule: same plan to the optimiser's own sensitivity
+        assert abs(r_g["jerk_cost"] - r_d["jerk_cost"]) <= 2e-2 * abs(r_d["jerk_cost"]), (r_g["jerk_cost"], r_d["jerk_cost"])
+        assert abs(r_g["T"].sum() - r_d["T"].sum()) <= 2e-2 * r_d["T"].sum()
+    # (4) kill_kernel (se3gcopter_gpu.hpp:907-909) frees the device side; the next compute() brings it back
+    gpu.kill_kernel()
+    T, Cf = cpu.forward(xs[1])
+    c1, _, _ = cpu.penalty(T, Cf)
+    c2, _, _ = gpu.penalty(T, Cf)
+    assert abs(c2 - 2.0 * c1) <= 1e-9 * abs(2.0 * c1) + 1e-300

@@ -60,12 +60,14 @@ def test_dense_state_rebuilt_from_a_history(frx, bound, newest):
     assert np.abs(d - d_ref).max() <= 1e-9 * np.abs(d_ref).max()
 
 
-def _plan(prob, tol, env, **kw):
+def _plan(prob, tol, env, takeover_at=0, **kw):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env); os.environ["FRX_TRACE"] = "1"
+    prob.set_takeover_at(takeover_at)                       # frx_debug_set_takeover_at: per-stage rounds first, hand-over after so many (0: the library's own rule)
     try:
         r = prob.optimize(tol, **kw)
     finally:
+        prob.set_takeover_at(0)
         os.environ.pop("FRX_TRACE", None)
         for k, v in saved.items():
             if v is None: os.environ.pop(k, None)
@@ -77,7 +79,7 @@ def _plan(prob, tol, env, **kw):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,at", [(1, 150), (3, 40), (20, 400)])
 def test_a_plan_that_changes_paths_midway_follows_the_per_stage_plan(frx, sc, B, at):
-    """FRX_TAKEOVER_AT=k hands a small batch over after k per-stage rounds (k = 400: the history has wrapped around three times; 150: once; 40: it is not full).
+    """frx_debug_set_takeover_at(p, k) hands a small batch over after k per-stage rounds (k = 400: the history has wrapped around three times; 150: once; 40: it is not full).
     From there the resident kernel runs on the SAME pairs: command by command the scalars that cross the mailbox - step, f, x.x, g.g and the new direction's
     slope g_p.d - equal the pure per-stage plan's to rounding for the next commands (they drift apart later like any two runs of the reference's stop rule),
     and the complete plans end with the same verdicts."""
@@ -86,7 +88,7 @@ def test_a_plan_that_changes_paths_midway_follows_the_per_stage_plan(frx, sc, B,
     x0 = prob.initial_guess()
     tol = sc.ZHANGJIAJIE["opt_rel_tol"]
     off = {"FRX_RESIDENT": "0"}
-    a = _plan(prob, tol, {"FRX_TAKEOVER_AT": str(at)}, x0=x0, max_iterations=at + 80)
+    a = _plan(prob, tol, {}, takeover_at=at, x0=x0, max_iterations=at + 80)
     b = _plan(prob, tol, off, x0=x0, max_iterations=at + 80)
     assert b["resident"] == 0 and b["taken_over"] == 0
     assert a["taken_over"] == B and a["resident"] > 0 and a["device_status"] == 0, (a["taken_over"], a["resident"], a["device_status"])
@@ -111,7 +113,7 @@ def test_a_plan_that_changes_paths_midway_follows_the_per_stage_plan(frx, sc, B,
     # (at the start of a plan it does not: tests/test_gpu_resident.py compares 30 commands at 1e-8).
     assert max(series[:4]) < 1e-9, series[:8]
     assert worst_after < 1e-2, worst_after
-    full_a = _plan(prob, tol, {"FRX_TAKEOVER_AT": str(at)}, x0=x0)
+    full_a = _plan(prob, tol, {}, takeover_at=at, x0=x0)
     full_b = _plan(prob, tol, off, x0=x0)
     assert full_a["taken_over"] == B and np.array_equal(full_a["status"] >= 0, full_b["status"] >= 0) and np.all(full_a["status"] >= 0)
     rel = np.abs(full_a["objective"] - full_b["objective"]) / np.abs(full_b["objective"])
