@@ -111,6 +111,62 @@ def cpu_baseline(cands, params, kappa, x_state, x_off, budget_s=12.0):
     }
 
 
+def boundary_calls(frx, sc, prob, cands, params, kappa, x_state, device, with_cpu, reps=200):
+    """What the two BOUNDARY calls cost with host buffers, PCIe included: a blocking frx_objective_eval (x up, the evaluation, f and the
+    gradient down, one synchronisation) and a blocking frx_penalty_eval (T and C up, the integrator, 20 partials per piece down, the host-side accumulation of
+    cuda_computer.cu:551-558) - the call the reference's cuda_computer::compute is (cuda_computer.cu:469-563) - at this run's workload and at BASELINE configs[0]
+    (ONE candidate x 64 pieces x the stock kappa = 48: the only shape the reference ever calls compute with, se3gcopter_gpu.hpp:219-227), each next to the CPU oracle's
+    time for the same call on one thread (the oracle is the checker being timed as the baseline here, never the product).  `value` stays the HBM-resident step."""
+    def time_calls(p, x):
+        T, Cf = p.forward(x)
+        for _ in range(10): p.objective(x); p.penalty(T, Cf)
+        t0 = time.perf_counter()
+        for _ in range(reps): p.objective(x)
+        t_obj = (time.perf_counter() - t0) / reps * 1e6
+        t0 = time.perf_counter()
+        for _ in range(reps): p.penalty(T, Cf)
+        t_pen = (time.perf_counter() - t0) / reps * 1e6
+        return t_obj, t_pen, T, Cf
+
+    def cpu_calls(cs, kap, x, x_off, T, Cf, p_off):
+        from oracle import binding as ob
+        o = ob.Oracle(cs[0], params, qd_intervals=kap)
+        xs = x[x_off[0]:x_off[1]]; Ts = T[p_off[0]:p_off[1]]; Cs = Cf[6 * p_off[0]:6 * p_off[1]]
+        n = 20
+        for _ in range(2): o.objective(xs); o.penalty(Ts, Cs)
+        t0 = time.perf_counter()
+        for _ in range(n): o.objective(xs)
+        t_obj = (time.perf_counter() - t0) / n * 1e6
+        t0 = time.perf_counter()
+        for _ in range(n): o.penalty(Ts, Cs)
+        t_pen = (time.perf_counter() - t0) / n * 1e6
+        return t_obj, t_pen
+
+    out = {"what": "host-buffer (PCIe-inclusive) cost of one blocking boundary call, us; python's ctypes call overhead (~2 us) included", "reps": reps}
+    t_obj, t_pen, T, Cf = time_calls(prob, x_state)
+    row = {"candidates": prob.B, "objective_eval_blocking": t_obj, "penalty_eval_blocking": t_pen,
+           "objective_eval_blocking_samples_per_s": prob.samples() / (t_obj * 1e-6), "penalty_eval_blocking_samples_per_s": prob.samples() / (t_pen * 1e-6)}
+    if with_cpu:
+        c_obj, c_pen = cpu_calls(cands, kappa, x_state, prob.x_off, T, Cf, prob.piece_off)
+        row.update({"cpu_oracle_objective_us_per_candidate_1thread": c_obj, "cpu_oracle_penalty_us_per_candidate_1thread": c_pen,
+                    "cpu_oracle_objective_us_whole_batch_1thread": c_obj * prob.B, "cpu_oracle_penalty_us_whole_batch_1thread": c_pen * prob.B})
+    out["workload"] = row
+    B0, N0, g0, k0 = sc.CONFIGS["plumbing"]
+    c0 = [sc.make_candidate(0, N0, g0, perturb_id=0)]
+    p0 = frx.Problem(c0, params, device=device, qd_intervals=k0)
+    x0 = p0.optimize(params["opt_rel_tol"], max_iterations=60)["x"]
+    t_obj, t_pen, T, Cf = time_calls(p0, x0)
+    row = {"config": "BASELINE configs[0]: 1 candidate x %d pieces x kappa %d" % (N0, k0), "objective_eval_blocking": t_obj, "penalty_eval_blocking": t_pen,
+           "penalty_eval_blocking_samples_per_s": p0.samples() / (t_pen * 1e-6),
+           "reference_call": "cuda_computer::compute (cuda_computer.cu:469-563): re-packs ~257 KB through mapped memory, flags its persistent kernel, spins on `done`"}
+    if with_cpu:
+        c_obj, c_pen = cpu_calls(c0, k0, x0, p0.x_off, T, Cf, p0.piece_off)
+        row.update({"cpu_oracle_objective_us_1thread": c_obj, "cpu_oracle_penalty_us_1thread": c_pen})
+    p0.close()
+    out["configs0_plumbing"] = row
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,6 +522,16 @@ def main():
             fl_big = fp64_dyn["large_batch"]["flops_per_sample"] if fp64_dyn else fp64["flops_per_sample"]
             large["fp64_flops_per_sample"] = fl_big
             large["fp64_frac"] = fl_big * big.samples() / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS
+        if valu and valu.get("valu_insts_per_wave") and valu.get("large_batch_waves_per_simd"):
+            # What THIS instruction count can reach: every SIMD issues one VALU instruction of a wave64 per 4 cycles at best, so a launch of
+            # W waves per SIMD with V VALU instructions each lasts at least W V 4 cycles; the HBM fraction at 100 % VALU issue is the kernel's own ceiling
+            n_waves = -(-big.P // max(1, (64 * 4) // (kappa + 1))) * 4              # four-wave workgroups of floor(256 / (kappa + 1)) pieces (LaunchGeom::ppg)
+            per_simd = n_waves / (256.0 * 4.0)
+            t_floor_us = per_simd * valu["valu_insts_per_wave"] * 4.0 / 2400.0      # 2.4 GHz
+            large["valu_ceiling_us"] = t_floor_us
+            large["valu_ceiling_frac"] = big.algorithmic_bytes() / (t_floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            large["valu_ceiling_note"] = ("bytes / (waves per SIMD x VALU instructions per wave x 4 cycles at 2.4 GHz) / HBM peak: the fraction this kernel would reach at 100 %% VALU issue - "
+                                          "its own ceiling; %d waves, %.1f per SIMD, %.0f VALU instructions per wave (counter pass %s)" % (n_waves, per_simd, valu["valu_insts_per_wave"], valu.get("source")))
         big.close(); del Tb, Cb, ob_
 
     # the HBM-bound kernel of the path: the L-BFGS two-loop recursion (k_lbfgs_pre) streams every candidate's (s, y) history twice
@@ -555,6 +621,25 @@ def main():
                              # scenario is the claim, the L-BFGS code of a plan that stalls on an infeasible corridor may differ
                              "work_queue_status_mismatches": int((np.asarray(r_q["status"]) != np.asarray(r["status"])).sum()),
                              "work_queue_verdict_mismatches": int(((np.asarray(r_q["status"]) >= 0) != (np.asarray(r["status"]) >= 0)).sum())})
+                # every scenario on which the two device paths disagree about success, with the CPU's verdict beside it: the four CPU variants of
+                # tests/golden/mc512_cpu_verdicts.npz (ids 0 .. 511 = rank 0's share of configs[4]; data, not the oracle - the oracle is not called here)
+                fix_path = os.path.join(ROOT, "tests", "golden", "mc512_cpu_verdicts.npz")
+                fix = np.load(fix_path) if (args.config == "montecarlo4096" and os.path.exists(fix_path)) else None
+                rows = []
+                for b in range(B):
+                    if (r_q["status"][b] >= 0) == (r["status"][b] >= 0): continue
+                    row = {"scenario": rank * B + b, "default_path_status": int(r["status"][b]), "work_queue_status": int(r_q["status"][b]),
+                           "default_path_objective": float(r["objective"][b]), "work_queue_objective": float(r_q["objective"][b])}
+                    if fix is not None and rank * B + b < len(fix["status"]):
+                        cs = [int(v) for v in fix["status"][rank * B + b]]
+                        row.update({"cpu_status_four_variants": cs, "every_cpu_variant_fails_too": bool(max(cs) < 0)})
+                    rows.append(row)
+                plan["work_queue_verdict_mismatch_list"] = rows
+                if fix is not None and rank == 0:
+                    cs = fix["status"][:B]
+                    inside = lambda st: int(sum(1 for b in range(B) if int(st[b]) in [int(v) for v in cs[b]] or cs[b].max() < 0))
+                    plan.update({"plan_verdicts_inside_the_cpu_variants_set": inside(r["status"]), "work_queue_verdicts_inside_the_cpu_variants_set": inside(r_q["status"]),
+                                 "cpu_verdict_source": "tests/golden/mc512_cpu_verdicts.npz: four CPU-oracle variants per scenario (tests/golden/make_mc_verdicts.py); a scenario every CPU variant fails on counts as inside whatever the device says"})
         if r_lib is not None:
             plan.update({"plan_front_end": "frx_multi_* (one process, one host thread + handle per device)", "plan_ms_whole_job": r_lib["ms_wall"],
                          "plan_shards": int(r_lib["n_shards"]), "plan_winner_exchange": r_lib["exchange"],
@@ -569,6 +654,12 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cands, params, kappa, x_state, prob.x_off)
+    boundary = None
+    if rank == 0:
+        try:
+            boundary = boundary_calls(frx, sc, prob, cands, params, kappa, x_state, local_rank, with_cpu=not args.no_cpu_baseline)
+        except Exception as e:                                              # a failing side leg must not cost the bench line
+            boundary = {"error": repr(e)}
 
     if rank == 0 and cpu is not None and plan:
         # The 1e-6 contract on optimised coefficients, where the number is: the device's plans against the CPU oracle's plans of
@@ -677,6 +768,7 @@ def main():
                                               "bound": "latency: one workgroup per candidate, a dependent FP64 chain (DESIGN.md 3.1, 3.3)"} for k in ("forward", "adjoint")},
                          "round": round_obj, "hbm_bound_kernel": hbm_kernel, "states": states},
             "cpu_baseline": cpu,
+            "boundary_call_us": boundary,
         }
         out.update(plan)
         print(json.dumps(out), flush=True)

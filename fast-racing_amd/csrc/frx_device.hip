@@ -1,4 +1,6 @@
-// hipcc translation unit: the gfx950 kernels and their launchers.
+// hipcc translation unit: the gfx950 stage kernels, the L-BFGS vector kernels, the corridor kernel and their launchers.
+// (The resident round kernel and the one-launch evaluation have translation units of their own - frx_device_round.hip, frx_device_eval.hip - so that the three
+// compile side by side: k_round's six instantiations alone take longer than everything else together.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -7,8 +9,6 @@
 
 #include "frx_kernels.hpp"
 #include "frx_lbfgs_kernels.hpp"
-#include "frx_round_kernel.hpp"
-#include "frx_eval_kernel.hpp"
 #include "frx_corridor_kernels.hpp"
 
 namespace frx {
@@ -23,7 +23,7 @@ static int raise_lds_limit(const void *fn, size_t bytes, size_t &held) {
 }
 int launch_set_limits(const LaunchGeom &g) {
     static std::mutex mu;
-    static size_t held_all[64][10] = {};                             // per device: a function's attributes belong to the device that is current
+    static size_t held_all[64][13] = {};                             // per device: a function's attributes belong to the device that is current
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
@@ -33,42 +33,17 @@ int launch_set_limits(const LaunchGeom &g) {
     if ((e = raise_lds_limit((const void *)k_backward, g.lds_bwd, held[1]))) return e;
     if ((e = raise_lds_limit((const void *)k_penalty, g.lds_pen, held[2]))) return e;
     if ((e = raise_lds_limit((const void *)k_penalty_lat, g.lds_pen, held[3]))) return e;
-    if (g.lds_pen2 && (e = raise_lds_limit((const void *)k_penalty_lat2, g.lds_pen2, held[4]))) return e;
+    if (g.lds_pen2) {                                                  // the instantiation launch_penalty takes for this geometry
+        const void *fn = g.lpp == 17 ? (const void *)k_penalty_lat2<17> : g.lpp == 49 ? (const void *)k_penalty_lat2<49> : (const void *)k_penalty_lat2<0>;
+        if ((e = raise_lds_limit(fn, g.lds_pen2, held[g.lpp == 17 ? 4 : g.lpp == 49 ? 10 : 11]))) return e;
+        if ((e = raise_lds_limit((const void *)k_penalty_lat2_r5, g.lds_pen2, held[12]))) return e;
+    }
     if ((e = raise_lds_limit((const void *)k_forward_knot, g.lds_kfwd, held[5]))) return e;
     if ((e = raise_lds_limit((const void *)k_backward_knot, g.lds_kbwd, held[6]))) return e;
     if ((e = raise_lds_limit((const void *)k_forward_knot64, g.lds_kfwd, held[7]))) return e;
     if ((e = raise_lds_limit((const void *)k_backward_knot64, g.lds_kbwd, held[8]))) return e;
-    if (g.ev_G && (e = raise_lds_limit((const void *)k_eval_cluster, g.lds_ev, held[9]))) return e;
+    if (g.ev_G && (e = eval_cluster_raise_limit(g.lds_ev))) return e;                   // (frx_device_eval.hip: the kernel lives in that translation unit)
     return 0;
-}
-static int eval_pen_lds(const LaunchGeom &g) { return g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21; }   // doubles per wave (penalty_body with a 64-lane group)
-int eval_cluster_geometry(LaunchGeom &g) {
-    g.ev_G = 0; g.lds_ev = 0;
-    if (g.solver != SOLVER_KNOT_PCR || g.knot_threads != 64 || g.ppw < 1) return 0;
-    const int ntasks = (g.maxN + g.ppw - 1) / g.ppw;
-    const size_t lds = sizeof(double) * (size_t)eval_cluster_lds(g.maxN * 19, g.maxXb, g.maxVb, g.maxCN, g.pcr_steps, eval_pen_lds(g)).total;
-    if (lds > (size_t)160 * 1024) return 0;
-    g.ev_G = 1 + (ntasks + 3) / 4;                                   // the members take every wave-task of the largest candidate in one pass
-    g.lds_ev = lds;
-    return g.ev_G;
-}
-int eval_cluster_blocks_per_cu(size_t lds_bytes) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_eval_cluster, 256, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return n;
-}
-int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *f, double *grad,
-                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream, unsigned *status_host) {
-    if (!g.ev_G) return (int)hipErrorInvalidValue;
-    EvalClusterArgs a;
-    a.status_host = status_host;
-    a.dp = dp; a.x = x; a.T = T; a.C = C; a.f = f; a.g = grad; a.out20ll = ll; a.ctll = ll + (size_t)40 * dp.P; a.words = words; a.status = words + (size_t)64 * dp.B; a.timeout_ticks = timeout_ticks;
-    a.G = g.ev_G; a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax; a.pen_lds = eval_pen_lds(g); a.maxN19 = g.maxN * 19;
-    { const char *e = std::getenv("FRX_EVAL_FUSED_WT"); a.force_wt = (e && e[0] == '1') ? 1 : 0; }
-    a.test_drop_members = timeout_ticks == 1ull ? 1 : 0;               // (test mode, frx_debug_set_eval_fused(p, 2): members that never arrive and a 50 us bound)
-    if (a.test_drop_members) a.timeout_ticks = 5000ull;
-    hipLaunchKernelGGL(k_eval_cluster, dim3(8 * g.ev_G * ((dp.B + 7) / 8)), dim3(256), g.lds_ev, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
 }
 int launch_forward(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *band, void *stream) {
     if (g.solver == SOLVER_KNOT_PCR)
@@ -86,7 +61,12 @@ int launch_penalty(const DevProblem &dp, const LaunchGeom &g, const double *T, c
     const int nwg = (dp.P + g.ppg - 1) / g.ppg;
     const char *tp_env = std::getenv("FRX_PENALTY_TWOPHASE");           // (read per launch: the test toggles it inside one process)
     const bool two_phase = !(tp_env && tp_env[0] == '0');
-    if (lat && two_phase && g.lds_pen2) hipLaunchKernelGGL(k_penalty_lat2, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen2, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+    if (lat && g.lds_pen2 && tp_env && tp_env[0] == '5') hipLaunchKernelGGL(k_penalty_lat2_r5, dim3(nwg), dim3(256), g.lds_pen2, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);   // (A/B: the round-5 form)
+    else if (lat && two_phase && g.lds_pen2) {                         // (pen_w == 4: 256 threads; the two boundary resolutions kappa = 16 / 48 have instantiations of their own)
+        if (g.lpp == 17) hipLaunchKernelGGL(k_penalty_lat2<17>, dim3(nwg), dim3(256), g.lds_pen2, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+        else if (g.lpp == 49) hipLaunchKernelGGL(k_penalty_lat2<49>, dim3(nwg), dim3(256), g.lds_pen2, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+        else hipLaunchKernelGGL(k_penalty_lat2<0>, dim3(nwg), dim3(256), g.lds_pen2, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
+    }
     else if (lat) hipLaunchKernelGGL(k_penalty_lat, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
     else hipLaunchKernelGGL(k_penalty, dim3(nwg), dim3(64 * g.pen_w), g.lds_pen, (hipStream_t)stream, dp, T, C, out20, g.lpp, g.ppg, g.Kmax);
     return (int)hipGetLastError();
@@ -133,72 +113,6 @@ int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *strea
 int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream) {
     hipLaunchKernelGGL(k_lbfgs_post, dim3(dv.B), dim3(64), 0, (hipStream_t)stream, to_buffers(dv), f, (const DvCommand *)cmd, (DvResult *)res);
     return (int)hipGetLastError();
-}
-
-// leader's resident LDS operands: (C, T) copy, x, waypoint polytopes, direction, reduction multipliers (ResidentOps), then gradient,
-// previous point and previous gradient (rk_leader_loop)
-static int round_ct_doubles(const LaunchGeom &g) {
-    const int xpad = (g.maxXb + 1) & ~1, vpad = (g.maxVb + g.knot_threads + 1) & ~1, pw = (g.pcr_steps * 8 + 5) * g.knot_threads;
-    return ((g.maxN * 19 + 1) & ~1) + 5 * xpad + vpad + ((pw + 1) & ~1) + 4 * g.knot_threads;
-}
-static int round_eval_doubles(const LaunchGeom &g) {
-    const size_t pen = (size_t)g.ppw * 19 + (size_t)g.ppw * (g.Kmax + 1) * 4 + 64 * 21;              // doubles per wave (LaunchGeom::lds_pen)
-    size_t e = std::max(g.lds_kfwd, g.lds_kbwd) / sizeof(double) + 2;
-    // <= 64 pieces: the evaluation bodies find x, polytopes, direction and multipliers in the resident operands, so their scratch ends
-    // behind the knot arrays (rows | knot arrays | Tf, gT | gCo | cross-wave partials)
-    if (g.knot_threads == 64) e = (size_t)36 * 64 + 9 * 65 + 2 * 64 + g.maxCN + 16;
-    e = std::max(e, 4 * pen + 8);
-    return (int)((e + 1) & ~(size_t)1) + round_ct_doubles(g);
-}
-size_t round_lds_bytes(const LaunchGeom &g, int m, int E) {
-    if ((E != ROUND_E && E != ROUND_E_SMALL) || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
-    return sizeof(double) * (size_t)round_lds(m, 2 * E, round_eval_doubles(g)).total;
-}
-static bool n64_class(const LaunchGeom &g) { static const bool generic = [] { const char *e = std::getenv("FRX_RESIDENT_NR"); return e && e[0] == '0'; }(); return g.knot_threads == 64 && !generic; }   // FRX_RESIDENT_NR=0: the generic instantiation (A/B)
-int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream) {
-    if (r.E != ROUND_E && r.E != ROUND_E_SMALL) return (int)hipErrorInvalidValue;
-    RoundArgs a;
-    a.dp = dp;
-    a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nrow = g.knot_threads; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppw = g.ppw; a.Kmax = g.Kmax;
-    a.pen_lds = g.ppw * 19 + g.ppw * (g.Kmax + 1) * 4 + 64 * 21;
-    a.x = r.x; a.g = r.g; a.xp = r.xp; a.gp = r.gp; a.d = r.d; a.f = r.f; a.T = r.T; a.C = r.C; a.out20 = r.out20; a.pcrw = g.pcrw;
-    a.out20ll = g.knot_threads == 64 ? r.out20ll : nullptr;                                                      // (only the <= 64-piece adjoint polls granules)
-    a.pubsyg = r.pubsyg; a.part = r.part; a.upub = r.upub; a.dpub = r.dpub; a.dbg = r.dbg; a.dbg_cap = r.dbg_cap; a.dbg_cands = r.dbg_cands;
-    a.phase = r.words; a.cntA = r.words + 32; a.uflag = r.words + 64; a.cntL = r.words + 96;                     // one 512-byte block per candidate, one 128-byte line per word
-    if (r.S < 1 || r.S > r.B) return (int)hipErrorInvalidValue;
-    a.census = r.words + (size_t)RK_WORDS_PER_CAND * r.S; a.status = a.census + 1; a.xcc = a.census + 2; a.spec = a.xcc + (size_t)r.S * r.G;
-    a.h_cmd = (RoundCmd *)r.h_cmd; a.h_res = (RoundRes *)r.h_res;
-    a.timeout_ticks = r.timeout_ticks;
-    a.census_ticks = std::min<unsigned long long>(r.timeout_ticks, 25000000ull);           // 250 ms
-    a.ls_ftol = r.ls_ftol; a.ls_gtol = r.ls_gtol; a.ls_min_step = r.ls_min_step; a.ls_max_step = r.ls_max_step; a.ls_xtol = r.ls_xtol; a.ls_max_linesearch = r.ls_max_linesearch; a.speculate = r.speculate;
-    { static const int ps = [] { const char *e = std::getenv("FRX_RESIDENT_POLL"); return e ? std::atoi(e) : 0; }(); a.poll_sleep = ps < 0 ? 0 : ps > 4 ? 4 : ps; }
-    a.cmd_stride = r.cmd_stride; a.stamp_round = r.stamp_round; a.fast_control = r.fast_control;
-    a.B = r.B; a.S = r.S; a.G = r.G; a.m = r.m; a.NXP = r.NXP; a.eval_doubles = round_eval_doubles(g); a.ct_doubles = round_ct_doubles(g); a.maxN19 = g.maxN * 19;
-    const size_t lds = round_lds_bytes(g, r.m, r.E);
-    a.prof = (rk_u64 *)r.prof;
-    a.trace = r.prof ? (rk_u64 *)r.trace : nullptr; a.trace_cap = r.trace_cap; a.trace_lo = r.trace_lo; a.trace_hi = r.trace_hi;
-    // Instantiations: history elements per thread (56: six history workgroups at the headline size; 28: twelve, for batches that leave the chip room -
-    // no history register in an AGPR, both history loops half as long), with / without the profile, for <= 64 pieces per candidate (the
-    // class-specific bodies only) or any geometry.
-    const bool n64 = n64_class(g);
-    const dim3 grid(8 * r.G * ((r.S + 7) / 8)), block(256);
-    auto go = [&](auto kernel) -> int {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, a);
-        return (int)hipGetLastError();
-    };
-    a.rs.cand = r.rs_cand; a.rs.f_last = r.rs_f; a.rs.S = r.rs_S; a.rs.Y = r.rs_Y; a.rs.hs = r.rs_hs; a.rs.newest = r.rs_newest; a.rs.bound = r.rs_bound; a.rs.rinv = r.rs_rinv; a.rs.yy = r.rs_yy; a.rs.vd = r.rs_vd;
-    if (r.rs_cand) {                                                   // take-over instantiation: <= 64 pieces, no profile
-        if (!n64 || r.prof) return (int)hipErrorInvalidValue;
-        return r.E == ROUND_E ? go(k_round<ROUND_E, false, 64, true>) : go(k_round<ROUND_E_SMALL, false, 64, true>);
-    }
-    if (r.E == ROUND_E) {
-        if (r.prof) return n64 ? go(k_round<ROUND_E, true, 64>) : go(k_round<ROUND_E, true, 0>);
-        return n64 ? go(k_round<ROUND_E, false, 64>) : go(k_round<ROUND_E, false, 0>);
-    }
-    if (r.prof) return n64 ? go(k_round<ROUND_E_SMALL, true, 64>) : go(k_round<ROUND_E_SMALL, true, 0>);
-    return n64 ? go(k_round<ROUND_E_SMALL, false, 64>) : go(k_round<ROUND_E_SMALL, false, 0>);
 }
 
 size_t dilate_lds_bytes(int pcap) { return sizeof(double) * ((size_t)3 * pcap + 32 + 36 + 16) + sizeof(int) * ((size_t)2 * pcap + 257 + 3); }

@@ -73,6 +73,7 @@ int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double 
                         unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream, unsigned *status_host = nullptr);
 // workgroups of k_eval_cluster a CU holds with lds_bytes of dynamic LDS (occupancy query of the runtime; 0 on error)
 int eval_cluster_blocks_per_cu(size_t lds_bytes);
+int eval_cluster_raise_limit(size_t lds_bytes);                 // raises k_eval_cluster's dynamic-LDS limit on the current device (never lowers it)
 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;

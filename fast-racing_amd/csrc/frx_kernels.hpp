@@ -24,6 +24,12 @@
 #include "frx_lbfgs.hpp"
 #include "frx_wave.hpp"
 
+// Linkage of the stage kernels defined in this header: external in the translation unit that launches them (frx_device.hip); the translation units that only
+// want the BODIES (frx_device_round.hip, frx_device_eval.hip) define it as `static`, and the unused kernels are not compiled there at all.
+#ifndef FRX_KERNEL_LINKAGE
+#define FRX_KERNEL_LINKAGE
+#endif
+
 namespace frx {
 
 // Optional epilogue of k_backward_knot for the device-vector L-BFGS: with d (the search direction) given, the kernel also
@@ -126,7 +132,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // k_forward: grid = B, block = 64.  Dynamic LDS: band[6N*13] | rhs[6N*3] | Tf[N] | Tc[cN]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(64) void k_forward(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout,
                                                 double *__restrict__ Cout, double *__restrict__ bandOut, int maxN, int maxCN) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -503,7 +509,7 @@ __device__ __forceinline__ bool penalty_wave_ll(const DevProblem &dp, const ll_u
     return true;
 }
 // Stage kernels: a workgroup of blockDim.x = 64 W threads owns ppg = floor(64 W / lpp) consecutive pieces (LaunchGeom::pen_w, ::ppg).
-__global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
                                                     double *__restrict__ out20, int lpp, int ppg, int Kmax) {
     extern __shared__ double sm[];
     const int gp0 = blockIdx.x * ppg;
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(256, 3) void k_penalty(DevProblem dp, const double 
 }
 // The latency form of the same kernel (penalty_sample<LAT>: no phase boundaries, 148 VGPRs) - the default: faster than the phased form at
 // every batch size measured.
-__global__ __launch_bounds__(256, FRX_PEN_OCC) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256, FRX_PEN_OCC) void k_penalty_lat(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
                                                         double *__restrict__ out20, int lpp, int ppg, int Kmax) {
     extern __shared__ double sm[];
     const int gp0 = blockIdx.x * ppg;
@@ -523,8 +529,115 @@ __global__ __launch_bounds__(256, FRX_PEN_OCC) void k_penalty_lat(DevProblem dp,
 // K = 8 - and the kernel is compiled for four waves per SIMD (128 VGPRs).  The one-phase form fits three workgroups on a CU by LDS and three waves on a SIMD by
 // registers, and its launch at 1024 candidates spends a quarter of its wave cycles waiting: more workgroups in flight hide the staging trips of one
 // another.  Bit-identical partials (each value is still summed over its piece's samples in sample order); FRX_PENALTY_TWOPHASE=0 keeps the one-phase launch.
-// Dynamic LDS (doubles): cS[ppg*18] | tS[ppg] | hS[ppg*(Kmax+1)*4] | red[blockDim.x * 11]
+// Dynamic LDS (doubles): cS[ppg*18] | tS[ppg] | hS[ppg*(Kmax+1)*4] | red[256 * 11]
+//
+// Round 6 - the instruction diet (520 VALU instructions per wave of which 298 were FP64 arithmetic).  What the other 222 were, from the ISA,
+// and where they went:
+//   * LPP (lanes per piece = kappa + 1) is a TEMPLATE parameter for the two resolutions the boundary is quoted on (17: BASELINE configs[2..4]; 49: the stock kappa = 48
+//     of configs[0]); 0 = any other, at run time.  `lane / lpp` was a run-time integer division (a v_rcp_iflag_f32 sequence of 25 instructions), the trip count of the
+//     `#pragma unroll 2` staging loop - a division by the run-time blockDim.x - another one, and the fixed-order reduction a three-level loop nest (16 reads in flight,
+//     remainder, unroll 4) with its address arithmetic; with LPP known the reduction is 17 (or 16 + 16 + 17) reads at immediate offsets and their additions.
+//   * the workgroup is 256 threads by definition of this form (LaunchGeom::pen_w == 4): a constant, not blockDim.x.
+//   * step = T / kappa (an IEEE division: 25 instructions) was computed by every lane of every wave; the few lanes that stage the durations now divide once per piece and
+//     leave the STEP in LDS (the duration itself is not used by a sample) - one wave of four pays.
+//   * `double o[20] = {0}` for every lane in front of the sample (20 v_mov_b64 and as many phi copies behind the branch): lanes that own no sample store nothing - their
+//     slots are never read - and lanes of a piece that is switched off (piece_active) store zeros in a branch of their own.
+template <int LPP>
 __global__ __launch_bounds__(256, 4) void k_penalty_lat2(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
+                                                         double *__restrict__ out20, int lpp_rt, int ppg, int Kmax) {
+    extern __shared__ double sm[];
+    constexpr int nthr = 256;
+    const int lpp = LPP ? LPP : lpp_rt;
+    const int lane = threadIdx.x;
+    const int gp0 = blockIdx.x * ppg, npieces = min(ppg, dp.P - gp0);
+    const int hstride = (Kmax + 1) * 4;
+    double *cS = sm, *tS = cS + ppg * 18, *hS = tS + ppg, *red = hS + (size_t)ppg * hstride;
+    const int pl = lane / lpp, jl = lane - pl * lpp;
+    const bool exists = pl < npieces;
+    const int pfl = (dp.piece_active && exists) ? dp.piece_active[gp0 + pl] : DV_EVAL;
+    {   // staging (16-byte loads, every sweep's first trips in flight before the first LDS store); corridor blocks: two trips cover K <= 16 at kappa = 16
+        const double2 *h2 = (const double2 *)(dp.hblk + (size_t)gp0 * hstride), *c2 = (const double2 *)(C + (size_t)gp0 * 18);
+        const int nh2 = (npieces * hstride) >> 1, nc2 = (npieces * 18) >> 1;
+        double2 hv0, hv1, cv0;
+        double tv;
+        const bool h0 = lane < nh2, h1 = lane + nthr < nh2, c0 = lane < nc2, t0 = lane < npieces;
+        if (h0) hv0 = h2[lane];
+        if (h1) hv1 = h2[lane + nthr];
+        if (c0) cv0 = c2[lane];
+        if (t0) tv = T[gp0 + lane];
+        if (h0) { hS[2 * lane] = hv0.x; hS[2 * lane + 1] = hv0.y; }
+        if (h1) { hS[2 * (lane + nthr)] = hv1.x; hS[2 * (lane + nthr) + 1] = hv1.y; }
+        if (c0) { cS[2 * lane] = cv0.x; cS[2 * lane + 1] = cv0.y; }
+#pragma unroll 1
+        for (int i = lane + nthr; i < nc2; i += nthr) { const double2 v = c2[i]; cS[2 * i] = v.x; cS[2 * i + 1] = v.y; }      // (more than 28 pieces per workgroup: kappa < 9)
+        if (t0) tS[lane] = tv / dp.kappa;                                      // the piece's STEP, CPU.hpp:245 - once per piece
+#pragma unroll 1
+        for (int i = lane + 2 * nthr; i < nh2; i += nthr) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }
+    }
+    __syncthreads();
+    const bool active = exists && (pfl & DV_EVAL);
+    double o[20];
+    if (active) {
+        LdsView c(cS + pl * 18), hb(hS + (size_t)pl * hstride);
+        const int K = (int)hb[3], kappa = dp.kappa;
+        const double step = tS[pl];
+        penalty_sample_partials<true>(dp, c, hb, K, Kmax, step * jl, step, (jl == 0 || jl == kappa) ? 0.5 : 1.0, dp.inv_kappa, jl, o);
+    }
+    double *mine = red + lane * 11;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (half) __syncthreads();                                            // the first half has been summed: its slots are free
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) mine[i] = o[10 * half + i];
+        } else if (exists) {                                                  // a piece that is switched off this round: its partials are zeros (nobody reads the slots of lanes without a piece)
+#pragma unroll
+            for (int i = 0; i < 10; i++) mine[i] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int idx = lane; idx < npieces * 10; idx += nthr) {               // (one trip unless a workgroup owns more than 25 pieces)
+            const int p2 = idx / 10, v = idx - p2 * 10;
+            const double *src = red + (p2 * lpp) * 11 + v;
+            double s = 0.0;
+            if (LPP) {
+                // the additions are one dependent chain in sample order (determinism); the LDS reads are not - up to seventeen in flight per block
+                constexpr int BLK = LPP <= 24 ? (LPP ? LPP : 1) : 16;
+                int l = 0;
+#pragma unroll
+                for (; l + BLK <= (LPP ? LPP : 1); l += BLK) {
+                    double b[BLK];
+#pragma unroll
+                    for (int j = 0; j < BLK; j++) b[j] = src[(l + j) * 11];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < BLK; j++) s += b[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (; l < LPP; l++) s += src[l * 11];
+            } else {
+                int l = 0;
+                for (; l + 16 <= lpp; l += 16) {                              // (as penalty_reduce: sixteen reads in flight, one chain of additions in sample order)
+                    double b[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) b[j] = src[(l + j) * 11];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) s += b[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll 4
+                for (; l < lpp; l++) s += src[l * 11];
+            }
+            out20[(size_t)(gp0 + p2) * 20 + 10 * half + v] = s;
+        }
+    }
+}
+
+// The round-5 form of the same kernel, kept for build-against-build measurements in ONE process (FRX_PENALTY_TWOPHASE=5; scripts/r06/penalty_ab.py): run-time lpp and
+// blockDim.x, the step divided by every lane, zero-initialised partials.  Bit-identical output.
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256, 4) void k_penalty_lat2_r5(DevProblem dp, const double *__restrict__ T, const double *__restrict__ C,
                                                          double *__restrict__ out20, int lpp, int ppg, int Kmax) {
     extern __shared__ double sm[];
     const int lane = threadIdx.x, nthr = blockDim.x;
@@ -598,7 +711,7 @@ __global__ __launch_bounds__(256, 4) void k_penalty_lat2(DevProblem dp, const do
 // ---------------------------------------------------------------------------------------------
 // k_backward: grid = B, block = 64.  Dynamic LDS: band[6N*13] | gd[6N*3] | cL[6N*3] | Tf[N] | gT[N] | gC[cN]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_backward(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(64) void k_backward(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                                  const double *__restrict__ Cin, const double *__restrict__ bandIn,
                                                  const double *__restrict__ out20, double *__restrict__ f, double *__restrict__ g,
                                                  int maxN, int maxCN) {
@@ -1480,14 +1593,14 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     }
     FRX_STAMP(6);
 }
-__global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
     if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) return;
     forward_knot_body<false>(dp, x, Tout, Cout, maxCN, maxXb, maxVb, nrow, pcrw, nsteps, blockIdx.x, sm);
 }
 // the same for batches whose candidates all have <= 64 pieces: only the wave-specialised form is compiled in (a third of the code)
-__global__ __launch_bounds__(256) void k_forward_knot64(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_forward_knot64(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
     if (dp.cand_active && !(dp.cand_active[blockIdx.x] & DV_EVAL)) return;
@@ -2623,7 +2736,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     FRX_STAMP(24);
 #undef KN
 }
-__global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow, const double *__restrict__ pcrw, int nsteps,
                                 LineSearchTap tap) {
@@ -2634,7 +2747,7 @@ __global__ __launch_bounds__(256) void k_backward_knot(DevProblem dp, const doub
     }
     backward_knot_body<false>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, nrow, pcrw, nsteps, tap, blockIdx.x, sm);
 }
-__global__ __launch_bounds__(256) void k_backward_knot64(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_backward_knot64(DevProblem dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, const double *__restrict__ pcrw, int nsteps,
                                 LineSearchTap tap) {

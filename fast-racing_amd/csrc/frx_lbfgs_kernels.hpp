@@ -9,6 +9,10 @@
 #include "frx_lbfgs.hpp"
 #include "frx_wave.hpp"
 
+#ifndef FRX_KERNEL_LINKAGE
+#define FRX_KERNEL_LINKAGE          // see frx_kernels.hpp
+#endif
+
 namespace frx {
 
 struct DvBuffers {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvComm
 }
 
 // after the objective kernels: f, g.d, x.x, g.g per candidate (lbfgs.hpp:830, 1296-1297)
-__global__ __launch_bounds__(64) void k_lbfgs_post(DvBuffers bf, const double *__restrict__ f, const DvCommand *__restrict__ cmd,
+FRX_KERNEL_LINKAGE __global__ __launch_bounds__(64) void k_lbfgs_post(DvBuffers bf, const double *__restrict__ f, const DvCommand *__restrict__ cmd,
                                                    DvResult *__restrict__ res) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (!(cmd[b].flags & DV_EVAL)) return;

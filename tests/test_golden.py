@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 sys_path = os.path.join(ROOT, "tests", "golden")
-FILES = sorted(f for f in glob.glob(os.path.join(sys_path, "*.npz")) if not os.path.basename(f).startswith(("corridor_", "refvs_")))   # corridor fixtures: test_next_rows.py
+FILES = sorted(f for f in glob.glob(os.path.join(sys_path, "*.npz")) if not os.path.basename(f).startswith(("corridor_", "refvs_", "mc512_")))   # corridor fixtures: test_next_rows.py; Monte-Carlo verdicts: test_gpu_configs.py + the CPU sample below
 
 
 def load_case(path, sc):
@@ -136,3 +136,27 @@ def test_device_plans_in_the_references_vertex_order(frx, sc, name):
     assert (r["status"][0] >= 0) == (int(d["opt_status"]) >= 0)
     assert abs(r["objective"][0] - float(d["opt_obj"])) <= 2e-2 * float(d["opt_obj"])       # independent runs of the reference's stop rule: DESIGN.md 4
     prob.close()
+
+
+def test_monte_carlo_verdict_fixture_is_this_oracles_data(sc, ob):
+    """tests/golden/mc512_cpu_verdicts.npz (make_mc_verdicts.py: four CPU variants of each of the 512 scenarios of one GPU's share of BASELINE configs[4]): a sample
+    recomputed with the live oracle - status and objective of every variant - so that the fixture cannot drift from the checker it stands for (CPU, seconds)."""
+    path = os.path.join(sys_path, "mc512_cpu_verdicts.npz")
+    assert os.path.exists(path), "python tests/golden/make_mc_verdicts.py"
+    fix = np.load(path)
+    B, N, gates, kappa = sc.CONFIGS["montecarlo4096"]
+    assert int(fix["first_id"]) == 0 and fix["status"].shape == (B // 8, 4) and int(fix["iteration_cap"]) == 60000
+    for sid in (3, 400):
+        cand = sc.make_candidate(sid, N, gates)
+        for v, (mode, seed) in enumerate(fix["variants"]):
+            o = ob.Oracle(cand, sc.ZHANGJIAJIE, qd_intervals=kappa)
+            o.set_abscissa_mode(bool(mode))
+            x0 = o.initial_guess()
+            if seed:
+                x0 = x0 * (1.0 + 4e-16 * np.random.default_rng(int(seed)).integers(-2, 3, x0.size))
+            r = o.optimize(sc.ZHANGJIAJIE["opt_rel_tol"], max_iterations=60000, x0=x0)
+            assert int(r["status"]) == int(fix["status"][sid, v]) and int(r["iters"]) == int(fix["iters"][sid, v])
+            assert abs(r["objective"] - fix["objective"][sid, v]) <= 1e-12 * abs(fix["objective"][sid, v])
+    # the share's shape: every feasible scenario converges under every variant (LBFGS_STOP), the two infeasible ones fail under every variant
+    st = fix["status"]
+    assert int(np.sum(st.max(axis=1) < 0)) == 2 and int(np.sum((st.min(axis=1) < 0) & (st.max(axis=1) >= 0))) == 0

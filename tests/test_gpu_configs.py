@@ -139,6 +139,79 @@ def test_config4_share_of_one_gpu(frx, sc, ob):
     assert s["failed_on_cpu"] >= 1                        # the share does contain an infeasible scenario
 
 
+def _mc_fixture():
+    path = os.path.join(ROOT, "tests", "golden", "mc512_cpu_verdicts.npz")
+    assert os.path.exists(path), "tests/golden/mc512_cpu_verdicts.npz is missing: python tests/golden/make_mc_verdicts.py"
+    return np.load(path)
+
+
+def mc_verdict_check(status, objective, fix, first=0):
+    """One path's verdicts on the scenarios first .. first + len(status) of the Monte-Carlo share against the CPU fixture (four CPU variants per scenario,
+    tests/golden/make_mc_verdicts.py).  The reference's verdict is lbfgs_optimize's return code (se3gcopter_cpu.hpp:1243-1249).  Rule, as _share_check:
+    the device's code is one the CPU variants produce; or EVERY CPU variant fails (an infeasible scenario: chaotic from the first iterations, how the stall is
+    labelled depends on the last bits) and the device either fails too or 'succeeds' on a penalty-dominated objective.  Returns (rows that break the rule, rows of
+    infeasible scenarios)."""
+    cs, co = fix["status"], fix["objective"]
+    feasible = np.median([co[i].min() for i in range(len(cs)) if cs[i].min() >= 0])
+    bad, infeasible = [], []
+    for b in range(len(status)):
+        i = first + b
+        sts = [int(v) for v in cs[i]]
+        st = int(status[b])
+        if st in sts:
+            continue
+        if max(sts) < 0:
+            infeasible.append({"scenario": i, "device_status": st, "device_objective": float(objective[b]), "cpu_status": sts})
+            if st >= 0 and not (objective[b] > 100.0 * feasible):
+                bad.append(infeasible[-1])
+            continue
+        bad.append({"scenario": i, "device_status": st, "device_objective": float(objective[b]), "cpu_status": sts, "cpu_objective": [float(v) for v in co[i]]})
+    return bad, infeasible
+
+
+def test_config4_full_share_of_one_gpu(frx, sc, ob):
+    """BASELINE.json configs[4] at a GPU's FULL share: all 512 Monte-Carlo scenarios of rank 0 as ONE batch through the path bench.py
+    uses (per-stage rounds, the last 32 on the resident kernel: take-over) AND through the resident kernel's work queue, each scenario's verdict against the four
+    CPU variants of the committed fixture; every scenario on which the two device paths disagree about success is listed with the CPU's verdicts and must be one
+    on which the CPU variants fail as well.  A sample of the fixture is recomputed live with the oracle (it is data, and this checks it is THIS oracle's data)."""
+    fix = _mc_fixture()
+    B, N, gates, kappa = sc.CONFIGS["montecarlo4096"]
+    B //= 8
+    assert int(fix["first_id"]) == 0 and fix["status"].shape == (B, 4)
+    tol = sc.ZHANGJIAJIE["opt_rel_tol"]
+    cands = [sc.make_candidate(b, N, gates) for b in range(B)]
+    # the fixture against the live oracle on a sample: the scenarios every variant fails on, the ones the variants disagree on, and a few ordinary ones
+    cs = fix["status"]
+    odd = [i for i in range(B) if cs[i].max() < 0 or len(set(int(v) >= 0 for v in cs[i])) > 1]
+    sample = sorted(set(odd[:6] + [0, 1, 255, 511]))
+    variants = [(bool(m), int(s)) for m, s in fix["variants"]]
+    live = _cpu_plans(ob, sc, [cands[i] for i in sample], kappa, tol, variants)
+    for i, plans in zip(sample, live):
+        assert [p["status"] for p in plans] == [int(v) for v in cs[i]], (i, [p["status"] for p in plans], cs[i])
+        assert np.allclose([p["objective"] for p in plans], fix["objective"][i], rtol=1e-12, atol=0.0, equal_nan=True), (i, [p["objective"] for p in plans], fix["objective"][i])
+    prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    x0 = prob.initial_guess()
+    r = prob.optimize(tol, x0=x0)                                           # bench.py's path: per-stage rounds + take-over
+    prob.set_resident(2)
+    q = prob.optimize(tol, x0=x0)                                           # the work queue
+    prob.close()
+    assert r["taken_over"] > 0 and q["device_status"] == 0 and 0 < q["clusters"] < B, (r["taken_over"], q["device_status"], q["clusters"])
+    bad_r, inf_r = mc_verdict_check(r["status"], r["objective"], fix)
+    bad_q, inf_q = mc_verdict_check(q["status"], q["objective"], fix)
+    mism = [{"scenario": int(b), "default_path_status": int(r["status"][b]), "work_queue_status": int(q["status"][b]), "cpu_status": [int(v) for v in cs[b]],
+             "every_cpu_variant_fails": bool(cs[b].max() < 0)} for b in range(B) if (r["status"][b] >= 0) != (q["status"][b] >= 0)]
+    summary = {"config": "montecarlo4096_full_share", "scenarios": B, "cpu_all_variants_fail": int(np.sum(cs.max(axis=1) < 0)), "cpu_some_variant_fails": int(np.sum(cs.min(axis=1) < 0)),
+               "default_path": {"ok": int(np.sum(r["status"] >= 0)), "taken_over": int(r["taken_over"]), "plan_ms": r["ms_total"], "outside_cpu_set": bad_r, "infeasible": inf_r},
+               "work_queue": {"ok": int(np.sum(q["status"] >= 0)), "clusters": int(q["clusters"]), "plan_ms": q["ms_total"], "outside_cpu_set": bad_q, "infeasible": inf_q},
+               "verdict_mismatches_between_the_paths": mism}
+    print(json.dumps(summary))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "share_montecarlo4096_full.json"), "w"), indent=1)
+    assert not bad_r, bad_r
+    assert not bad_q, bad_q
+    assert all(m["every_cpu_variant_fails"] for m in mism), mism
+
+
 @pytest.mark.parametrize("sid,N,gates,kappa", [(1, 16, 4, 8), (2, 32, 8, 8)])
 def test_coefficient_spread_against_stopping_tolerance(frx, sc, ob, sid, N, gates, kappa):
     """device-driven vs CPU-driven plans at delta = 1e-6 (stock) ... 1e-12.  At every delta the device plan is

@@ -449,6 +449,61 @@ def test_one_launch_evaluation_fails_loudly_and_the_handle_stays_usable(frx, sc)
 
 
 @pytest.mark.gpu
+def test_device_form_notices_an_expired_wait_by_itself(frx, sc):
+    """the capturable frx_objective_eval_device has no host-synchronous point of its own.  After a one-launch evaluation whose wait expired (test mode),
+    the leader has left the code in mapped host memory: the NEXT device-form call takes the three stage launches by itself and gives the right numbers, frx_eval_status
+    reports the failure once (FRX_ERR_TIMEOUT) and then is clean, and a captured graph of the failed form keeps answering NaN fast (no 250 ms spin per replay)
+    until the caller looks.  In a process of its own (torch for device buffers, loaded before the library)."""
+    import subprocess, sys, json
+    code = r"""
+import json, sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch
+from frx_import import frx
+from fast_racing_amd import scenario as sc
+cands = [sc.make_candidate(0, 32, 8, perturb_id=b) for b in range(4)]
+prob = frx.Problem(cands, sc.ZHANGJIAJIE, qd_intervals=16)
+x = prob.initial_guess()
+f0, g0 = prob.objective(x)
+x_dev = torch.from_numpy(x).cuda(); f_dev = torch.zeros(prob.B, dtype=torch.float64, device="cuda"); g_dev = torch.zeros(prob.NX, dtype=torch.float64, device="cuda")
+s = torch.cuda.Stream()
+out = {"fused_before": prob.eval_fused()}
+prob.eval_status()                                                   # clean
+prob.set_eval_fused(2)                                               # members leave at once, 50 us bound
+with torch.cuda.stream(s):
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s):
+        for _ in range(5): prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    gr.replay(); s.synchronize()
+    out["nan_after_failed_replay"] = bool(np.all(np.isnan(f_dev.cpu().numpy())))
+    t0 = time.perf_counter(); gr.replay(); s.synchronize(); out["second_replay_ms"] = (time.perf_counter() - t0) * 1e3      # early exits: the sticky word is set
+    out["still_nan"] = bool(np.all(np.isnan(f_dev.cpu().numpy())))
+    # a DIRECT call now: the launcher sees the host word and takes the stage kernels
+    prob.objective_device(x_dev.data_ptr(), f_dev.data_ptr(), g_dev.data_ptr(), s.cuda_stream); s.synchronize()
+    out["fused_after"] = prob.eval_fused()
+    out["direct_call_right"] = bool(np.array_equal(f_dev.cpu().numpy(), f0) and np.abs(g_dev.cpu().numpy() - g0).max() <= 1e-10 * np.abs(g0).max())
+try:
+    prob.eval_status(); out["status_first"] = 0
+except frx.FrxError as e:
+    out["status_first"] = e.code
+try:
+    prob.eval_status(); out["status_second"] = 0
+except frx.FrxError as e:
+    out["status_second"] = e.code
+prob.set_eval_fused(1)
+f1, g1 = prob.objective(x)
+out["back_on"] = bool(prob.eval_fused() > 0 and np.array_equal(f1, f0) and np.array_equal(g1, g0))
+print(json.dumps(out))
+""" % ROOT
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    r = json.loads(res.stdout.strip().splitlines()[-1])
+    print(json.dumps(r))
+    assert r["fused_before"] > 0 and r["nan_after_failed_replay"] and r["still_nan"] and r["second_replay_ms"] < 50.0, r
+    assert r["fused_after"] == 0 and r["direct_call_right"] and r["status_first"] == -7 and r["status_second"] == 0 and r["back_on"], r
+
+
+@pytest.mark.gpu
 def test_one_launch_evaluation_only_for_batches_the_chip_holds(frx, sc):
     """A leader waits for members of its own launch, so every workgroup of the grid has to get a CU: 36 candidates x 7 workgroups fit 256 CUs, 40 do not and
     are evaluated by three stage launches; ragged batches take the cluster size of their largest candidate, smaller candidates leave members idle."""
