@@ -181,6 +181,7 @@ struct frx_problem {
     DevBuf<unsigned long long> d_rprof;                     // FRX_RESIDENT_PROF: [B][G][16] per-segment ticks of the last resident launch
     std::vector<unsigned long long> rprof;
     DevBuf<unsigned> d_rwords;
+    DevBuf<unsigned char> d_rargs;                          // the resident launch's arguments in device memory (k_round takes them by pointer)
     PinBuf<unsigned long long> h_rcmd, h_rres;              // [S] x 8 words each (S clusters: one mailbox per cluster)
     int rk_B = 0, rk_S = 0, rk_G = 0, rk_NXP = 0;
     // take-over of a per-stage batch's stragglers by the resident kernel (optimize_resident with a TakeOver): per cluster candidate index, last objective value,
@@ -203,6 +204,8 @@ struct frx_problem {
     DevBuf<unsigned long long> d_ev_ll; unsigned *d_ev_words = nullptr;   // one allocation: [78 P] granule words, then the [64 B + 1] control words
     int eval_fused = 0, eval_fused_G = 0, eval_fused_stamps = 0;
     unsigned long long eval_fused_ticks = 25000000ull;      // bound of every wait inside the launch, ticks of the 100 MHz counter: 250 ms (a healthy evaluation takes ~20 us; FRX_EVAL_TIMEOUT_MS)
+    std::vector<unsigned char> ev_args, ev_args_up;         // the one-launch evaluation's constant arguments (frx::eval_cluster_args): as they should be / as the device copy holds them
+    DevBuf<unsigned char> d_ev_args;
     PinBuf<unsigned> h_ev_status;                           // mapped host word: the code of an expired wait, written by the leader that saw it - launch_eval reads it without a synchronisation
     unsigned eval_fused_code = 0;                           // the code that retired the one-launch form on this handle (0: none)
     frx::LaunchGeom geo;
@@ -221,8 +224,16 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
     // handle takes the stage kernels by itself - also on the capturable _device form and inside the host-vector L-BFGS, which have no status check of their own.
     // No HIP call here (the caller may be capturing): the device's sticky word is cleared at the next host-synchronous point (eval_cluster_status).
     if (p->eval_fused && p->h_ev_status.p && *(volatile unsigned *)p->h_ev_status.p != 0u) { p->eval_fused_code = *(volatile unsigned *)p->h_ev_status.p; p->eval_fused = 0; }
-    if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps))
-        return frx::launch_eval_cluster(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, f_dev, g_dev, p->d_ev_ll.p, p->d_ev_words, p->eval_fused_ticks, st, p->h_ev_status.p);
+    if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps)) {
+        // the handle's constant arguments live in device memory (uploaded at create); they only change when a diagnostic switches the cycle stamps on or off -
+        // a synchronous copy then (never inside somebody's capture: the diagnostics are blocking calls of their own)
+        frx::eval_cluster_args(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_ev_ll.p, p->d_ev_words, p->ev_args.data());
+        if (p->ev_args != p->ev_args_up) {
+            if (hipMemcpy(p->d_ev_args.p, p->ev_args.data(), p->ev_args.size(), hipMemcpyHostToDevice) != hipSuccess) return (int)hipErrorUnknown;
+            p->ev_args_up = p->ev_args;
+        }
+        return frx::launch_eval_cluster(p->geo, p->B, p->ev_args.data(), p->d_ev_args.p, x_dev, f_dev, g_dev, p->eval_fused_ticks, st, p->h_ev_status.p);
+    }
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
@@ -469,6 +480,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         CR(p->d_ev_ll.alloc(n_ll + n_w64)); CR(hipMemset(p->d_ev_ll.p, 0, sizeof(unsigned long long) * (n_ll + n_w64)));   // (not on the handle's stream: the first evaluation may come on the caller's)
         p->d_ev_words = (unsigned *)(p->d_ev_ll.p + n_ll);
         CR(p->h_ev_status.alloc(16));
+        p->ev_args.assign(frx::eval_cluster_args_bytes(), 0); CR(p->d_ev_args.alloc(p->ev_args.size()));
     }
     CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
     CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
@@ -492,6 +504,12 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     d.coarse_iv = p->d_coarse_iv.p; d.coarse_fbeg = p->d_coarse_fbeg.p;
     d.wp_vbeg = p->d_wp_vbeg.p; d.wp_nv = p->d_wp_nv.p; d.wp_xbeg = p->d_wp_xbeg.p;
     d.hblk = p->d_hblk.p; d.vrec = p->d_vrec.p; d.wq_glob = p->d_wq.p; d.stamps = nullptr; d.cand_active = nullptr; d.piece_active = nullptr;
+    if (p->eval_fused_G) {                                                  // (the first evaluation may be captured: the device copy of its arguments is complete before create returns)
+        frx::eval_cluster_args(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_ev_ll.p, p->d_ev_words, p->ev_args.data());
+        const hipError_t e_ = hipMemcpy(p->d_ev_args.p, p->ev_args.data(), p->ev_args.size(), hipMemcpyHostToDevice);
+        if (e_ != hipSuccess) { const std::string m_ = std::string("upload of the evaluation arguments: ") + hipGetErrorString(e_); (void)hipStreamDestroy(p->stream); delete p; return fail(FRX_ERR_HIP, m_); }
+        p->ev_args_up = p->ev_args;
+    }
     if (std::getenv("FRX_SETUP_TIMING")) fprintf(stderr, "[frx setup] frx_problem_create: B = %d, host descriptors %.3f ms, device allocations + uploads %.3f ms\n", B, ms_host_build, ms_since(t_create0) - ms_host_build);
     *out = p;
     return FRX_OK;
@@ -1249,6 +1267,8 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     rl.x = p->d_x.p; rl.g = p->d_g.p; rl.xp = p->d_xp.p; rl.gp = p->d_gp.p; rl.d = p->d_dir.p; rl.f = p->d_f.p; rl.T = p->d_T.p; rl.C = p->d_C.p; rl.out20 = p->d_out20.p;
     rl.pubsyg = p->d_pubsyg.p; rl.part = p->d_part.p; rl.upub = p->d_upub.p; rl.dpub = p->d_dpub.p; rl.out20ll = std::getenv("FRX_RESIDENT_NO_LL20") ? nullptr : (unsigned long long *)p->d_out20ll.p; rl.dbg = want_dbg ? p->d_rdbg.p : nullptr; rl.dbg_cap = want_dbg ? p->dirlog_cap : 0; rl.dbg_cands = want_dbg ? log_cands : 0;
     rl.words = p->d_rwords.p; rl.h_cmd = p->h_rcmd.p; rl.h_res = p->h_rres.p;
+    if (!p->d_rargs.p && p->d_rargs.alloc(frx::round_args_bytes()) != hipSuccess) { (void)hipGetLastError(); p->d_rargs.p = nullptr; }
+    rl.args_dev = p->d_rargs.p;
     rl.timeout_ticks = (unsigned long long)(timeout_ms * 1e5);                        // wall_clock64: 100 MHz
     rl.B = B; rl.S = S; rl.G = G; rl.m = m; rl.E = E; rl.NXP = NXP;
     rl.prof = want_prof ? p->d_rprof.p : nullptr;

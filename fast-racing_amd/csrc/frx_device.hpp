@@ -68,9 +68,13 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
 // One launch per evaluation (frx_eval_kernel.hpp): clusters of g.ev_G workgroups, one per candidate.  ll: [P][40 + 38] granule words (penalty partials, then (C, T)), words: [64 B + 1] (the last one: status), both
 // zeroed ONCE at allocation.  The caller has checked that dp.B * g.ev_G workgroups are resident at once (eval_cluster_geometry).
 int eval_cluster_geometry(LaunchGeom &g);                         // fills ev_G / lds_ev from the other fields; returns ev_G
+// The handle's constant arguments are packed ONCE (eval_cluster_args into eval_cluster_args_bytes() bytes) and live in host AND device memory; a launch passes the
+// device copy by pointer (the by-value form behind FRX_EVAL_ARGPTR=0 reads the host copy) plus what changes per call.
 // status_host: one word of mapped host memory that receives the code of an expired wait (the device's own sticky word stays the authority inside the launch).
-int launch_eval_cluster(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *f, double *grad,
-                        unsigned long long *ll, unsigned *words, unsigned long long timeout_ticks, void *stream, unsigned *status_host = nullptr);
+size_t eval_cluster_args_bytes();
+void eval_cluster_args(const DevProblem &dp, const LaunchGeom &g, double *T, double *C, unsigned long long *ll, unsigned *words, void *out);
+int launch_eval_cluster(const LaunchGeom &g, int B, const void *args_host, const void *args_dev, const double *x, double *f, double *grad,
+                        unsigned long long timeout_ticks, void *stream, unsigned *status_host = nullptr);
 // workgroups of k_eval_cluster a CU holds with lds_bytes of dynamic LDS (occupancy query of the runtime; 0 on error)
 int eval_cluster_blocks_per_cu(size_t lds_bytes);
 int eval_cluster_raise_limit(size_t lds_bytes);                 // raises k_eval_cluster's dynamic-LDS limit on the current device (never lowers it)
@@ -115,10 +119,12 @@ struct RoundLaunch {
     const int *rs_cand = nullptr, *rs_newest = nullptr, *rs_bound = nullptr;
     const double *rs_f = nullptr, *rs_S = nullptr, *rs_Y = nullptr, *rs_rinv = nullptr, *rs_yy = nullptr, *rs_vd = nullptr;   // S, Y: the per-stage history [B][m][rs_hs]; rinv [S][128][129], yy [S][128][128], vd [S][128]
     size_t rs_hs = 0;
+    void *args_dev = nullptr;                                       // optional device buffer of round_args_bytes() bytes: the kernel takes its arguments through it (k_round<.., ARGP>)
 };
 enum { ROUND_E = 56, ROUND_E_SMALL = 28, ROUND_WORDS_PER_CAND = 128 };                                             // history doubles per thread and array of the instantiated kernel
 // LDS bytes one workgroup of the round kernel needs (0 = geometry not supported)
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E);
+size_t round_args_bytes();
 int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r, void *stream);
 int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void *res, void *stream);
 

@@ -25,6 +25,7 @@ static int round_eval_doubles(const LaunchGeom &g) {
     e = std::max(e, 4 * pen + 8);
     return (int)((e + 1) & ~(size_t)1) + round_ct_doubles(g);
 }
+size_t round_args_bytes() { return sizeof(RoundArgs); }
 size_t round_lds_bytes(const LaunchGeom &g, int m, int E) {
     if ((E != ROUND_E && E != ROUND_E_SMALL) || m < 1 || m > 128 || g.solver != SOLVER_KNOT_PCR) return 0;
     return sizeof(double) * (size_t)round_lds(m, 2 * E, round_eval_doubles(g)).total;
@@ -63,6 +64,22 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, a);
         return (int)hipGetLastError();
     };
+    // the arguments by POINTER (k_round<.., ARGP>): copied into the handle's device buffer in front of the launch, on its stream (pageable source: staged before the call returns)
+    [[maybe_unused]] auto go_ptr = [&](auto kernel) -> int {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipMemcpyAsync(r.args_dev, &a, sizeof(a), hipMemcpyHostToDevice, (hipStream_t)stream)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, (const RoundArgs *)r.args_dev);
+        return (int)hipGetLastError();
+    };
+    // Measured (profiles/r06_ab_argptr.jsonl, four alternating processes per form on one box, bit-identical plans): 602 -> 301 SGPR spills and 4077 -> 1377 v_readlane
+    // reloads buy k_round NOTHING - 25.35 against 25.44 us per round at 32 candidates, 23.05 against 23.60 with one, 24.18 against 24.82 at the stock kappa = 48: an
+    // s_load at the use is no faster than a v_readlane there, and neither sits on the leader's dependent chain.  (k_eval_cluster, whose arguments are read once per
+    // launch instead of once per round, gains 0.23 us of 17.4: frx_device_eval.hip.)  The by-pointer instantiations are therefore only built with
+    // -DFRX_ROUND_ARGPTR_BUILD (and then taken with FRX_ROUND_ARGPTR=1); the default is by value.
+#ifdef FRX_ROUND_ARGPTR_BUILD
+    static const bool argp = [] { const char *e = std::getenv("FRX_ROUND_ARGPTR"); return e && e[0] == '1'; }();
+#endif
     a.rs.cand = r.rs_cand; a.rs.f_last = r.rs_f; a.rs.S = r.rs_S; a.rs.Y = r.rs_Y; a.rs.hs = r.rs_hs; a.rs.newest = r.rs_newest; a.rs.bound = r.rs_bound; a.rs.rinv = r.rs_rinv; a.rs.yy = r.rs_yy; a.rs.vd = r.rs_vd;
     if (r.rs_cand) {                                                   // take-over instantiation: <= 64 pieces, no profile
         if (!n64 || r.prof) return (int)hipErrorInvalidValue;
@@ -70,9 +87,15 @@ int launch_round(const DevProblem &dp, const LaunchGeom &g, const RoundLaunch &r
     }
     if (r.E == ROUND_E) {
         if (r.prof) return n64 ? go(k_round<ROUND_E, true, 64>) : go(k_round<ROUND_E, true, 0>);
+#ifdef FRX_ROUND_ARGPTR_BUILD
+        if (n64 && argp && r.args_dev) return go_ptr(k_round<ROUND_E, false, 64, false, true>);
+#endif
         return n64 ? go(k_round<ROUND_E, false, 64>) : go(k_round<ROUND_E, false, 0>);
     }
     if (r.prof) return n64 ? go(k_round<ROUND_E_SMALL, true, 64>) : go(k_round<ROUND_E_SMALL, true, 0>);
+#ifdef FRX_ROUND_ARGPTR_BUILD
+    if (n64 && argp && r.args_dev) return go_ptr(k_round<ROUND_E_SMALL, false, 64, false, true>);
+#endif
     return n64 ? go(k_round<ROUND_E_SMALL, false, 64>) : go(k_round<ROUND_E_SMALL, false, 0>);
 }
 

@@ -24,23 +24,21 @@
 // cluster's blocks are 8 apart within one group of 8 G consecutive blocks (the XCD mapping of k_round), so the resident blocks of a launch always contain
 // whole clusters, which finish and make room; the launcher only takes this path when B G <= the device's CU count (frx_device.hip).
 #pragma once
+#include <type_traits>
+
 #include "frx_round_kernel.hpp"
 
 namespace frx {
 
-struct EvalClusterArgs {
+struct EvalClusterArgs {                      // constant for the life of a handle (a copy lives in device memory: ARGP below)
     DevProblem dp;
-    const double *x; double *T, *C, *f, *g;
+    double *T, *C;
     ll_u64 *out20ll;                         // [P][20] granules: the penalty partials, members -> leader (its own buffer: the round kernel's carries tags of its own)
     ll_u64 *ctll;                            // [P][19] granules: coefficients and duration of every piece, leader -> members
     unsigned *words;                         // [B][64]: cluster k's 256-byte block: word 0 = gate (tag << 4 | the leader's XCD + 1: (C, T) are out), words 8 .. 8 + G - 2 = tag << 4 | XCD + 1 of
                                              // members 1 .. G-1 (written at their entry), word 32 = tag of the last completed evaluation
     unsigned *status;                        // [1] sticky error word
-    unsigned *status_host;                   // optional, mapped host memory: the code of an expired wait, where the launcher sees it without a synchronisation (frx_api.cpp: launch_eval)
-    rk_u64 timeout_ticks;
     int G, maxCN, maxXb, maxVb, nsteps, lpp, ppw, Kmax, pen_lds, maxN19;
-    int test_drop_members;                   // tests (frx_debug_set_eval_fused(p, 2)): the members leave at once, as if they never got a CU - the leader's wait for the partials expires
-    int force_wt;                            // 1 = every payload store write-through, as if no two workgroups shared an XCD (tests: FRX_EVAL_FUSED_WT=1)
 };
 
 // LDS of a workgroup (doubles): 2 control | leader: (C, T) copy, x, polytopes, multipliers, waypoint sums, evaluation scratch | member: 4 waves x pen_lds
@@ -61,7 +59,21 @@ __host__ __device__ inline EvalClusterLds eval_cluster_lds(int maxN19, int maxXb
     return L;
 }
 
-__global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
+// ARGP (round 6): the arguments that are constant for the life of a handle - the problem descriptor and the geometry, ~400 bytes - come
+// through a POINTER to a copy in device memory instead of by value, and only what changes per call (x, f, g, the bound, the test switches) stays in the kernarg
+// segment.  By value every field is loaded into a scalar register at entry and stays live for the whole kernel: 100 registers' worth of them for a budget of 102 -
+// the shipped object had 63 SGPR spills and 767 v_readlane reloads in front of their uses (scripts/isa_report.py).  Behind a pointer a field is an s_load at its
+// use (scalar cache) and nothing is kept: 0 spills, 12 v_readlane, 3463 instead of 4093 VALU instructions in the kernel.
+struct EvalCallArgs {                         // what changes per call
+    const double *x; double *f, *g;
+    unsigned *status_host;                   // optional, mapped host memory: the code of an expired wait, where the launcher sees it without a synchronisation (frx_api.cpp: launch_eval)
+    rk_u64 timeout_ticks;                    // bound of every spin
+    int test_drop_members;                   // tests (frx_debug_set_eval_fused(p, 2)): the members leave at once, as if they never got a CU - the leader's wait for the partials expires
+    int force_wt;                            // 1 = every payload store write-through, as if no two workgroups shared an XCD (tests: FRX_EVAL_FUSED_WT=1)
+};
+template <bool ARGP>
+__global__ __launch_bounds__(256, 1) void k_eval_cluster(typename std::conditional<ARGP, const EvalClusterArgs *__restrict__, EvalClusterArgs>::type arg, EvalCallArgs call) {
+    const EvalClusterArgs &a = [&]() -> const EvalClusterArgs & { if constexpr (ARGP) return *arg; else return arg; }();
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane8 = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int wg = rest % a.G, k = lane8 + 8 * (rest / a.G);       // (k_round's mapping: a cluster's blocks share blockIdx % 8 - one XCD, as observed)
@@ -73,11 +85,11 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
     unsigned *flag = a.words + (size_t)k * 64, *done = flag + 32;
     const int p0 = a.dp.poff[c], N = a.dp.poff[c + 1] - p0;
     const int ntasks = (N + a.ppw - 1) / a.ppw;                     // wave-tasks of this candidate: ppw pieces each; members 1 .. G-1 hold 4 (G - 1) >= ntasks waves
-    if (wg != 0 && ((wg - 1) * 4 >= ntasks || a.test_drop_members)) return;   // a member without a task
+    if (wg != 0 && ((wg - 1) * 4 >= ntasks || call.test_drop_members)) return;   // a member without a task
     // A wait of an EARLIER launch expired and nobody has cleared the word yet (the capturable form has no host-synchronous point of its own: replays of a captured
     // graph go on until the caller polls frx_eval_status): nothing is evaluated, nothing spins; the objective values say so.
     if (__builtin_expect(__hip_atomic_load(a.status, FRX_RLX_AGENT) != 0u, 0)) {
-        if (wg == 0 && threadIdx.x == 0) a.f[k] = __builtin_nan("");
+        if (wg == 0 && threadIdx.x == 0) call.f[k] = __builtin_nan("");
         return;
     }
     unsigned tag = __hip_atomic_load(done, FRX_RLX_AGENT) + 1u;     // (stays in a vector register: nothing waits for the load until the tag is used)
@@ -88,34 +100,34 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(EvalClusterArgs a) {
     // the gate word, and whoever finds a partner elsewhere (or not yet heard of) writes through.
     unsigned my_xcc = 0;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
-    my_xcc = a.force_wt ? 0u : (my_xcc & 7u) + 1u;                  // 0: "nowhere" - never equal to a partner's
+    my_xcc = call.force_wt ? 0u : (my_xcc & 7u) + 1u;                  // 0: "nowhere" - never equal to a partner's
     const EvalClusterLds L = eval_cluster_lds(a.maxN19, a.maxXb, a.maxVb, a.maxCN, a.nsteps, a.pen_lds);
     if (wg != 0) {
         // every WAVE of a member is on its own from here (no workgroup barrier below): its task's corridor blocks, the gate, its granules, its samples, its partials
         if (t == 0) __hip_atomic_store(flag + 8 + (wg - 1), (tag << 4) | my_xcc, FRX_RLX_AGENT);
         const int task = (wg - 1) * 4 + wave;
         if (task >= ntasks) return;
-        penalty_wave_ll<true>(a.dp, a.ctll, flag, tag, a.out20ll, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, min(a.ppw, N - task * a.ppw), sm + 2 + (size_t)wave * a.pen_lds, lane, a.status, a.timeout_ticks, my_xcc, (k == 0 && wg == 1 && wave == 0) ? a.dp.stamps : nullptr);
+        penalty_wave_ll<true>(a.dp, a.ctll, flag, tag, a.out20ll, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, min(a.ppw, N - task * a.ppw), sm + 2 + (size_t)wave * a.pen_lds, lane, a.status, call.timeout_ticks, my_xcc, (k == 0 && wg == 1 && wave == 0) ? a.dp.stamps : nullptr);
         return;
     }
     // ---- leader ----
     double *ctl = sm + L.ctl, *ev = sm + L.ev;
     ResidentOps ro;
     ro.xs = sm + L.xs; ro.vs = sm + L.vs; ro.dsv = sm + L.xs; ro.pw = sm + L.pw; ro.gs = nullptr; ro.vskew = 0; ro.wq = sm + L.wq; ro.gpub = nullptr; ro.gwt = true;
-    const GranuleOut go{a.ctll, tag, flag, (tag << 4) | (my_xcc ? my_xcc : 15u), a.force_wt ? nullptr : flag + 8, (ntasks + 3) / 4};   // (C, T) leave as granules; nothing is drained, no flag follows them
-    forward_knot_body<true, 64, 3>(a.dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro, nullptr, &go);
+    const GranuleOut go{a.ctll, tag, flag, (tag << 4) | (my_xcc ? my_xcc : 15u), call.force_wt ? nullptr : flag + 8, (ntasks + 3) / 4};   // (C, T) leave as granules; nothing is drained, no flag follows them
+    forward_knot_body<true, 64, 3>(a.dp, call.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro, nullptr, &go);
     if (a.dp.stamps && k == 0 && t == 0) a.dp.stamps[41] = (long long)wall_clock64();
-    ro.o20ll = a.out20ll; ro.o20tag = tag; ro.status = a.status; ro.spin_ticks = a.timeout_ticks;
+    ro.o20ll = a.out20ll; ro.o20tag = tag; ro.status = a.status; ro.spin_ticks = call.timeout_ticks;
     const LineSearchTap tap{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr};
-    backward_knot_body<true, 64>(a.dp, a.x, a.T, a.C, nullptr, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, tap, c, ev, ctl, &ro);
+    backward_knot_body<true, 64>(a.dp, call.x, a.T, a.C, nullptr, call.f, call.g, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, tap, c, ev, ctl, &ro);
     if (a.dp.stamps && k == 0 && t == 0) a.dp.stamps[42] = (long long)wall_clock64();
     __syncthreads();
     if (t == 0) {
         const double fv = ev[36 * 64 + 9 * 65 + 2 * 64 + a.maxCN];  // `red[0]` of backward_knot_wsp64: the objective value (a resident caller's f does not go to global memory there)
         const unsigned code = __hip_atomic_load(a.status, FRX_RLX_AGENT);
         const bool bad = code != 0u;
-        a.f[c] = bad ? __builtin_nan("") : fv;
-        if (bad && a.status_host) __hip_atomic_store(a.status_host, code, FRX_RLX_SYS);
+        call.f[c] = bad ? __builtin_nan("") : fv;
+        if (bad && call.status_host) __hip_atomic_store(call.status_host, code, FRX_RLX_SYS);
         __hip_atomic_store(done, tag, FRX_RLX_AGENT);
         if (a.dp.stamps && k == 0) a.dp.stamps[43] = (long long)wall_clock64();
     }

@@ -37,6 +37,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "frx_kernels.hpp"
@@ -1177,8 +1178,12 @@ __device__ __forceinline__ void rk_dense_loop(const RoundArgs &a, const RoundVie
 }
 
 // NR: 64 = every candidate has <= 64 pieces (the wave-specialised bodies, nothing else compiled in), 0 = the geometry class is a run-time value
-template <int E, bool PROF, int NR, bool RESUME = false>
-__global__ __launch_bounds__(256, 1) void k_round(RoundArgs a) {
+// ARGP (round 6): the launch's arguments - ~90 scalar registers' worth of pointers and sizes for a budget of 102 - come through a pointer to a copy
+// in device memory instead of by value: a field is then an s_load at its use (scalar cache) instead of a register that is live for the whole plan and spilled to a
+// VGPR lane (production instantiation: 602 -> 301 SGPR spills, 4077 -> 1377 v_readlane reloads, 19.0 k -> 16.2 k VALU instructions; scripts/isa_report.py).
+template <int E, bool PROF, int NR, bool RESUME = false, bool ARGP = false>
+__global__ __launch_bounds__(256, 1) void k_round(typename std::conditional<ARGP, const RoundArgs *__restrict__, RoundArgs>::type arg) {
+    const RoundArgs &a = [&]() -> const RoundArgs & { if constexpr (ARGP) return *arg; else return arg; }();
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int CHT = 2 * E;
     // Workgroup -> (candidate, role).  Blocks b with equal b % 8 have been observed to share an XCD (MI355X guide; HIP promises
