@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
     "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
-    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at",
+    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
 ]
 
 _lib = None
@@ -169,6 +169,13 @@ def _check(rc: int):
         e = FrxError(f"frx error {rc}: {lib().frx_last_error().decode()}")
         e.code = rc
         raise e
+
+
+def shader_clock(device: int = 0, ms: float = 2.0):
+    """frx_debug_shader_clock: (min, mean, max) MHz the device sustains under a latency-bound FP64 load."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _check(lib().frx_debug_shader_clock(device, C.c_double(ms), C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def gcopter_lbfgs_params(rel_cost_tol: float, max_iterations: int = 0) -> LbfgsParams:

@@ -145,6 +145,68 @@ int mailbox_threads_for(int S, int extra_plans) { return std::max(1, std::min(st
 int host_cpu_share_for(int extra_plans) { return share_of(extra_plans); }
 } // namespace frx
 
+static bool device_numa_cpus(int device, cpu_set_t *out);
+// CPUs of the NUMA node the device hangs on (sysfs: the PCI function's numa_node, the node's cpulist), intersected with what the process may use.
+// The mailbox threads of a resident plan are kept there: with the threads on the OTHER socket of a two-socket box every command the device reads
+// and every result it writes crosses the socket interconnect and its cache-coherence traffic (measured, 32 candidates: 28.2-28.9 us per round with
+// the process on the device's node, 30.6-32.5 on the other one; waits for the host's confirmation: p90 2.3 against 6.9 us - profiles/r04_numa.txt).
+static bool device_numa_cpus_uncached(int device, cpu_set_t *out);
+// (ADVICE r4) looked up once per device and process - two sysfs reads and a PCI query are not something to do while a resident kernel's clusters
+// already spin; a change of the process's affinity mask after the first plan on a device is not followed
+static bool device_numa_cpus(int device, cpu_set_t *out) {
+    struct Entry { bool ok; cpu_set_t set; };
+    static std::mutex lock;
+    static std::map<int, Entry> cache;
+    std::lock_guard<std::mutex> g(lock);
+    auto it = cache.find(device);
+    if (it == cache.end()) { Entry e; e.ok = device_numa_cpus_uncached(device, &e.set); it = cache.emplace(device, e).first; }
+    if (it->second.ok) *out = it->second.set;
+    return it->second.ok;
+}
+static bool device_numa_cpus_uncached(int device, cpu_set_t *out) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return false;
+    for (char *c = bdf; *c; c++) *c = (char)std::tolower(*c);
+    int node = -1;
+    { const std::string p = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node"; if (FILE *f = std::fopen(p.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); } }
+    if (node < 0) return false;
+    std::string list;
+    { const std::string p = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"; if (FILE *f = std::fopen(p.c_str(), "r")) { char buf[4096] = {0}; if (std::fgets(buf, sizeof(buf), f)) list = buf; std::fclose(f); } }
+    if (list.empty()) return false;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    for (size_t i = 0; i < list.size();) {                                   // "0-63,128-191"
+        if (!std::isdigit((unsigned char)list[i])) { i++; continue; }
+        size_t j = i; int a = 0; while (j < list.size() && std::isdigit((unsigned char)list[j])) a = 10 * a + (list[j++] - '0');
+        int b = a;
+        if (j < list.size() && list[j] == '-') { j++; b = 0; while (j < list.size() && std::isdigit((unsigned char)list[j])) b = 10 * b + (list[j++] - '0'); }
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
+        i = j;
+    }
+    if (CPU_COUNT(&want) < 2) return false;                                 // nothing (or a single CPU) of that node is ours: leave the threads where they are
+    *out = want;
+    return true;
+}
+
+// The calling thread on the CPUs of the device's NUMA node for the length of a scope (FRX_NUMA=0: wherever it is).  Used around the allocation - and first touch - of
+// the mailboxes in mapped host memory: pinned pages are taken from the node the allocating thread runs on, and a process whose main thread happened to sit on the other
+// socket at that moment kept its mailboxes there for good - every command the device read and every result it wrote crossed the socket interconnect, and so did the
+// service threads' scans from the right socket.  Round 6 found the two MODES of a process that round 5 put down to "the box's host" (profiles/r06_mode_probe.jsonl:
+// 25.0-25.2 us per round with a mailbox scan of 0.07 us, 26.2-26.3 with 0.12-0.15, constant within a process, same clocks, same XCD placement; stretching the scan
+// period itself to 3.2 us changes nothing, profiles/r06_ab_host_scan.jsonl).
+struct NumaScope {
+    cpu_set_t saved; bool active = false;
+    explicit NumaScope(int device) {
+        const char *e = std::getenv("FRX_NUMA"), *ea = std::getenv("FRX_NUMA_ALLOC");       // FRX_NUMA_ALLOC=0: allocations where the caller happens to run (round 5's behaviour, for A/B)
+        cpu_set_t want;
+        if ((e && e[0] == '0') || (ea && ea[0] == '0') || !device_numa_cpus(device, &want)) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) != 0) return;
+        active = pthread_setaffinity_np(pthread_self(), sizeof(want), &want) == 0;
+    }
+    ~NumaScope() { if (active) (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved); }
+};
+
 struct frx_problem {
     frx_config cfg;
     int device = 0, B = 0, P = 0, Pc = 0, NX = 0, Kmax = 0, maxN = 0, maxCN = 0, sumKfine = 0;
@@ -479,11 +541,14 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         const size_t n_ll = (size_t)78 * p->P, n_w64 = ((size_t)64 * B + 2) / 2;
         CR(p->d_ev_ll.alloc(n_ll + n_w64)); CR(hipMemset(p->d_ev_ll.p, 0, sizeof(unsigned long long) * (n_ll + n_w64)));   // (not on the handle's stream: the first evaluation may come on the caller's)
         p->d_ev_words = (unsigned *)(p->d_ev_ll.p + n_ll);
-        CR(p->h_ev_status.alloc(16));
+        { NumaScope numa_alloc(device); CR(p->h_ev_status.alloc(16)); }
         p->ev_args.assign(frx::eval_cluster_args_bytes(), 0); CR(p->d_ev_args.alloc(p->ev_args.size()));
     }
-    CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
-    CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
+    {   // pinned staging buffers: pages from the device's NUMA node (NumaScope)
+        NumaScope numa_alloc(device);
+        CR(p->h_x.alloc(p->NX)); CR(p->h_f.alloc(B)); CR(p->h_g.alloc(p->NX));
+        CR(p->h_T.alloc(p->P)); CR(p->h_C.alloc((size_t)p->P * 18)); CR(p->h_out20.alloc((size_t)p->P * 20));
+    }
 #undef CR
 
     frx::DevProblem &d = p->dp;
@@ -970,6 +1035,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         p->dv_mem = 0; p->dv_hs = 0;
         const size_t hist = (size_t)m * B * HS;
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };   // keep what is large enough
+        NumaScope numa_alloc(p->device);                                          // command / result mailboxes of the per-stage rounds: pages from the device's NUMA node
         if ((e = need(p->d_xp, p->NX)) != hipSuccess || (e = need(p->d_gp, p->NX)) != hipSuccess || (e = need(p->d_dir, p->NX)) != hipSuccess ||
             (e = need(p->d_S, hist)) != hipSuccess || (e = need(p->d_Y, hist)) != hipSuccess ||
             (e = need(p->d_ys, (size_t)B * m)) != hipSuccess || (e = need(p->d_gt, (size_t)B * m * 4)) != hipSuccess || (e = need(p->h_cmd, B)) != hipSuccess || (e = need(p->h_res, B)) != hipSuccess) {
@@ -1029,6 +1095,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         }
     }
     if (mailbox) {
+        NumaScope numa_alloc(p->device);
         if (!p->d_arrive.p && ((e = p->d_arrive.alloc(1)) != hipSuccess || (e = p->h_flag.alloc(1)) != hipSuccess)) return fail(FRX_ERR_ALLOC, hipGetErrorString(e));
         HIP_TRY(hipMemsetAsync(p->d_arrive.p, 0, sizeof(unsigned), p->stream));
         p->h_flag.p[0] = 0;
@@ -1122,7 +1189,6 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
 // device - two shards of frx_multi on one GPU, two user threads - could each get a partially resident grid, and neither census would
 // ever complete.  Launches of this process are therefore serialised per device: the second plan waits for the first one's kernel to
 // leave (another PROCESS on the same device is caught by the census bound instead: 250 ms, then the per-stage path).
-static bool device_numa_cpus(int device, cpu_set_t *out);
 static std::mutex &resident_device_lock(int device) {
     static std::mutex table_lock;
     static std::map<int, std::unique_ptr<std::mutex>> table;
@@ -1198,6 +1264,7 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     if (p->rk_B != B || p->rk_S != S || p->rk_G != G || p->rk_NXP != NXP) {
         p->rk_B = 0;
         auto need = [](auto &buf, size_t count) -> hipError_t { return buf.n >= count && buf.p ? hipSuccess : buf.alloc(count); };
+        NumaScope numa_alloc(p->device);                                                  // the mailboxes' pages come from the device's NUMA node
         if ((e = p->d_pubsyg.alloc((size_t)S * (3 * NXP + 2))) != hipSuccess || (e = p->d_part.alloc((size_t)S * G * 512)) != hipSuccess ||
             (e = p->d_upub.alloc((size_t)S * 258)) != hipSuccess || (e = p->d_dpub.alloc((size_t)S * 2 * NXP)) != hipSuccess ||
             (e = p->d_out20ll.alloc((size_t)p->P * 40)) != hipSuccess || (e = p->d_rwords.alloc(n_words)) != hipSuccess || (e = p->h_rcmd.alloc((size_t)8 * S)) != hipSuccess || (e = p->h_rres.alloc((size_t)8 * S)) != hipSuccess ||
@@ -1531,49 +1598,6 @@ static int optimize_resident(frx_problem *p, const frx_lbfgs_params &pm, double 
     return FRX_OK;
 }
 
-// CPUs of the NUMA node the device hangs on (sysfs: the PCI function's numa_node, the node's cpulist), intersected with what the process may use.
-// The mailbox threads of a resident plan are kept there: with the threads on the OTHER socket of a two-socket box every command the device reads
-// and every result it writes crosses the socket interconnect and its cache-coherence traffic (measured, 32 candidates: 28.2-28.9 us per round with
-// the process on the device's node, 30.6-32.5 on the other one; waits for the host's confirmation: p90 2.3 against 6.9 us - profiles/r04_numa.txt).
-static bool device_numa_cpus_uncached(int device, cpu_set_t *out);
-// (ADVICE r4) looked up once per device and process - two sysfs reads and a PCI query are not something to do while a resident kernel's clusters
-// already spin; a change of the process's affinity mask after the first plan on a device is not followed
-static bool device_numa_cpus(int device, cpu_set_t *out) {
-    struct Entry { bool ok; cpu_set_t set; };
-    static std::mutex lock;
-    static std::map<int, Entry> cache;
-    std::lock_guard<std::mutex> g(lock);
-    auto it = cache.find(device);
-    if (it == cache.end()) { Entry e; e.ok = device_numa_cpus_uncached(device, &e.set); it = cache.emplace(device, e).first; }
-    if (it->second.ok) *out = it->second.set;
-    return it->second.ok;
-}
-static bool device_numa_cpus_uncached(int device, cpu_set_t *out) {
-    char bdf[64] = {0};
-    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return false;
-    for (char *c = bdf; *c; c++) *c = (char)std::tolower(*c);
-    int node = -1;
-    { const std::string p = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node"; if (FILE *f = std::fopen(p.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); } }
-    if (node < 0) return false;
-    std::string list;
-    { const std::string p = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"; if (FILE *f = std::fopen(p.c_str(), "r")) { char buf[4096] = {0}; if (std::fgets(buf, sizeof(buf), f)) list = buf; std::fclose(f); } }
-    if (list.empty()) return false;
-    cpu_set_t allowed, want;
-    CPU_ZERO(&allowed); CPU_ZERO(&want);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
-    for (size_t i = 0; i < list.size();) {                                   // "0-63,128-191"
-        if (!std::isdigit((unsigned char)list[i])) { i++; continue; }
-        size_t j = i; int a = 0; while (j < list.size() && std::isdigit((unsigned char)list[j])) a = 10 * a + (list[j++] - '0');
-        int b = a;
-        if (j < list.size() && list[j] == '-') { j++; b = 0; while (j < list.size() && std::isdigit((unsigned char)list[j])) b = 10 * b + (list[j++] - '0'); }
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
-        i = j;
-    }
-    if (CPU_COUNT(&want) < 2) return false;                                 // nothing (or a single CPU) of that node is ours: leave the threads where they are
-    *out = want;
-    return true;
-}
-
 // final generate (CPU.hpp:1258-1263) and the reference's return value (CPU.hpp:1267)
 static int finish_optimize(frx_problem *p, const double *x, double *C, double *T, double *jerk_cost) {
     int rc;
@@ -1833,6 +1857,25 @@ int frx_debug_trace(const frx_problem *p, double *out, int cap_rows) {
 int frx_debug_set_takeover_at(frx_problem *p, long rounds) {
     if (!p) return fail(FRX_ERR_INVALID_ARG, "null argument");
     p->takeover_at = rounds > 0 ? rounds : 0;
+    return FRX_OK;
+}
+int frx_debug_shader_clock(int device, double ms, double *mhz_min, double *mhz_mean, double *mhz_max) {
+    if (ms <= 0.0 || ms > 100.0) return fail(FRX_ERR_INVALID_ARG, "frx_debug_shader_clock: 0 < ms <= 100");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int blocks = std::max(1, prop.multiProcessorCount);
+    DevBuf<double> out; DevBuf<unsigned long long> st;
+    if (out.alloc(1) != hipSuccess || st.alloc((size_t)2 * blocks) != hipSuccess) return fail(FRX_ERR_ALLOC, "clock probe buffers");
+    HIP_TRY((hipError_t)frx::launch_clock_probe(out.p, st.p, blocks, (unsigned long long)(ms * 1e5), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)2 * blocks);
+    HIP_TRY(hipMemcpy(h.data(), st.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    double lo = 1e30, hi = 0.0, sum = 0.0;
+    for (int b = 0; b < blocks; b++) { const double mhz = 100.0 * (double)h[2 * b] / (double)std::max<unsigned long long>(1, h[2 * b + 1]); lo = std::min(lo, mhz); hi = std::max(hi, mhz); sum += mhz; }
+    if (mhz_min) *mhz_min = lo;
+    if (mhz_mean) *mhz_mean = sum / blocks;
+    if (mhz_max) *mhz_max = hi;
     return FRX_OK;
 }
 int frx_debug_taken_over(const frx_problem *p, int *candidates) {

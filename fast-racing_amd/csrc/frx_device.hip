@@ -115,6 +115,28 @@ int launch_lbfgs_post(const DvLaunch &dv, const double *f, const void *cmd, void
     return (int)hipGetLastError();
 }
 
+
+// Diagnostic (bench): the shader clock the device SUSTAINS under a latency-bound FP64 load like the round kernel's - one lone wave per CU on every CU running a
+// dependent FMA chain for ~`ms` milliseconds - as shader cycles (s_memtime) per tick of the constant 100 MHz counter.  Boxes of the pool differ by 3-6 % per round
+// with the SAME code object (profiles/NOTES.md); a round is a chain of dependent instructions, so its time is cycles / clock, and this is the clock.
+__global__ __launch_bounds__(64) void k_clock_probe(double *out, unsigned long long *stamps, unsigned long long ticks) {
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+    double a = 1.0 + threadIdx.x * 1e-9, b = 0.999999999;
+    unsigned long long w1 = w0;
+    while (w1 - w0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 256; i++) a = __builtin_fma(a, b, 1e-12);
+        w1 = wall_clock64();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = w1 - w0; }
+    if (a == 12345.678) out[0] = a;                                      // (keeps the chain)
+}
+int launch_clock_probe(double *out, unsigned long long *stamps, int blocks, unsigned long long ticks, void *stream) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(64), 0, (hipStream_t)stream, out, stamps, ticks);
+    return (int)hipGetLastError();
+}
+
 size_t dilate_lds_bytes(int pcap) { return sizeof(double) * ((size_t)3 * pcap + 32 + 36 + 16) + sizeof(int) * ((size_t)2 * pcap + 257 + 3); }
 int launch_dilate(const DilateLaunch &d, void *stream) {
     DilateArgs a;

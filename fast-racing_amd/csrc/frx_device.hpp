@@ -136,6 +136,7 @@ struct DilateLaunch {
     int *n_planes; double *h_rec, *ell_C, *ell_d;
 };
 size_t dilate_lds_bytes(int pcap);
+int launch_clock_probe(double *out, unsigned long long *stamps, int blocks, unsigned long long ticks, void *stream);   // stamps [2 blocks]: shader cycles, 100 MHz ticks per block
 int launch_dilate(const DilateLaunch &d, void *stream);
 
 } // namespace frx

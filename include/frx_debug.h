@@ -95,6 +95,11 @@ int frx_debug_taken_over(const frx_problem *p, int *candidates);
 int frx_debug_set_takeover_at(frx_problem *p, long rounds);
 int frx_debug_compact_from_history(int m, int n, int hs, int bound, int newest, const double *S, const double *Y, double *rinv129, double *yy, double *vd);
 
+/* Diagnostic (bench): the shader clock the device sustains under a latency-bound FP64 load (one lone wave per CU on every CU, a dependent FMA chain for `ms`
+ * milliseconds): shader cycles per tick of the constant 100 MHz counter, as MHz - minimum, mean and maximum over the CUs' workgroups.  A round of the resident kernel
+ * is a chain of dependent instructions: its time is cycles / this clock, which is what differs between the boxes of a pool running the same code object. */
+int frx_debug_shader_clock(int device, double ms, double *mhz_min, double *mhz_mean, double *mhz_max);
+
 #ifdef __cplusplus
 }
 #endif

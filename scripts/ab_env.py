@@ -38,6 +38,7 @@ if os.environ.get("AB_KAPPA48"):
     r = prob.optimize(tol, x0=x0)
     out["plumbing_k48"] = {"us_per_round": round(1e3 * r["ms_total"] / r["rounds"], 3), "rounds": int(r["rounds"]), "plan_ms": round(r["ms_total"], 2), "resident": int(r["resident"])}
     prob.close()
+out["sclk_mhz"] = [round(v, 1) for v in frx.shader_clock(0, 3.0)]
 print(json.dumps(out))
 '''
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
