@@ -464,7 +464,7 @@ def main():
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
     fp64 = None
     fp64_dyn = None                                                     # dynamic counts of the same gpurun call's counter pass (scripts/r05/gpu_pmc.sh), per launch class
-    fc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_fp64_count_k_penalty.json", "r04_fp64_count_k_penalty.json", "r02_fp64_count_k_penalty.json")) if os.path.exists(f)), "")
+    fc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_fp64_count_k_penalty.json", "r05_fp64_count_k_penalty.json", "r04_fp64_count_k_penalty.json", "r02_fp64_count_k_penalty.json")) if os.path.exists(f)), "")
     if os.path.exists(fc):
         fj = json.load(open(fc))
         fl = fj["flops_per_sample_no_violation"]
@@ -475,7 +475,7 @@ def main():
     # read from profiles/, never measured inside this process - hence "from_profile".  FETCH_SIZE / WRITE_SIZE are converted to bytes with the
     # factors calibrated in the same call on a coalesced copy of known size (8-byte and 16-byte accesses per lane).
     traffic, traffic_src, valu, knot_traffic, calib, one_traffic = None, None, None, {}, None, None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_headline.json", "r04_pmc_headline.json", "r03_pmc_headline.json")) if os.path.exists(f)), None)
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_headline.json", "r05_pmc_headline.json", "r04_pmc_headline.json", "r03_pmc_headline.json")) if os.path.exists(f)), None)
     if pmc_file and args.config == "headline":
         pj = json.load(open(pmc_file))
         traffic, traffic_src, calib = pj["traffic_bytes_per_launch"], os.path.relpath(pmc_file, ROOT), {k: v["bytes_per_counted_byte"] for k, v in pj["calibration"].items()}
@@ -497,8 +497,17 @@ def main():
         cls = sorted(pj.get("valu_k_penalty_lat", {}).items(), key=lambda kv: int(kv[0].split("_")[1]))          # launch classes by grid size: headline, large batch
         if cls:
             valu = {"from_profile": True, "source": traffic_src, "headline_valu_busy": cls[0][1]["valu_busy_frac"], "large_batch_valu_busy": cls[-1][1]["valu_busy_frac"],
-                    "large_batch_waves_per_simd": cls[-1][1]["mean_waves_per_simd"], "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"]}
+                    "large_batch_waves_per_simd": cls[-1][1]["mean_waves_per_simd"], "valu_insts_per_wave": cls[-1][1]["valu_insts_per_wave"],
+                    "large_batch_non_fp64_valu_frac": cls[-1][1].get("non_fp64_valu_frac"), "large_batch_wait_frac_of_wave_cycles": cls[-1][1].get("wait_frac_of_wave_cycles"),
+                    "dynamic_instructions_headline": pj.get("dynamic_instructions_headline")}
 
+    if pmc_file and args.config == "montecarlo4096":
+        # the knot kernels at Monte-Carlo scale: counter traffic of the 512-candidate launches of the same record call (kernel_sweep.py --batches 32,512,1024)
+        pj = json.load(open(pmc_file))
+        traffic_src = os.path.relpath(pmc_file, ROOT)
+        for kname, key in (("k_forward_knot", "forward"), ("k_backward_knot", "adjoint")):
+            e = pj["kernels"].get(kname, {}).get("grid_%d" % (256 * B))
+            if e: knot_traffic[key] = e.get("traffic_bytes_per_launch_range")
     # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
     # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
     large = None
@@ -704,7 +713,7 @@ def main():
                      "fp64_flops_per_round": pen_flops + dir_flops, "fp64_flops_penalty": pen_flops, "fp64_flops_direction": dir_flops,
                      "fp64_frac": (pen_flops + dir_flops) / (us_round * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
                      "bound": "latency: per candidate a round is ONE dependent chain (direction -> forward map -> penalty -> adjoint) on 8 of the chip's 256 CUs"}
-        for name in ("r05_round_budget_B32.json", "r04_round_budget_B32.json", "r03_round_budget_B32.json"):
+        for name in ("r06_round_budget_B32.json", "r05_round_budget_B32.json", "r04_round_budget_B32.json", "r03_round_budget_B32.json"):
             bp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(bp) and args.config == "headline":
                 try:

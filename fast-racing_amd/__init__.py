@@ -603,3 +603,27 @@ class Problem:
     def samples(self) -> int:
         """constraint samples per evaluation: pieces x (kappa + 1)."""
         return self.P * (self.kappa + 1)
+
+
+class PenaltyProblem(Problem):
+    """The inner boundary on its own (frx_penalty_problem_create): a handle built from what cuda_computer::compute receives on every call - per piece the index of
+    its H-polytope (idxHs), the polytopes (cfgHs), the scalar limits and weights - serving `penalty` / `penalty_device` only (cuda_computer.cuh:118-134)."""
+
+    def __init__(self, params: dict, piece_n, piece_poly, h_polys, device: int = 0, **override):
+        self.cfg = FrxConfig.from_params(params, **override)
+        self.kappa = int(self.cfg.qd_intervals)
+        piece_n = np.ascontiguousarray(piece_n, dtype=np.int32); piece_poly = np.ascontiguousarray(piece_poly, dtype=np.int32)
+        h_off = np.zeros(len(h_polys) + 1, dtype=np.int32)
+        for i, hp in enumerate(h_polys):
+            h_off[i + 1] = h_off[i] + hp.shape[1]
+        h_rec = np.ascontiguousarray(np.concatenate([hp.T.reshape(-1) for hp in h_polys]), dtype=np.float64)
+        h = C.c_void_p()
+        _check(lib().frx_penalty_problem_create(C.byref(self.cfg), device, len(piece_n), C.c_void_p(piece_n.ctypes.data), C.c_void_p(piece_poly.ctypes.data),
+                                                C.c_void_p(h_off.ctypes.data), C.c_void_p(h_rec.ctypes.data), C.byref(h)))
+        self.h = h
+        t = np.zeros(6, dtype=np.int32)
+        _check(lib().frx_problem_totals(self.h, t))
+        self.B, self.P, self.Pc, self.NX, self.Kmax, self.sum_K = (int(v) for v in t)
+        self.piece_off = np.zeros(self.B + 1, np.int32); self.coarse_off = np.zeros(self.B + 1, np.int32)
+        self.x_off = np.zeros(self.B + 1, np.int32); self.dim_t = np.zeros(self.B, np.int32)
+        _check(lib().frx_problem_layout(self.h, self.piece_off, self.coarse_off, self.x_off, self.dim_t))

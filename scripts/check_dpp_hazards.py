@@ -27,7 +27,11 @@ def disassemble(lib):
         subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=td, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         co = [f for f in os.listdir(td) if "gfx950" in f]
         if not co: raise RuntimeError("no gfx950 code object in " + lib)
-        return subprocess.run([OBJDUMP, "-d", "--symbolize-operands", co[0]], cwd=td, check=True, capture_output=True, text=True).stdout.split("\n")
+        out = []                                                # one code object per device translation unit (three since round 6): all of them
+        for c in sorted(co):
+            out += subprocess.run([OBJDUMP, "-d", "--symbolize-operands", c], cwd=td, check=True, capture_output=True, text=True).stdout.split("\n")
+            out.append("<end of code object>:")
+        return out
 
 
 def scan(lines):

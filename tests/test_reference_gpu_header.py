@@ -91,3 +91,60 @@ def test_reference_gpu_header_runs_the_hip_integrator_through_its_own_call_site(
     c1, _, _ = cpu.penalty(T, Cf)
     c2, _, _ = gpu.penalty(T, Cf)
     assert abs(c2 - 2.0 * c1) <= 1e-9 * abs(2.0 * c1) + 1e-300
+
+
+@pytest.mark.gpu
+def test_penalty_only_handle_matches_the_oracle_and_accumulates(frx, sc, ob):
+    """frx_penalty_problem_create through ctypes: a ragged batch of three candidates whose pieces SHARE polytopes (two fine pieces per corridor cell, as gridMesh
+    produces with a finite gridRes), the integrator alone against the oracle's addTimeIntPenalty at 1e-9, accumulating like cuda_computer::compute (cc.cu:551-558);
+    the outer boundary's entry points refuse such a handle."""
+    kappa = 16
+    cands = [sc.make_candidate(40, 12, 3), sc.make_candidate(41, 16, 4, obstacles=True), sc.make_candidate(42, 8, 2)]
+    polys, piece_n, piece_poly, Ts, Cs, refs = [], [], [], [], [], []
+    for c in cands:
+        o = ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=kappa)
+        x = o.optimize(1e-6, max_iterations=25)["x"]
+        T, _, Cf = o.forward(x)
+        base = len(polys)
+        polys += list(c.h_polys)
+        # every piece split in two halves that share the cell's polytope: [c(t)] on [0, T/2] and the re-expanded quintic on [T/2, T]
+        n = 0
+        for i in range(c.coarse_n):
+            h = 0.5 * T[i]
+            co = Cf[6 * i:6 * i + 6]                                        # rows = powers
+            from math import comb
+            sh = np.array([[comb(kk, j) * h ** (kk - j) if kk >= j else 0.0 for kk in range(6)] for j in range(6)])   # coefficients of c(t + h)
+            Ts += [h, h]; Cs += [co, sh @ co]; piece_poly += [base + i, base + i]; n += 2
+        piece_n.append(n)
+        # the oracle on the SAME split trajectory: a candidate with every cell listed twice
+        refs.append((c, T, Cf))
+    T_all = np.array(Ts); C_all = np.concatenate(Cs)
+    pp = frx.PenaltyProblem(sc.ZHANGJIAJIE, piece_n, piece_poly, polys, qd_intervals=kappa)
+    assert pp.P == sum(piece_n) and pp.B == 3
+    cost, gdT, gdC = pp.penalty(T_all, C_all)
+    # reference: the oracle's penalty of each half-piece = its penalty on a one-piece-per-cell candidate whose cells are duplicated; computed piece by piece through
+    # a one-cell oracle is overkill - the integrand is local to a piece, so the oracle of the ORIGINAL candidate evaluated on the split pieces is built from
+    # single-piece problems sharing the parameters
+    off = 0
+    for b, (c, T, Cf) in enumerate(refs):
+        tot = 0.0
+        for i in range(c.coarse_n):
+            for hlf in range(2):
+                one = sc.Candidate(c.ini_state, c.fin_state, [c.h_polys[i]], [c.v_polys[2 * i]])
+                o1 = ob.Oracle(one, sc.ZHANGJIAJIE, qd_intervals=kappa)
+                c1, t1, g1 = o1.penalty(T_all[off:off + 1], C_all[6 * off:6 * off + 6])
+                tot += c1
+                assert abs(gdT[off] - t1[0]) <= 1e-9 * max(abs(t1[0]), 1e-300) + 1e-12 * abs(c1)
+                assert np.abs(gdC[6 * off:6 * off + 6] - g1).max() <= 1e-9 * max(np.abs(g1).max(), 1e-300) + 1e-12 * abs(c1)
+                off += 1
+        assert abs(cost[b] - tot) <= 1e-9 * max(abs(tot), 1e-300)
+    # accumulation: a second call adds to what the caller passes in (here through the raw entry point)
+    import ctypes as Cc
+    cost2 = cost.copy(); gdT2 = gdT.copy(); gdC2 = np.ascontiguousarray(gdC.reshape(-1)).copy()
+    assert frx.lib().frx_penalty_eval(pp.h, T_all, np.ascontiguousarray(C_all.reshape(-1)), cost2, gdT2, gdC2) == 0
+    assert np.allclose(cost2, 2.0 * cost, rtol=1e-15) and np.allclose(gdT2, 2.0 * gdT, rtol=1e-15, atol=0.0) and np.allclose(gdC2, 2.0 * gdC.reshape(-1), rtol=1e-15, atol=0.0)
+    with pytest.raises(frx.FrxError, match="penalty_eval"):
+        pp.initial_guess()
+    with pytest.raises(frx.FrxError, match="penalty_eval"):
+        pp.objective(np.zeros(pp.NX))
+    pp.close()
