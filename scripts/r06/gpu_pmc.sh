@@ -4,6 +4,7 @@
 #   VALU utilisation  SQ counters of k_penalty_lat on both batches
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+[ -x $R/scripts/micro/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $R/scripts/micro/fetch_calib $R/scripts/micro/fetch_calib.hip
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc6_cal_$c -o p -- $R/scripts/micro/fetch_calib > /dev/null 2> $R/gpurun_out/pmc6_cal_$c.err
 done
