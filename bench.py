@@ -430,8 +430,14 @@ def main():
     # "full objective evaluation fused on device"; the penalty integrator alone (the stage kernel) moves to roofline.penalty_integrator.
     fused_G = prob.eval_fused()
     one_us = min(prob.eval_launch_time(x_state, reps=max(args.steps, 100)) for _ in range(3)) if fused_G else None   # (best of three brackets: a bracket of direct launches also holds the launch path's gaps)
+    # batches beyond the clusters' reach in the window where it wins (a GPU's share of the Monte-Carlo config): the SOLO launch - one workgroup per candidate runs the three
+    # stage bodies back to back (csrc/frx_solo_kernel.hpp; bit-identical results); timed here in both forms
+    solo_wgs = prob.eval_solo()
+    solo_us = min(prob.eval_launch_time(x_state, reps=max(args.steps, 100)) for _ in range(3)) if solo_wgs else None
     prob.set_eval_fused(False)
+    prob.set_eval_solo(0)
     three_us = min(prob.eval_launch_time(x_state, reps=max(args.steps, 100)) for _ in range(3))
+    prob.set_eval_solo(1)
     prob.set_eval_fused(True)
     # evaluation time along the optimisation (SURVEY.md 8d "kernel-only benchmark state"): the reference initial guess and the iterates
     # after 10 / 20 / 40 / 80 iterations; the headline `value` is taken at the 60-iteration state above
@@ -736,18 +742,21 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_host_wall": dt_wall / args.steps * 1e3, "value_host_wall": world * samples_per_step * args.steps / dt_wall,
             "timing": "HIP events on the launch stream around the K steps (first launch -> last kernel end), inside the barrier + synchronize bracket whose host wall clock is ms_per_step_host_wall; max over ranks",
-            "launch": ((f"ONE hipGraph of the K steps ({'K kernel nodes: one k_eval_cluster launch per step' if fused_G else '3 K kernel nodes'}, captured from K calls of frx_objective_eval_device)") if graph is not None
-                       else (graph_note or ("K direct launches of k_eval_cluster" if fused_G else "K x 3 direct kernel launches"))),
+            "launch": ((f"ONE hipGraph of the K steps ({'K kernel nodes: one k_eval_cluster launch per step' if fused_G else 'K kernel nodes: one k_eval_solo launch per step' if solo_wgs else '3 K kernel nodes'}, captured from K calls of frx_objective_eval_device)") if graph is not None
+                       else (graph_note or ("K direct launches of k_eval_cluster" if fused_G else "K direct launches of k_eval_solo" if solo_wgs else "K x 3 direct kernel launches"))),
             "evaluation_form": ({"kernel": "frx::k_eval_cluster", "workgroups_per_candidate": fused_G, "what": "one launch per evaluation: a cluster of workgroups per candidate (leader: forward map and adjoint; members: penalty integral), csrc/frx_eval_kernel.hpp",
                                  "us_per_evaluation_back_to_back_launches": one_us, "us_per_evaluation_as_three_stage_launches": three_us}
-                                if fused_G else {"kernel": "three stage kernels", "us_per_evaluation_back_to_back_launches": three_us}),
+                                if fused_G else
+                                {"kernel": "frx::k_eval_solo", "workgroups_per_cu": solo_wgs, "what": "one launch per evaluation: ONE workgroup per candidate runs forward map, penalty integral of its own pieces and adjoint back to back (the stage kernels' bodies; bit-identical results), csrc/frx_solo_kernel.hpp",
+                                 "us_per_evaluation_back_to_back_launches": solo_us, "us_per_evaluation_as_three_stage_launches": three_us}
+                                if solo_wgs else {"kernel": "three stage kernels", "us_per_evaluation_back_to_back_launches": three_us}),
             "warmup_graph_replays": GRAPH_WARM_REPLAYS if graph is not None else 0,
             "ms_per_step_graph_replayed_back_to_back": (dt_b2b / args.steps * 1e3) if dt_b2b else None,
             "ms_per_step_direct_launches": dt_direct / args.steps * 1e3, "value_direct_launches": world * samples_per_step * args.steps / dt_direct,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {B} candidate trajs/GPU x {N} pieces x {kappa} quadrature intervals "
                                    f"({samples_per_step} constraint samples/step/GPU), 16-gate Zhangjiajie-like corridor, K_i=8",
-                       "step": "one batched objective evaluation x->(f,grad), inputs resident in HBM: " + ("forward map + penalty integral + adjoint in ONE launch (k_eval_cluster)" if fused_G else "k_forward + k_penalty + k_backward"),
+                       "step": "one batched objective evaluation x->(f,grad), inputs resident in HBM: " + ("forward map + penalty integral + adjoint in ONE launch (k_eval_cluster)" if fused_G else "forward map + penalty integral + adjoint in ONE launch (k_eval_solo: one workgroup per candidate)" if solo_wgs else "k_forward + k_penalty + k_backward"),
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective",
                        "front_end": ("frx_multi_* in one process" if lib_mode else "one process per GPU (torch.distributed)") if world > 1 else "one process, one device"},
@@ -774,12 +783,12 @@ def main():
                              "traffic": traffic, "traffic_from_profile": traffic is not None, "traffic_source": traffic_src, "counter_calibration_bytes_per_counted_byte": calib,
                              "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6), "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)}),
                          "fp64": fp64, "valu": valu, "large_batch": large,
-                         "evaluation": {"what": "one whole step x -> (f, grad) as timed (`value`): forward map + penalty integrator + adjoint, " + ("one launch" if fused_G else "three launches"),
+                         "evaluation": {"what": "one whole step x -> (f, grad) as timed (`value`): forward map + penalty integrator + adjoint, " + ("one launch (clusters)" if fused_G else "one launch (one workgroup per candidate)" if solo_wgs else "three launches"),
                                         "algorithmic_bytes_per_step": eval_bytes, "definition": "SURVEY.md 8d: penalty bytes + 16 n + 24 sum(nv) per candidate",
                                         "us_per_step": dt / args.steps * 1e6, "achieved": eval_bytes / (dt / args.steps) / 1e9, "unit": "GB/s",
                                         "frac": eval_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_kernels_us": stage_us,
-                         "stage_kernels_note": "the three stage kernels of an evaluation, one at a time" + (" (not what the timed steps launched: see evaluation_form)" if fused_G else ""),
+                         "stage_kernels_note": "the three stage kernels of an evaluation, one at a time" + (" (not what the timed steps launched: see evaluation_form)" if (fused_G or solo_wgs) else ""),
                          "knot_kernels": {k: {"kernel": {"forward": "frx::k_forward_knot64", "adjoint": "frx::k_backward_knot64"}[k] if N <= 64 else {"forward": "frx::k_forward_knot", "adjoint": "frx::k_backward_knot"}[k], "avg_kernel_us": stage_us[k],
                                               "implementation_traffic_bytes": stage_bytes[k],
                                               "implementation_traffic_note": "x, waypoint polytopes, (T, C), out20, saved reduction multipliers, g: stage buffers between the three launches, NOT algorithmic bytes",

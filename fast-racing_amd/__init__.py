@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
     "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
-    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
+    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_debug_set_eval_solo", "frx_debug_eval_solo", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
 ]
 
 _lib = None
@@ -118,6 +118,8 @@ def lib():
         L.frx_eval_launch_time.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
         L.frx_debug_set_eval_fused.argtypes = [C.c_void_p, C.c_int]
         L.frx_debug_eval_fused.argtypes = [C.c_void_p]
+        L.frx_debug_set_eval_solo.argtypes = [C.c_void_p, C.c_int]
+        L.frx_debug_eval_solo.argtypes = [C.c_void_p]
         L.frx_debug_profile_eval_cluster.argtypes = [C.c_void_p, _dp, C.c_void_p]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_multi_destroy.argtypes = [C.c_void_p]
@@ -595,6 +597,23 @@ class Problem:
     def eval_fused(self) -> int:
         """Workgroups per candidate of the one-launch evaluation in use, 0 = one launch per stage."""
         return int(lib().frx_debug_eval_fused(self.h))
+
+    def set_eval_solo(self, mode: int):
+        """Diagnostic: 0 = never the solo form (one workgroup per candidate, one launch per evaluation, frx_solo_kernel.hpp), 1 = from the handle's batch-size
+        threshold on (default), 2 = at every batch size."""
+        _check(lib().frx_debug_set_eval_solo(self.h, int(mode)))
+
+    def solo_applies(self) -> bool:
+        """Does the solo form exist for this handle's geometry (<= 64 pieces and samples per piece, knot solver)?"""
+        was = int(lib().frx_debug_set_eval_solo(self.h, 2))
+        if was != 0: return False
+        ok = self.eval_solo() >= 1
+        _check(lib().frx_debug_set_eval_solo(self.h, 1))
+        return ok
+
+    def eval_solo(self) -> int:
+        """Workgroups of the solo kernel a CU holds if the next evaluation takes that form, 0 = it does not."""
+        return int(lib().frx_debug_eval_solo(self.h))
 
     def algorithmic_bytes(self) -> int:
         """Penalty-kernel bytes per evaluation, SURVEY.md §8d: sum over pieces of 312 + 48 K_i."""

@@ -270,6 +270,8 @@ struct frx_problem {
     DevBuf<unsigned char> d_ev_args;
     PinBuf<unsigned> h_ev_status;                           // mapped host word: the code of an expired wait, written by the leader that saw it - launch_eval reads it without a synchronisation
     unsigned eval_fused_code = 0;                           // the code that retired the one-launch form on this handle (0: none)
+    // one launch per evaluation for LARGE batches (frx_solo_kernel.hpp: one workgroup per candidate): 0 = never, 1 = from eval_solo_min_B candidates on (default), 2 = always
+    int eval_solo = 0, eval_solo_min_B = 0, eval_solo_max_B = 0;
     frx::LaunchGeom geo;
     bool banded_ok = true;
     bool penalty_only = false;              // frx_penalty_problem_create: the inner boundary alone (no variables, no waypoint polytopes: only frx_penalty_eval[_device] apply)
@@ -286,6 +288,9 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
     // handle takes the stage kernels by itself - also on the capturable _device form and inside the host-vector L-BFGS, which have no status check of their own.
     // No HIP call here (the caller may be capturing): the device's sticky word is cleared at the next host-synchronous point (eval_cluster_status).
     if (p->eval_fused && p->h_ev_status.p && *(volatile unsigned *)p->h_ev_status.p != 0u) { p->eval_fused_code = *(volatile unsigned *)p->h_ev_status.p; p->eval_fused = 0; }
+    const bool solo_ok = backward && p->geo.lds_solo && p->geo.solver == frx::SOLVER_KNOT_PCR && (!p->dp.stamps || p->eval_solo == 2);   // (cycle stamps of the stage kernels' phases: frx_profile_phases; the forced form carries them too)
+    auto solo = [&]() { return frx::launch_eval_solo(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, p->d_out20.p, f_dev, g_dev, st, p->tap_d, p->tap_flags, p->tap_res, p->tap_arrive, p->tap_flag, p->tap_round); };
+    if (solo_ok && p->eval_solo == 2) return solo();                          // (forced: tests and measurements at batch sizes the other forms would take)
     if (backward && p->eval_fused && p->geo.solver == frx::SOLVER_KNOT_PCR && !p->tap_d && !p->dp.cand_active && (!p->dp.stamps || p->eval_fused_stamps)) {
         // the handle's constant arguments live in device memory (uploaded at create); they only change when a diagnostic switches the cycle stamps on or off -
         // a synchronous copy then (never inside somebody's capture: the diagnostics are blocking calls of their own)
@@ -296,6 +301,9 @@ int launch_eval(frx_problem *p, const double *x_dev, double *f_dev, double *g_de
         }
         return frx::launch_eval_cluster(p->geo, p->B, p->ev_args.data(), p->d_ev_args.p, x_dev, f_dev, g_dev, p->eval_fused_ticks, st, p->h_ev_status.p);
     }
+    // batches beyond the clusters' reach: one workgroup per candidate runs the three stage bodies back to back - plain evaluations AND the optimiser's rounds (same
+    // stage buffers, tap and skipped candidates as the three launches; bit-identical results)
+    if (solo_ok && p->eval_solo == 1 && p->B >= p->eval_solo_min_B && p->B <= p->eval_solo_max_B) return solo();
     int e = frx::launch_forward(p->dp, p->geo, x_dev, p->d_T.p, p->d_C.p, backward ? p->d_band.p : (double *)nullptr, st);
     if (e || !backward) return e;
     if ((e = frx::launch_penalty(p->dp, p->geo, p->d_T.p, p->d_C.p, p->d_out20.p, st))) return e;
@@ -487,6 +495,13 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         const bool shared_device = ranks > ndev && !(ef && ef[0] == '1');
         if (!G || (long long)B * G > cus || (ef && ef[0] == '0') || shared_device) { ge.ev_G = 0; ge.lds_ev = 0; }
         p->eval_fused_G = ge.ev_G; p->eval_fused = ge.ev_G ? 1 : 0;
+        // (the solo form: from the batch size on at which the stage launches' ramps and stage-buffer trips outweigh a lone workgroup's five penalty passes - measured,
+        // profiles/NOTES.md round 6; FRX_EVAL_SOLO=0 never, =1 always, FRX_EVAL_SOLO_MIN_B=n moves the threshold)
+        frx::eval_solo_geometry(ge);
+        p->eval_solo = ge.lds_solo ? 1 : 0; p->eval_solo_min_B = 416; p->eval_solo_max_B = 576;
+        if (const char *es = std::getenv("FRX_EVAL_SOLO")) { if (es[0] == '0') p->eval_solo = 0; else if (es[0] == '1' && ge.lds_solo) p->eval_solo = 2; }
+        if (const char *mb = std::getenv("FRX_EVAL_SOLO_MIN_B")) { const int v = std::atoi(mb); if (v > 0) p->eval_solo_min_B = v; }
+        if (const char *mb = std::getenv("FRX_EVAL_SOLO_MAX_B")) { const int v = std::atoi(mb); if (v > 0) p->eval_solo_max_B = v; }
         if (const char *tm = std::getenv("FRX_EVAL_TIMEOUT_MS")) { const double v = std::atof(tm); if (v > 0.0) p->eval_fused_ticks = (unsigned long long)(v * 1e5); }
     }
     const size_t lds_cap = 160 * 1024;
@@ -516,6 +531,8 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
     const double ms_host_build = ms_since(t_create0);
     CR(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     CR((hipError_t)frx::launch_set_limits(p->geo));
+    CR((hipError_t)frx::eval_solo_raise_limit(p->geo));
+    if (p->geo.lds_solo && frx::eval_solo_blocks_per_cu(p->geo) < 1) { p->geo.lds_solo = 0; p->eval_solo = 0; }
     if (p->geo.ev_G && frx::eval_cluster_blocks_per_cu(p->geo.lds_ev) < 1) { p->geo.ev_G = 0; p->geo.lds_ev = 0; p->eval_fused_G = 0; p->eval_fused = 0; }   // (the runtime's own occupancy answer: a CU must hold a workgroup of the cluster kernel)
     CR(p->d_cvoff.upload(cvoff)); CR(p->d_poff.upload(p->poff)); CR(p->d_coff.upload(p->coff)); CR(p->d_xoff.upload(p->xoff)); CR(p->d_boff.upload(p->boff));
     CR(p->d_piece_hbeg.upload(piece_hbeg)); CR(p->d_piece_K.upload(piece_K)); CR(p->d_piece_coarse.upload(piece_coarse)); CR(p->d_piece_iv.upload(piece_iv));
@@ -812,6 +829,20 @@ int frx_debug_set_eval_fused(frx_problem *p, int enable) {
     return FRX_OK;
 }
 int frx_debug_eval_fused(const frx_problem *p) { return (p && p->eval_fused) ? p->eval_fused_G : 0; }
+// Diagnostic (bench, tests): the solo form of an evaluation (one workgroup per candidate, one launch).  mode: 0 = never, 1 = from the handle's threshold on (the
+// default), 2 = at every batch size.  frx_debug_eval_solo: workgroups of the kernel a CU holds when the NEXT evaluation of this handle takes the form, 0 = it does not.
+int frx_debug_set_eval_solo(frx_problem *p, int mode) {
+    if (!p || mode < 0 || mode > 2) return fail(FRX_ERR_INVALID_ARG, "null argument or unknown mode");
+    if (mode && !p->geo.lds_solo) return fail(FRX_ERR_INVALID_ARG, "the solo form does not apply to this handle (more than 64 pieces or samples per piece, or the banded solver)");
+    p->eval_solo = mode;
+    return FRX_OK;
+}
+int frx_debug_eval_solo(const frx_problem *p) {
+    if (!p || !p->geo.lds_solo || p->geo.solver != frx::SOLVER_KNOT_PCR) return 0;
+    if (!(p->eval_solo == 2 || (p->eval_solo == 1 && p->B >= p->eval_solo_min_B && p->B <= p->eval_solo_max_B))) return 0;
+    if (p->eval_fused && p->eval_solo != 2) return 0;                          // (a plain evaluation of a batch the chip holds as clusters takes that form first)
+    return frx::eval_solo_blocks_per_cu(p->geo);
+}
 // Diagnostic (bench): average duration of one evaluation at x in the form frx_objective_eval_device takes, HIP events around `reps` back-to-back evaluations.
 int frx_eval_launch_time(frx_problem *p, const double *x, int reps, double *out_us) {
     if (!p || !x || !out_us || reps < 1) return fail(FRX_ERR_INVALID_ARG, "null argument or reps < 1");

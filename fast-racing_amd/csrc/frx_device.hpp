@@ -53,6 +53,7 @@ struct LaunchGeom {
     double *pcrw;                          // [(pcr_steps*8 + 4)][P] saved multipliers + final D^-1 per knot
     int ev_G = 0;                          // one-launch evaluation (frx_eval_kernel.hpp): workgroups per candidate, 0 = not applicable (more than 64 pieces, banded solver)
     size_t lds_ev = 0;
+    size_t lds_solo = 0;                   // one workgroup per candidate, one launch per evaluation (frx_solo_kernel.hpp): dynamic LDS, 0 = not applicable
 };
 
 // all return a hipError_t value as int (0 = hipSuccess); stream is a hipStream_t
@@ -78,6 +79,15 @@ int launch_eval_cluster(const LaunchGeom &g, int B, const void *args_host, const
 // workgroups of k_eval_cluster a CU holds with lds_bytes of dynamic LDS (occupancy query of the runtime; 0 on error)
 int eval_cluster_blocks_per_cu(size_t lds_bytes);
 int eval_cluster_raise_limit(size_t lds_bytes);                 // raises k_eval_cluster's dynamic-LDS limit on the current device (never lowers it)
+
+// One launch per evaluation for LARGE batches (frx_solo_kernel.hpp): one workgroup per candidate runs forward map, penalty integral and adjoint back to back.
+// Same stage buffers, same tap, same results (bit for bit) as launch_forward + launch_penalty + launch_backward.
+int eval_solo_geometry(LaunchGeom &g);                            // fills lds_solo; returns 1 when the form applies
+int eval_solo_raise_limit(const LaunchGeom &g);
+int eval_solo_blocks_per_cu(const LaunchGeom &g);                 // workgroups of the kernel a CU holds (occupancy query of the runtime; 0 on error)
+int launch_eval_solo(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *out20, double *f, double *grad, void *stream,
+                     const double *tap_d = nullptr, const int *tap_flags = nullptr, void *tap_res = nullptr,
+                     unsigned *tap_arrive = nullptr, volatile unsigned *tap_flag = nullptr, unsigned tap_round = 0);
 
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;

@@ -57,6 +57,12 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
  * 0 = one launch per stage.  The environment variable FRX_EVAL_FUSED=0 turns the form off for every handle created afterwards. */
 int frx_debug_set_eval_fused(frx_problem *p, int enable);
 int frx_debug_eval_fused(const frx_problem *p);
+/* The solo form of an evaluation (one workgroup per candidate runs forward map, penalty integral and adjoint in ONE launch; batches larger than the clusters of the
+ * one-launch form reach; the per-stage rounds of frx_optimize take it too).  mode 0 = never, 1 = from the handle's batch-size threshold on (default; FRX_EVAL_SOLO_MIN_B),
+ * 2 = at every batch size, also where the cluster form would apply.  Results are bit-identical to the three stage launches (replaces the same objectiveFunc,
+ * se3gcopter_cpu.hpp:961-1000).  frx_debug_eval_solo = workgroups of the kernel a CU holds if the next evaluation takes the form, 0 = it does not. */
+int frx_debug_set_eval_solo(frx_problem *p, int mode);
+int frx_debug_eval_solo(const frx_problem *p);
 /* Diagnostic (bench): average microseconds of one evaluation at x in the form frx_objective_eval_device takes, over `reps` back-to-back evaluations. */
 int frx_eval_launch_time(frx_problem *p, const double *x, int reps, double *out_us);
 /* Diagnostic: one evaluation at x in the one-launch form with shader-clock stamps of candidate 0's cluster: out64[0..12] forward map and [16..31] adjoint as

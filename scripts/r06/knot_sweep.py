@@ -23,6 +23,21 @@ for B in batches:
     for _ in range(3):
         t = prob.stage_times(xb, reps)
         best = t if best is None else {k: min(best[k], t[k]) for k in t}
+    # the whole evaluation as the library launches it: three stage launches against the solo form (one workgroup per candidate, one launch; frx_solo_kernel.hpp)
+    ev = {}
+    fused = prob.eval_fused()
+    if fused: prob.set_eval_fused(False)
+    for name, mode in (("three_launches", 0), ("solo", 2)):
+        if mode and not prob.solo_applies(): continue
+        prob.set_eval_solo(mode)
+        ev[name] = min(prob.eval_launch_time(xb, reps) for _ in range(3))
+    f3 = g3 = None
+    if "solo" in ev:
+        prob.set_eval_solo(0); f3, g3 = prob.objective(xb)
+        prob.set_eval_solo(2); f1, g1 = prob.objective(xb)
+        ev["solo_bit_identical"] = bool(np.array_equal(f1, f3) and np.array_equal(g1, g3))
+        ev["solo_workgroups_per_cu"] = prob.eval_solo()
     print(json.dumps({"candidates": B, **{k + "_us": round(v, 2) for k, v in best.items()}, "sum_us": round(sum(best.values()), 2),
+                      "eval_us": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ev.items()},
                       "ns_per_candidate": {k: round(1e3 * v / B, 1) for k, v in best.items()}}), flush=True)
     prob.close()
