@@ -554,11 +554,13 @@ def main():
     hbm_kernel = None
     if rank == 0 and args.large_batch > 0:
         n_x = int(np.max(np.diff(prob.x_off))); m_hist = 128; bl = 256
-        row = min(64 * w * e for e in (2, 4, 6, 8) for w in range(1, 9) if 64 * w * e >= n_x)   # padded row, frx::dv_geometry (768 at n ~ 704)
+        row = min(64 * w * e for e in (2, 4, 6, 8) for w in range(1, 9) if 64 * w * e >= n_x)   # the geometry's row, frx::dv_geometry (768 at n = 641) ...
+        tight = (n_x + 2 + 15) // 16 * 16                                  # ... stored as n + 2 rounded up to 16 doubles since round 6 (frx::dv_row_stride: 656 at n = 641)
+        if row >= 512 and tight < row: row = tight
         err, us = frx.dv_selftest(n_x, B=bl, m=m_hist, iters=160)
         byts = bl * m_hist * 2 * 2 * row * 8                               # S and Y rows, read once in each of the two loops
         hbm_kernel = {"kernel": "frx::k_lbfgs_pre", "candidates": bl, "history_pairs": m_hist, "vector_length": n_x, "avg_kernel_us": us,
-                      "bytes_per_launch": byts, "achieved": byts / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                      "history_row_doubles": row, "bytes_per_launch": byts, "achieved": byts / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                       "check_rel_err_vs_host_recursion": err}
         if pmc_file and "k_lbfgs_pre" in json.load(open(pmc_file)):         # counter pass of the same record call (scripts/r04/gpu_pmc.sh), calibrated in that call
             hbm_kernel["traffic"] = json.load(open(pmc_file))["k_lbfgs_pre"]["traffic_bytes_per_launch"]; hbm_kernel["traffic_source"] = os.path.relpath(pmc_file, ROOT); hbm_kernel["traffic_from_profile"] = True

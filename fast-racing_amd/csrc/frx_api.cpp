@@ -705,7 +705,8 @@ int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4
     frx::dv_geometry(n, &E, &W, &PF);
     if (geom4) { E = geom4[0]; W = geom4[1]; PF = geom4[2]; BLK = geom4[3]; }
     if (E == 0 || n > 64 * W * E) return fail(FRX_ERR_CAPACITY, "vector too long for k_lbfgs_pre");
-    const size_t HS = (size_t)64 * W * E, NX = (size_t)n * B;
+    const char *tight_env = std::getenv("FRX_DV_TIGHT");                          // (read per call: the A/B of the row stride runs both in one process)
+    const size_t HS = frx::dv_row_stride(n, E, W, !(tight_env && tight_env[0] == '0')), NX = (size_t)n * B;
     DevBuf<double> dx, dg, dxp, dgp, dd, dS, dY, dys, dgt; DevBuf<int> dxoff;
     PinBuf<frx::DvCommand> cmd; PinBuf<frx::DvResult> res;
     hipError_t e;
@@ -719,7 +720,7 @@ int frx_dv_selftest(int device, int n, int B, int m, int iters, const int *geom4
     HIP_TRY(hipMemcpy(dxoff.p, xoff.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice));
     frx::DvLaunch dv;
     dv.xoff = dxoff.p; dv.x = dx.p; dv.g = dg.p; dv.xp = dxp.p; dv.gp = dgp.p; dv.d = dd.p; dv.S = dS.p; dv.Y = dY.p; dv.ys = dys.p; dv.gt = dgt.p;
-    dv.ld = NX; dv.m = m; dv.B = B; dv.E = E; dv.W = W; dv.PF = PF; dv.BLK = BLK;
+    dv.ld = NX; dv.hs = HS; dv.m = m; dv.B = B; dv.E = E; dv.W = W; dv.PF = PF; dv.BLK = BLK;
     unsigned long long st = 0x9E3779B97F4A7C15ull * (seed + 1);
     auto rnd = [&]() { st += 0x9E3779B97F4A7C15ull; unsigned long long z = st; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; };
     std::vector<double> x(NX), g(NX), xp(NX), gp(NX), dref(n), ddev(NX);
@@ -1060,7 +1061,9 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
         if (std::sscanf(gs, "%d,%d,%d,%d", &e, &w, &pf, &blk) == 4 && p->geo.maxXb <= 64 * w * e) { E = e; W = w; PF = pf; BLK = blk; }
     }
     if (E == 0 || m > 512 || m < 1) return 1;                                  // caller falls back to host vectors
-    const size_t HS = (size_t)64 * W * E;
+    // rows as long as the longest candidate's vector needs (FRX_DV_TIGHT=0: the full 64 W E of round 5 - A/B)
+    const char *tight_env = std::getenv("FRX_DV_TIGHT");
+    const size_t HS = frx::dv_row_stride(p->geo.maxXb, E, W, !(tight_env && tight_env[0] == '0'));
     hipError_t e;
     if (p->dv_mem != m || p->dv_hs != HS) {
         p->dv_mem = 0; p->dv_hs = 0;
@@ -1085,7 +1088,7 @@ static int optimize_device_vectors(frx_problem *p, const frx_lbfgs_params &pm, d
     }
     frx::DvLaunch dv;
     dv.xoff = p->d_xoff.p; dv.x = p->d_x.p; dv.g = p->d_g.p; dv.xp = p->d_xp.p; dv.gp = p->d_gp.p; dv.d = p->d_dir.p;
-    dv.S = p->d_S.p; dv.Y = p->d_Y.p; dv.ys = p->d_ys.p; dv.gt = p->d_gt.p; dv.ld = (size_t)p->NX; dv.m = m; dv.B = B; dv.E = E; dv.W = W; dv.PF = PF; dv.BLK = BLK;
+    dv.S = p->d_S.p; dv.Y = p->d_Y.p; dv.ys = p->d_ys.p; dv.gt = p->d_gt.p; dv.ld = (size_t)p->NX; dv.hs = HS; dv.m = m; dv.B = B; dv.E = E; dv.W = W; dv.PF = PF; dv.BLK = BLK;
     std::memcpy(p->h_x.p, x, sizeof(double) * p->NX);
     HIP_TRY(hipMemcpyAsync(p->d_x.p, p->h_x.p, sizeof(double) * p->NX, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_ys.p, 0, sizeof(double) * (size_t)B * m, p->stream));

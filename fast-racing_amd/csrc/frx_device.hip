@@ -91,7 +91,7 @@ int launch_backward(const DevProblem &dp, const LaunchGeom &g, const double *x, 
 
 static DvBuffers to_buffers(const DvLaunch &dv) {
     DvBuffers b;
-    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.gt = dv.gt; b.dflags = dv.dflags; b.pflags = dv.pflags; b.poff = dv.poff; b.m = dv.m; b.B = dv.B;
+    b.xoff = dv.xoff; b.x = dv.x; b.g = dv.g; b.xp = dv.xp; b.gp = dv.gp; b.d = dv.d; b.S = dv.S; b.Y = dv.Y; b.ys = dv.ys; b.gt = dv.gt; b.dflags = dv.dflags; b.pflags = dv.pflags; b.poff = dv.poff; b.m = dv.m; b.B = dv.B; b.hs = dv.hs ? (int)dv.hs : 64 * dv.W * dv.E;
     return b;
 }
 int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream) {

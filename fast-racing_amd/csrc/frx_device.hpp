@@ -92,7 +92,7 @@ int launch_eval_solo(const DevProblem &dp, const LaunchGeom &g, const double *x,
 // ---- device-vector L-BFGS (frx_lbfgs_kernels.hpp) ----
 struct DvBuffers;
 struct DvLaunch {
-    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; int *dflags = nullptr, *pflags = nullptr; const int *poff = nullptr; size_t ld; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
+    const int *xoff; double *x, *g, *xp, *gp, *d, *S, *Y, *ys, *gt; int *dflags = nullptr, *pflags = nullptr; const int *poff = nullptr; size_t ld; size_t hs = 0; int m, B, E, W, PF, BLK;   // k_lbfgs_pre: E doubles per thread, W waves per candidate, PF history rows of look-ahead, BLK pairs per reduction
 };
 // E doubles per thread x W waves: the smallest padded row 64*W*E that holds n; among equal rows the one with FEWER waves
 // (every wave runs the whole serial chain of the recursion and the cross-wave part of a reduction grows with the wave count;
@@ -105,6 +105,15 @@ inline void dv_geometry(int n, int *E, int *W, int *PF) {
             const size_t hs = (size_t)64 * w * e;
             if ((size_t)n <= hs && hs < best) { best = hs; *E = e; *W = w; *PF = e == 2 ? 16 : e == 8 ? 4 : 8; }
         }
+}
+// Row stride of the history (doubles) for vectors of at most n elements under the geometry (E, W): tight - n + 2 rounded up to 16 - when only a thread's LAST pair can lie
+// beyond the row's end (k_lbfgs_pre reads such a pair from the row's zero tail), else the full 64 W E.
+inline size_t dv_row_stride(int n, int E, int W, bool tight = true) {
+    const size_t HS = (size_t)64 * W * E, hs = ((size_t)n + 2 + 15) & ~(size_t)15;
+    if (!tight || hs >= HS) return HS;
+    if (HS < 512) return HS;                                            // (short rows measured SLOWER tight: n = 200, 256 candidates, 50.0 -> 54.3 us per advance - profiles/r06_dv_tight_ab.jsonl)
+    if (hs / 2 <= (size_t)64 * W * (E / 2 - 1)) return HS;            // (a whole slab of pairs beyond the end: not the case the kernel clamps)
+    return hs;
 }
 int launch_lbfgs_pre(const DvLaunch &dv, const void *cmd, void *res, void *stream);
 

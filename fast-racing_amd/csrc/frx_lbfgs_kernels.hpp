@@ -19,14 +19,18 @@ struct DvBuffers {
     const int *xoff;          // [B+1]
     double *x, *g;            // packed evaluation input / output (the objective kernels read x, write g)
     double *xp, *gp, *d;      // packed
-    double *S, *Y;            // [B][m][TPB*E]  history: row = slot, rows zero-padded to TPB*E doubles, so every
-                              // thread can issue unconditional 16-byte loads (thread t owns elements 2*(t + TPB*q) + {0,1})
+    double *S, *Y;            // [B][m][hs]  history: row = slot, natural element order, zero beyond n; thread t owns elements 2*(t + TPB*q) + {0,1} and
+                              // issues unconditional 16-byte loads.  hs = TPB*E (every thread's pairs exist) or TIGHT (round 6): hs = n + 2 rounded up to 16
+                              // doubles - the pairs beyond the row's end are read from its LAST pair, which lies in the zero tail (same cache line as the
+                              // neighbours' loads: no traffic of their own).  The kernel is HBM-bound from ~100 candidates on and streams 4 m rows per accepted
+                              // step: at the headline n = 641 a row is 656 instead of 768 doubles, 14.6 % fewer bytes.
     double *ys;               // [B][m]   y.s per slot
     int *dflags;              // [B] device copy of this round's command flags (for k_backward_knot's LineSearchTap)
     int *pflags;              // [P] the same per fine piece (for k_penalty), or null
     const int *poff;          // [B+1] fine-piece offsets (with pflags)
     double *gt;               // [B][m][4] cross products s_j . y_{j+d}, d = 1..3 (entry 3 unused), see k_lbfgs_pre
     int m, B;
+    int hs;                   // row stride of S and Y in doubles (even; see above)
 };
 
 // One workgroup of W waves (TPB = 64 W threads) per candidate; E = doubles per THREAD (even), n <= TPB*E.  The host picks
@@ -122,7 +126,8 @@ __global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvComm
         // and are neutralised by a zero 1/(y.s).  Visit v lives in buffer v % PF and is requested PF visits ahead, unconditionally
         // (a conditional reload makes the compiler wait for the load at once).
         const int m = bf.m;
-        double *Sb = bf.S + (size_t)b * m * HS, *Yb = bf.Y + (size_t)b * m * HS;      // this candidate's [m][HS] history blocks
+        const int hs = bf.hs, hs2 = hs >> 1;                            // row stride (doubles), pairs per row
+        double *Sb = bf.S + (size_t)b * m * hs, *Yb = bf.Y + (size_t)b * m * hs;      // this candidate's [m][hs] history blocks
         double *ysrow = bf.ys + (size_t)b * m, *gtrow = bf.gt + (size_t)b * m * 4;
         const int jnew = c.slot, last = c.bound - 1;                   // newest pair; older pairs are jnew-1, jnew-2, ... (mod m)
         const int V1 = ((c.bound + PF - 1) / PF) * PF, pad = V1 - c.bound;               // table index = age + pad
@@ -138,17 +143,21 @@ __global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvComm
         }
         for (int v = t; v < 2 * V1 + PF; v += TPB) {
             const int a = v < V1 ? min(v, last) : max(last - (v - V1), 0);
-            voff[v] = row_of_age(a) * (int)(HS * sizeof(double));
+            voff[v] = row_of_age(a) * (int)(hs * sizeof(double));
         }
         lds_barrier();
         double sb[PF][E], yb[PF][E];
         const int toff = t * (int)sizeof(double2);
+        // the LAST pair of a thread may lie beyond a tight row's end: it is read from the row's last pair (zeros) instead - one offset per thread, fixed for the kernel
+        const bool last_in = t + TPB * (Q - 1) < hs2;
+        const int lastoff = (last_in ? t + TPB * (Q - 1) : hs2 - 1) * (int)sizeof(double2) - toff;
         auto load_row = [&](int u, int v) {                           // buffer u <- row of visit v
             const int off = voff[v] + toff;
             const double2 *Sj = (const double2 *)((const char *)Sb + off), *Yj = (const double2 *)((const char *)Yb + off);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const double2 a = Sj[TPB * q], bq = Yj[TPB * q];
+                const double2 a = q == Q - 1 ? *(const double2 *)((const char *)Sj + lastoff) : Sj[TPB * q];
+                const double2 bq = q == Q - 1 ? *(const double2 *)((const char *)Yj + lastoff) : Yj[TPB * q];
                 sb[u][2 * q] = a.x; sb[u][2 * q + 1] = a.y; yb[u][2 * q] = bq.x; yb[u][2 * q + 1] = bq.y;
             }
         };
@@ -165,9 +174,10 @@ __global__ __launch_bounds__(64 * W) void k_lbfgs_pre(DvBuffers bf, const DvComm
 #pragma unroll
             for (int e = 0; e < E; e++) { yb[0][e] = gv[e] - tmp[e]; hd[0] += yb[0][e] * sb[0][e]; hd[1] += yb[0][e] * yb[0][e]; dv[e] = -gv[e]; }
             store_vec(xp, xv); store_vec(gp, gv);                       // the accepted point becomes the base of the next search
-            double2 *Sw = (double2 *)(Sb + (size_t)jnew * HS), *Yw = (double2 *)(Yb + (size_t)jnew * HS);
+            double2 *Sw = (double2 *)(Sb + (size_t)jnew * hs), *Yw = (double2 *)(Yb + (size_t)jnew * hs);
 #pragma unroll
-            for (int q = 0; q < Q; q++) { Sw[t + TPB * q] = make_double2(sb[0][2 * q], sb[0][2 * q + 1]); Yw[t + TPB * q] = make_double2(yb[0][2 * q], yb[0][2 * q + 1]); }
+            for (int q = 0; q < Q; q++)
+                if (q < Q - 1 || last_in) { Sw[t + TPB * q] = make_double2(sb[0][2 * q], sb[0][2 * q + 1]); Yw[t + TPB * q] = make_double2(yb[0][2 * q], yb[0][2 * q + 1]); }   // (a pair beyond a tight row's end is zero and has no place)
             if (BLK > 1) {
 #pragma unroll
                 for (int d = 1; d < 4 && d < PF; d++)

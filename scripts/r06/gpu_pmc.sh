@@ -140,8 +140,8 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     out[name] = sum(v) / len(v) * 1024
 f16 = res["calibration"]["FETCH_SIZE_16B"]["bytes_per_counted_byte"]; w8 = res["calibration"]["WRITE_SIZE_8B"]["bytes_per_counted_byte"]
 res["k_lbfgs_pre"] = {"command": "frx_dv_selftest(n=641, B=256, m=128, iters=160)", "fetch_bytes_counted": out["FETCH_SIZE"], "write_bytes_counted": out["WRITE_SIZE"],
-                      "traffic_bytes_per_launch": out["FETCH_SIZE"] * f16 + out["WRITE_SIZE"] * w8, "algorithmic_bytes_per_launch": 256 * 128 * 2 * 2 * 768 * 8,
-                      "note": "history rows are read by 16-byte loads: FETCH_SIZE with the 16-byte calibration factor of this call"}
+                      "traffic_bytes_per_launch": out["FETCH_SIZE"] * f16 + out["WRITE_SIZE"] * w8, "algorithmic_bytes_per_launch": 256 * 128 * 2 * 2 * 656 * 8,
+                      "history_row_doubles": 656, "note": "history rows (n = 641: 656 doubles since round 6, 768 before) are read by 16-byte loads: FETCH_SIZE with the 16-byte calibration factor of this call"}
 json.dump(res, open("gpurun_out/r06_pmc_headline.json", "w"), indent=1)
 print("k_lbfgs_pre", res["k_lbfgs_pre"])
 PY
