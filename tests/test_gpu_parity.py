@@ -646,6 +646,36 @@ def test_two_phase_form_of_the_large_batch_integrator_is_bit_identical(frx, sc, 
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kappa", [16, 48])
+def test_large_batch_integrator_against_the_oracle_directly(frx, sc, ob, kappa):
+    """k_penalty_lat2 was pinned to k_penalty_lat (bit-identical) and only through it to the oracle.  Here the large-batch launch itself (320 candidates: four-wave
+    workgroups, the two-phase form; the instantiations for kappa = 16 and 48) is held against the oracle's addTimeIntPenalty (se3gcopter_cpu.hpp:188-408 restated) at the
+    per-evaluation tolerance, on the oracle's own (T, C), for candidates at the start, in the middle and at the end of the batch - with obstacles, K_i up to 14."""
+    B0, N, gates, _ = sc.CONFIGS["headline"]
+    base = [sc.make_candidate(0, N, gates, perturb_id=b, obstacles=(b % 3 == 0)) for b in range(B0)]
+    rep = 10
+    picks = [0, 3, 17, 31]
+    Ts, Cs, refs = [], [], {}
+    for b, c in enumerate(base):
+        o = ob.Oracle(c, sc.ZHANGJIAJIE, qd_intervals=kappa)
+        o.set_abscissa_mode(False)                                        # (the device's s = step * j, cc.cu:152)
+        x = o.optimize(1e-6, max_iterations=12)["x"] if b in picks else o.initial_guess()
+        T, _, Cf = o.forward(x)
+        Ts.append(T); Cs.append(Cf.reshape(-1))
+        if b in picks: refs[b] = o.penalty(T, Cf)
+    big = frx.Problem(base * rep, sc.ZHANGJIAJIE, qd_intervals=kappa)
+    cost, gdT, gdC = big.penalty(np.tile(np.concatenate(Ts), rep), np.tile(np.concatenate(Cs), rep))
+    for r in (0, rep // 2, rep - 1):
+        for b in picks:
+            gb = r * B0 + b
+            c_ref, gT_ref, gC_ref = refs[b]
+            sl = slice(big.piece_off[gb], big.piece_off[gb + 1])
+            assert abs(cost[gb] - c_ref) <= PER_EVAL_TOL * max(abs(c_ref), 1e-300), f"cost replica {r} cand {b}"
+            assert rel(gdT[sl], gT_ref) < PER_EVAL_TOL and rel(gdC[6 * sl.start:6 * sl.stop], gC_ref) < PER_EVAL_TOL, f"gradients replica {r} cand {b}"
+    assert any(refs[b][0] > 0.0 for b in picks)
+    big.close()
+
+
 def test_penalty_of_a_large_batch_reproduces_the_small_batch(frx, sc):
     """320 candidates = the 32 headline candidates ten times over (6827 wave-tasks, more than twice the chip's 3072 wave slots: the grid
     runs in several waves of workgroups): every replica must reproduce the 32-candidate batch, which the tests above check against the
