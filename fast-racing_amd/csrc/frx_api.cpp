@@ -834,7 +834,7 @@ int frx_debug_eval_fused(const frx_problem *p) { return (p && p->eval_fused) ? p
 // default), 2 = at every batch size.  frx_debug_eval_solo: workgroups of the kernel a CU holds when the NEXT evaluation of this handle takes the form, 0 = it does not.
 int frx_debug_set_eval_solo(frx_problem *p, int mode) {
     if (!p || mode < 0 || mode > 2) return fail(FRX_ERR_INVALID_ARG, "null argument or unknown mode");
-    if (mode && !p->geo.lds_solo) return fail(FRX_ERR_INVALID_ARG, "the solo form does not apply to this handle (more than 64 pieces or samples per piece, or the banded solver)");
+    if (mode == 2 && !p->geo.lds_solo) return fail(FRX_ERR_INVALID_ARG, "the solo form does not apply to this handle (more than 64 pieces or samples per piece, or the banded solver)");   // (1 = where it applies: always accepted)
     p->eval_solo = mode;
     return FRX_OK;
 }

@@ -139,18 +139,19 @@ __global__ __launch_bounds__(256, 2) void k_eval_solo(DevProblem dp, SoloArgs a,
         if (threadIdx.x == 0 && tap.arrive && atomicAdd(tap.arrive, 1u) + 1u == (unsigned)gridDim.x * tap.round) *tap.flag = tap.round;
         return;
     }
+// (cycle stamps of candidate 0, frx_profile_phases with the form forced: slots 7 / 13 / 14 / 15 = entry, forward map done, penalty phase done, end - the bodies' own stamps use 0-6, 8-12 and 16-31)
 #define SOLO_STAMP(slot) do { if (dp.stamps && b == 0 && threadIdx.x == 0) dp.stamps[slot] = (long long)__builtin_readcyclecounter(); } while (0)
     double2 hv[5];
     solo_prefetch_corridor(dp, a.Kmax, b, hv);
-    SOLO_STAMP(25);
+    SOLO_STAMP(7);
     forward_knot_body<false, 64>(dp, a.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, (a.dbg & 1) ? nullptr : a.pcrw, a.nsteps, b, sm);
     __syncthreads();                                                            // (C, T) and the multipliers of this candidate are out - this workgroup's own stores, read back below
-    SOLO_STAMP(26);
+    SOLO_STAMP(13);
     solo_penalty_phase<LPP>(dp, a.T, a.C, a.out20, a.lpp, a.ppg, a.Kmax, b, sm, hv);
     __syncthreads();
-    SOLO_STAMP(27);
+    SOLO_STAMP(14);
     backward_knot_body<false, 64>(dp, a.x, a.T, a.C, a.out20, a.f, a.g, a.maxCN, a.maxXb, a.maxVb, 64, a.pcrw, a.nsteps, tap, b, sm);
-    SOLO_STAMP(28);
+    SOLO_STAMP(15);
 #undef SOLO_STAMP
 }
 

@@ -20,7 +20,7 @@ for B in batches:
     for _ in range(5):
         st = np.zeros(32, np.int64)
         assert frx.lib().frx_profile_phases(prob.h, xb, st) == 0
-        rows.append([int(st[26] - st[25]), int(st[27] - st[26]), int(st[28] - st[27]), int(st[28] - st[25])])
+        rows.append([int(st[13] - st[7]), int(st[14] - st[13]), int(st[15] - st[14]), int(st[15] - st[7])])
     r = np.median(np.array(rows), axis=0)
     print(json.dumps({"candidates": B, "cycles_forward": r[0], "cycles_penalty": r[1], "cycles_adjoint": r[2], "cycles_total": r[3], "us_at_2.4GHz": round(r[3] / 2400, 2),
                       "forward_phases": np.diff(st[:7]).tolist(), "adjoint_phases": np.diff(st[16:25]).tolist()}), flush=True)
