@@ -434,6 +434,7 @@ def main():
     # stage bodies back to back (csrc/frx_solo_kernel.hpp; bit-identical results); timed here in both forms
     solo_wgs = prob.eval_solo()
     solo_us = min(prob.eval_launch_time(x_state, reps=max(args.steps, 100)) for _ in range(3)) if solo_wgs else None
+    one1_us = one_us if fused_G else solo_us                           # the ONE kernel of a timed step, where the step is one launch
     prob.set_eval_fused(False)
     prob.set_eval_solo(0)
     three_us = min(prob.eval_launch_time(x_state, reps=max(args.steps, 100)) for _ in range(3))
@@ -464,7 +465,7 @@ def main():
     fwd_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + (8 * steps + 4) * 8 * npc))
     adj_bytes = int(np.sum(8 * nx + 24 * nvert + 152 * npc + 160 * npc + (8 * steps + 4) * 8 * npc + 8 * nx + 8))
     stage_bytes = {"forward": fwd_bytes, "penalty": alg_bytes, "adjoint": adj_bytes}
-    pen_kernel = "frx::k_penalty" if os.environ.get("FRX_PENALTY_FORM", "l")[0] == "t" else "frx::k_penalty_lat"     # launch_penalty's choice (csrc/frx_device.hip)
+    pen_kernel = prob.penalty_kernel()                                 # launch_penalty's choice for this handle (csrc/frx_device.hip): k_penalty_lat, or k_penalty_lat2 from four-wave workgroups on
     # SURVEY.md 8d, "full objective evaluation": penalty bytes + x in and g out (16 n) + the waypoint polytopes (24 bytes per vertex) per candidate
     eval_bytes = int(alg_bytes + np.sum(16 * nx + 24 * nvert))
     # FP64 work of the penalty integrator (scripts/count_fp64.py: FP64 flops per sample counted in the emitted ISA, no corridor violation)
@@ -514,6 +515,7 @@ def main():
         for kname, key in (("k_forward_knot", "forward"), ("k_backward_knot", "adjoint")):
             e = pj["kernels"].get(kname, {}).get("grid_%d" % (256 * B))
             if e: knot_traffic[key] = e.get("traffic_bytes_per_launch_range")
+        one_traffic = (pj.get("k_eval_solo") or {}).get("grid_%d" % (256 * B), {}).get("traffic_bytes_per_launch_range")   # the timed form at this size: the solo launch
     # the same kernel on a large batch (the headline batch replicated: every replica owns its data in HBM), where the HBM
     # fraction is meaningful; reported next to the headline-size figure, which is launch-latency bound
     large = None
@@ -762,22 +764,23 @@ def main():
                        "state": "iterate after 60 L-BFGS iterations from the reference initial guess",
                        "parallelism": f"candidates sharded {B}/GPU, no data-path collective",
                        "front_end": ("frx_multi_* in one process" if lib_mode else "one process per GPU (torch.distributed)") if world > 1 else "one process, one device"},
-            "roofline": {**({"bound": "hbm", "kernel": "frx::k_eval_cluster", "selected_by": "the dominant (only) kernel of the timed region: one launch per evaluation",
-                             "achieved": eval_bytes / (one_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eval_bytes / (one_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {**({"bound": "hbm", "kernel": "frx::k_eval_cluster" if fused_G else "frx::k_eval_solo", "selected_by": "the dominant (only) kernel of the timed region: one launch per evaluation",
+                             "achieved": eval_bytes / (one1_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eval_bytes / (one1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": eval_bytes, "algorithmic_bytes_definition": "SURVEY.md 8d, full objective evaluation fused on device: penalty bytes (sum over pieces of 312 + 48 K_i) + 16 n + 24 sum(nv) per candidate",
-                             "avg_kernel_us": one_us, "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_launch_time)",
+                             "avg_kernel_us": one1_us, "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_launch_time)",
                              "traffic": (0.5 * (one_traffic[0] + one_traffic[1]) if one_traffic else None), "traffic_range": one_traffic, "traffic_from_profile": one_traffic is not None, "traffic_source": traffic_src if one_traffic else None,
-                             "traffic_note": "FETCH_SIZE / WRITE_SIZE of k_eval_cluster, bracketed by the 8-byte and the 16-byte calibration of the same call (its loads are a mix); includes the granules that carry (C, T) and the partials between the workgroups (2 x 16 bytes per value)",
+                             "traffic_note": "FETCH_SIZE / WRITE_SIZE of the kernel, bracketed by the 8-byte and the 16-byte calibration of the same call (its loads are a mix); includes the granules that carry (C, T) and the partials between the workgroups (2 x 16 bytes per value)",
                              "counter_calibration_bytes_per_counted_byte": calib,
-                             "kernel_samples_per_s": samples_per_step / (one_us * 1e-6), "workgroups_per_candidate": fused_G,
-                             "bound_in_fact": "latency: per candidate one dependent chain - forward map (one wave per axis behind a matrix wave), penalty share of 24 member waves, adjoint - on 7 of 256 CUs; nothing of it streams",
+                             "kernel_samples_per_s": samples_per_step / (one1_us * 1e-6), "workgroups_per_candidate": fused_G if fused_G else 1,
+                             "bound_in_fact": ("latency: per candidate one dependent chain - forward map (one wave per axis behind a matrix wave), penalty share of 24 member waves, adjoint - on 7 of 256 CUs; nothing of it streams" if fused_G else
+                                               "latency: per candidate one dependent chain in ONE workgroup - forward map, five penalty passes on its four waves, adjoint - two workgroups per CU (DESIGN.md 3.8)"),
                              "penalty_integrator": {"what": "the penalty integrator alone, as a stage kernel (the kernel SURVEY.md 8d prices; it is what large batches and the optimiser's per-stage rounds launch)",
                                                     "kernel": pen_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,
                                                     "measured_by": "HIP events on the library's launch stream around back-to-back launches of this kernel, in this run (frx_eval_stage_times)",
                                                     "traffic": traffic, "traffic_from_profile": traffic is not None, "traffic_source": traffic_src,
                                                     "kernel_samples_per_s": samples_per_step / (pen_us * 1e-6), "sample_halfspace_pairs_per_s": pairs_per_step / (pen_us * 1e-6)}}
-                            if fused_G else
+                            if (fused_G or solo_wgs) else
                             {"bound": "hbm", "kernel": pen_kernel, "selected_by": "the kernel SURVEY.md 8d prices: the penalty integrator (CPU.hpp:188-408 = cuda_computer::compute)",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_definition": "sum over pieces of 312 + 48 K_i (SURVEY.md 8d)", "avg_kernel_us": pen_us,

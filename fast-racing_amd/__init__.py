@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
     "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
-    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_debug_set_eval_solo", "frx_debug_eval_solo", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
+    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_debug_set_eval_solo", "frx_debug_eval_solo", "frx_debug_penalty_kernel", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
 ]
 
 _lib = None
@@ -120,6 +120,7 @@ def lib():
         L.frx_debug_eval_fused.argtypes = [C.c_void_p]
         L.frx_debug_set_eval_solo.argtypes = [C.c_void_p, C.c_int]
         L.frx_debug_eval_solo.argtypes = [C.c_void_p]
+        L.frx_debug_penalty_kernel.argtypes = [C.c_void_p]
         L.frx_debug_profile_eval_cluster.argtypes = [C.c_void_p, _dp, C.c_void_p]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_multi_destroy.argtypes = [C.c_void_p]
@@ -614,6 +615,10 @@ class Problem:
     def eval_solo(self) -> int:
         """Workgroups of the solo kernel a CU holds if the next evaluation takes that form, 0 = it does not."""
         return int(lib().frx_debug_eval_solo(self.h))
+
+    def penalty_kernel(self) -> str:
+        """Name of the penalty kernel a stage launch of this handle takes."""
+        return {0: "frx::k_penalty", 1: "frx::k_penalty_lat", 2: "frx::k_penalty_lat2"}.get(int(lib().frx_debug_penalty_kernel(self.h)), "?")
 
     def algorithmic_bytes(self) -> int:
         """Penalty-kernel bytes per evaluation, SURVEY.md §8d: sum over pieces of 312 + 48 K_i."""

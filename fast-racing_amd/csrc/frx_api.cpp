@@ -838,6 +838,15 @@ int frx_debug_set_eval_solo(frx_problem *p, int mode) {
     p->eval_solo = mode;
     return FRX_OK;
 }
+// Diagnostic (bench): which penalty kernel a stage launch of this handle takes - 0 = k_penalty (FRX_PENALTY_FORM=thr), 1 = k_penalty_lat, 2 = k_penalty_lat2 (four-wave
+// workgroups, one sample per lane: the large-batch form; FRX_PENALTY_TWOPHASE=0 keeps the one-phase launch).  Mirrors launch_penalty (frx_device.hip).
+int frx_debug_penalty_kernel(const frx_problem *p) {
+    if (!p) return -1;
+    const char *f = std::getenv("FRX_PENALTY_FORM");
+    if (f && f[0] != 'l') return 0;
+    const char *tp = std::getenv("FRX_PENALTY_TWOPHASE");
+    return (p->geo.lds_pen2 && !(tp && tp[0] == '0')) ? 2 : 1;
+}
 int frx_debug_eval_solo(const frx_problem *p) {
     if (!p || !p->geo.lds_solo || p->geo.solver != frx::SOLVER_KNOT_PCR) return 0;
     if (!(p->eval_solo == 2 || (p->eval_solo == 1 && p->B >= p->eval_solo_min_B && p->B <= p->eval_solo_max_B))) return 0;

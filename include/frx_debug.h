@@ -62,6 +62,8 @@ int frx_debug_eval_fused(const frx_problem *p);
  * 2 = at every batch size, also where the cluster form would apply.  Results are bit-identical to the three stage launches (replaces the same objectiveFunc,
  * se3gcopter_cpu.hpp:961-1000).  frx_debug_eval_solo = workgroups of the kernel a CU holds if the next evaluation takes the form, 0 = it does not. */
 int frx_debug_set_eval_solo(frx_problem *p, int mode);
+/* which penalty kernel a stage launch of this handle takes: 0 = k_penalty, 1 = k_penalty_lat, 2 = k_penalty_lat2 (large batches: four-wave workgroups, two-phase transpose) */
+int frx_debug_penalty_kernel(const frx_problem *p);
 int frx_debug_eval_solo(const frx_problem *p);
 /* Diagnostic (bench): average microseconds of one evaluation at x in the form frx_objective_eval_device takes, over `reps` back-to-back evaluations. */
 int frx_eval_launch_time(frx_problem *p, const double *x, int reps, double *out_us);

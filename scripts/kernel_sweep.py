@@ -46,6 +46,7 @@ for B in [int(b) for b in args.batches.split(",")]:
             xd = torch.from_numpy(xb).cuda(); fd = torch.zeros(prob.B, dtype=torch.float64, device="cuda"); gd = torch.zeros(prob.NX, dtype=torch.float64, device="cuda")
             # both forms of an evaluation where the one-launch form applies (k_eval_cluster, batches the chip holds at once): the counter passes need the stage
             # kernels AND the cluster kernel at the headline batch
+            prob.set_eval_solo(0)                                   # (the stage kernels at every size: the counter passes need them; the solo launch separately below)
             for form in ((False, True) if prob.eval_fused() else (False,)):
                 prob.set_eval_fused(form)
                 for _ in range(5): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
@@ -54,5 +55,13 @@ for B in [int(b) for b in args.batches.split(",")]:
                 e1.record(); torch.cuda.synchronize()
                 row["eval_one_launch_us" if form else "eval_us"] = round(e0.elapsed_time(e1) * 1e3 / args.reps, 2)
             prob.set_eval_fused(True)
+            if prob.solo_applies():                                 # one workgroup per candidate, one launch (frx_solo_kernel.hpp)
+                prob.set_eval_solo(2)
+                for _ in range(5): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
+                e0.record()
+                for _ in range(args.reps): prob.objective_device(xd.data_ptr(), fd.data_ptr(), gd.data_ptr(), stream)
+                e1.record(); torch.cuda.synchronize()
+                row["eval_solo_us"] = round(e0.elapsed_time(e1) * 1e3 / args.reps, 2)
+            prob.set_eval_solo(1)
         rows.append(row); print(json.dumps(row), flush=True)
     if rep > 1: prob.close()

@@ -61,6 +61,23 @@ try:
     res["k_eval_cluster"] = m
 except Exception as e:
     res["k_eval_cluster"] = {"error": repr(e)}
+# the solo launch (k_eval_solo: one workgroup per candidate runs the three stage bodies): per batch size, bracketed like the knot kernels
+try:
+    per = collections.defaultdict(dict)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        g = collections.defaultdict(list)
+        for r in allrows(f"pmc6_{c}"):
+            if "k_eval_solo" in r["Kernel_Name"]: g[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+        for grid, v in g.items(): per[grid][c + "_KB_raw"] = sum(v) / len(v)
+    out = {}
+    for grid, m in sorted(per.items()):
+        fk, wk = m.get("FETCH_SIZE_KB_raw", 0.0) * 1024, m.get("WRITE_SIZE_KB_raw", 0.0) * 1024
+        e = dict(m)
+        e["traffic_bytes_per_launch_range"] = [fk * min(f8, f16) + wk * min(w8, w16), fk * max(f8, f16) + wk * max(w8, w16)]
+        out["grid_%d" % grid] = e
+    res["k_eval_solo"] = out
+except Exception as e:
+    res["k_eval_solo"] = {"error": repr(e)}
 pen = kern["k_penalty"]
 small = sorted(pen, key=lambda k: int(k.split("_")[1]))[0]
 res["traffic_bytes_per_launch"] = pen[small]["traffic_bytes_per_launch"]      # headline launch of the penalty integrator
