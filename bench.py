@@ -617,6 +617,8 @@ def main():
         b_, s_, t_ = _C.c_double(), _C.c_int(), _C.c_int()
         frx.lib().frx_debug_host_cpu_share(int(r["clusters"]) or B, (world - 1) if lib_mode else 0, _C.byref(b_), _C.byref(s_), _C.byref(t_))
         plan.update({"plan_host_cpus": b_.value, "plan_host_cpu_share_of_this_rank": s_.value, "plan_mailbox_threads": t_.value, "local_world_size": os.environ.get("LOCAL_WORLD_SIZE")})
+        try: plan["plan_mailbox_numa"] = prob.mailbox_numa()               # where the resident plan's mailbox pages live against the device's NUMA node (round 6: the "slow host" of round 5)
+        except Exception as e_: plan["plan_mailbox_numa"] = {"error": repr(e_)}
         if world > 1 and not lib_mode:
             plan["plan_ms_per_rank"] = [v[0] for v in r["per_rank"]]
             plan["plan_us_per_round_per_rank"] = [1e3 * v[0] / max(v[1], 1.0) for v in r["per_rank"]]

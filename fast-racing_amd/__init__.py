@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "frx_debug_trace", "frx_resident_profile", "frx_debug_direction_log", "frx_debug_direction_log_read", "frx_debug_set_resident_retry",
     "frx_debug_resident_counts", "frx_debug_resident_clusters", "frx_debug_resident_predictions", "frx_eval_stage_times", "frx_profile_phases", "frx_dv_selftest", "frx_jps_tables", "frx_debug_host_cpu_share", "frx_debug_taken_over", "frx_debug_compact_from_history",
-    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_debug_set_eval_solo", "frx_debug_eval_solo", "frx_debug_penalty_kernel", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
+    "frx_debug_set_eval_fused", "frx_debug_eval_fused", "frx_debug_set_eval_solo", "frx_debug_eval_solo", "frx_debug_penalty_kernel", "frx_debug_mailbox_numa", "frx_eval_launch_time", "frx_debug_profile_eval_cluster", "frx_debug_set_takeover_at", "frx_debug_shader_clock",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def lib():
         L.frx_debug_set_eval_solo.argtypes = [C.c_void_p, C.c_int]
         L.frx_debug_eval_solo.argtypes = [C.c_void_p]
         L.frx_debug_penalty_kernel.argtypes = [C.c_void_p]
+        L.frx_debug_mailbox_numa.argtypes = [C.c_void_p, C.c_void_p]
         L.frx_debug_profile_eval_cluster.argtypes = [C.c_void_p, _dp, C.c_void_p]
         L.frx_multi_create.argtypes = [C.POINTER(FrxConfig), C.c_int, C.c_void_p, C.c_int, _ip, _dp, _dp, _ip, _dp, _ip, _dp, C.POINTER(C.c_void_p)]
         L.frx_multi_destroy.argtypes = [C.c_void_p]
@@ -615,6 +616,12 @@ class Problem:
     def eval_solo(self) -> int:
         """Workgroups of the solo kernel a CU holds if the next evaluation takes that form, 0 = it does not."""
         return int(lib().frx_debug_eval_solo(self.h))
+
+    def mailbox_numa(self):
+        """{NUMA node of the resident plan's command / result mailbox pages, the device's node, the caller's CPU}; -1 = unknown."""
+        out = np.zeros(4, np.int32)
+        _check(lib().frx_debug_mailbox_numa(self.h, out.ctypes.data))
+        return {"cmd_node": int(out[0]), "res_node": int(out[1]), "device_node": int(out[2]), "caller_cpu": int(out[3])}
 
     def penalty_kernel(self) -> str:
         """Name of the penalty kernel a stage launch of this handle takes."""

@@ -22,6 +22,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <unistd.h>
+#include <sys/syscall.h>
 #include <vector>
 
 #include "../../include/frx.h"
@@ -1902,6 +1903,29 @@ int frx_debug_set_takeover_at(frx_problem *p, long rounds) {
     p->takeover_at = rounds > 0 ? rounds : 0;
     return FRX_OK;
 }
+// Diagnostic (bench, scripts/r06/mode_probe.py): where the resident plan's mailboxes live.  out4 = {NUMA node of the command mailbox's first page, of the result
+// mailbox's first page (move_pages query; -1: no resident plan yet or not available), NUMA node the device hangs on (sysfs; -1: unknown), CPU the caller runs on}.
+int frx_debug_mailbox_numa(const frx_problem *p, int *out4) {
+    if (!p || !out4) return fail(FRX_ERR_INVALID_ARG, "null argument");
+    auto node_of = [](const void *ptr) -> int {
+        if (!ptr) return -1;
+        void *page = (void *)((uintptr_t)ptr & ~(uintptr_t)4095);
+        int status = -1;
+        const long rc = syscall(SYS_move_pages, 0, 1UL, &page, (const int *)nullptr, &status, 0);
+        return rc == 0 ? status : -1;
+    };
+    out4[0] = node_of(p->h_rcmd.p); out4[1] = node_of(p->h_rres.p);
+    out4[2] = -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), p->device) == hipSuccess) {
+        for (char *c = bdf; *c; c++) *c = (char)std::tolower(*c);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+        if (FILE *f = std::fopen(path.c_str(), "r")) { int node = -1; if (std::fscanf(f, "%d", &node) == 1) out4[2] = node; std::fclose(f); }
+    }
+    out4[3] = sched_getcpu();
+    return FRX_OK;
+}
+
 int frx_debug_shader_clock(int device, double ms, double *mhz_min, double *mhz_mean, double *mhz_max) {
     if (ms <= 0.0 || ms > 100.0) return fail(FRX_ERR_INVALID_ARG, "frx_debug_shader_clock: 0 < ms <= 100");
     HIP_TRY(hipSetDevice(device));

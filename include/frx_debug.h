@@ -107,6 +107,8 @@ int frx_debug_compact_from_history(int m, int n, int hs, int bound, int newest, 
  * milliseconds): shader cycles per tick of the constant 100 MHz counter, as MHz - minimum, mean and maximum over the CUs' workgroups.  A round of the resident kernel
  * is a chain of dependent instructions: its time is cycles / this clock, which is what differs between the boxes of a pool running the same code object. */
 int frx_debug_shader_clock(int device, double ms, double *mhz_min, double *mhz_mean, double *mhz_max);
+/* where the resident plan's mailboxes live: out4 = {NUMA node of the command mailbox's page, of the result mailbox's page, the device's NUMA node, the caller's CPU}; -1 = unknown */
+int frx_debug_mailbox_numa(const frx_problem *p, int *out4);
 
 #ifdef __cplusplus
 }
