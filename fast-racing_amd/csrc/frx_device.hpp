@@ -82,7 +82,7 @@ int eval_cluster_raise_limit(size_t lds_bytes);                 // raises k_eval
 
 // One launch per evaluation for LARGE batches (frx_solo_kernel.hpp): one workgroup per candidate runs forward map, penalty integral and adjoint back to back.
 // Same stage buffers, same tap, same results (bit for bit) as launch_forward + launch_penalty + launch_backward.
-int eval_solo_geometry(LaunchGeom &g);                            // fills lds_solo; returns 1 when the form applies
+int eval_solo_geometry(LaunchGeom &g, int samples_per_piece);     // fills lds_solo; returns 1 when the form applies (<= 64 pieces, kappa + 1 <= 64 samples per piece, knot solver)
 int eval_solo_raise_limit(const LaunchGeom &g);
 int eval_solo_blocks_per_cu(const LaunchGeom &g);                 // workgroups of the kernel a CU holds (occupancy query of the runtime; 0 on error)
 int launch_eval_solo(const DevProblem &dp, const LaunchGeom &g, const double *x, double *T, double *C, double *out20, double *f, double *grad, void *stream,

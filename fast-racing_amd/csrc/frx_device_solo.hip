@@ -13,9 +13,10 @@ namespace frx {
 static const void *solo_fn(int lpp) { return lpp == 17 ? (const void *)k_eval_solo<17> : lpp == 49 ? (const void *)k_eval_solo<49> : (const void *)k_eval_solo<0>; }
 
 // fills g.lds_solo (0: this geometry keeps the stage kernels): candidates of <= 64 pieces on the knot solver, one quadrature sample per lane
-int eval_solo_geometry(LaunchGeom &g) {
+int eval_solo_geometry(LaunchGeom &g, int samples_per_piece) {
     g.lds_solo = 0;
-    if (g.solver != SOLVER_KNOT_PCR || g.knot_threads != 64 || g.lpp > 64 || g.lpp < 1) return 0;
+    // (one quadrature sample per lane: with kappa + 1 > 64 a lane of the stage kernel walks over several samples - k_penalty_lat's loop, not this kernel's passes)
+    if (g.solver != SOLVER_KNOT_PCR || g.knot_threads != 64 || samples_per_piece > 64 || g.lpp != samples_per_piece || g.lpp < 1) return 0;
     const size_t lds = std::max(std::max(g.lds_kfwd, g.lds_kbwd), sizeof(double) * solo_pen_lds(g.maxN, g.Kmax));
     if (lds > (size_t)160 * 1024) return 0;
     g.lds_solo = lds;

@@ -344,6 +344,10 @@ def test_capacity_and_argument_errors(frx, sc):
     (700, 5, 23, None),                    # history shorter than the look-ahead, many wrap-arounds
     (700, 7, 9, (4, 3, 8, 1)),             # one pair per reduction (the reference's sequential order)
     (37, 3, 8, None), (129, 6, 15, None), (1500, 9, 12, None), (2048, 4, 6, None),
+    # round 6: history rows as long as the vector (n + 2 rounded up to 16 doubles; a thread's last pair beyond the end comes from the row's zero tail) - the headline
+    # n = 641 (656 on a 768 shape), one past a shape (513 on 640: a single slab of pairs, half its threads clamped), 769 / 1153 (other (E, W) classes), 639 and 655 / 657
+    # (a full shape; the last and the first n of a 16-double step)
+    (641, 128, 140, None), (513, 20, 45, None), (769, 9, 20, None), (1153, 12, 30, None), (639, 8, 20, None), (655, 6, 14, None), (657, 6, 14, None),
 ])
 def test_device_two_loop_recursion_matches_host(frx, n, m, iters, geom):
     """k_lbfgs_pre (blocked two-loop recursion, history in HBM) vs a host two-loop recursion on the same random history."""

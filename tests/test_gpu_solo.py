@@ -104,9 +104,12 @@ def test_per_stage_rounds_on_the_solo_launch_give_the_same_plan(frx, sc):
 
 
 @pytest.mark.gpu
-def test_solo_does_not_apply_beyond_64_pieces(frx, sc):
-    prob = frx.Problem([sc.make_candidate(80, 100, 25)], sc.ZHANGJIAJIE, qd_intervals=8)
-    assert prob.eval_solo() == 0
+@pytest.mark.parametrize("N,gates,kappa", [(100, 25, 8), (12, 3, 70)])
+def test_solo_does_not_apply_beyond_64_pieces_or_samples_per_piece(frx, sc, N, gates, kappa):
+    """More than 64 pieces (the knot bodies' other geometry classes) or more than 64 quadrature samples per piece (a lane of the stage kernel then walks over several
+    samples - found by running the whole GPU suite with FRX_EVAL_SOLO=1: kappa = 70 took the form and integrated 64 of its 71 samples): the handle keeps the stage kernels."""
+    prob = frx.Problem([sc.make_candidate(80, N, gates)], sc.ZHANGJIAJIE, qd_intervals=kappa)
+    assert prob.eval_solo() == 0 and not prob.solo_applies()
     with pytest.raises(frx.FrxError):
         prob.set_eval_solo(2)
     prob.close()
