@@ -12,7 +12,7 @@
 // still travel, a store does not leave its line behind in the L2 for the load that follows; keeping them in LDS does not fit two workgroups on a CU)
 //
 // Penalty phase: the candidate's coefficients, steps and corridor blocks are staged ONCE (one memory trip for all its pieces), then ceil(N / ppg) passes of
-// ppg = floor(256 / (kappa + 1)) pieces each - lane = one quadrature sample, the two-phase LDS transpose and the fixed-order sums of k_penalty_lat2: the
+// ppg = floor(256 / (kappa + 1)) pieces each - lane = one quadrature sample, one LDS transpose and the fixed-order sums of the stage kernels (penalty_reduce): the
 // partials are BIT-IDENTICAL to the stage kernel's, and so are f and the gradient (same bodies on the same inputs).
 // LDS: max(forward map, adjoint, penalty phase) - the phases overlay each other; nothing is kept in LDS across a phase boundary in this first form.
 #pragma once
@@ -27,8 +27,8 @@ struct SoloArgs {
     int dbg;                                 // measurements only (FRX_SOLO_DEBUG): bit 0 = the forward map does not save its multipliers (the adjoint reads those of an earlier evaluation at the same point)
 };
 
-// doubles of dynamic LDS the penalty phase needs: cS[maxN*18] | tS[maxN] | hS[maxN*(Kmax+1)*4] | red[256*11]
-__host__ __device__ inline size_t solo_pen_lds(int maxN, int Kmax) { return (size_t)maxN * 19 + (size_t)maxN * (Kmax + 1) * 4 + (size_t)256 * 11; }
+// doubles of dynamic LDS the penalty phase needs: cS[maxN*18] | tS[maxN] | hS[maxN*(Kmax+1)*4] | red[256*21]
+__host__ __device__ inline size_t solo_pen_lds(int maxN, int Kmax) { return (size_t)maxN * 19 + (size_t)maxN * (Kmax + 1) * 4 + (size_t)256 * 21 + 2; }
 
 template <int LPP>
 __device__ __forceinline__ void solo_penalty_phase(const DevProblem &dp, const double *T, const double *C, double *out20, int lpp_rt, int ppg, int Kmax, int b, double *sm, const double2 (&hv)[5]) {
@@ -55,69 +55,30 @@ __device__ __forceinline__ void solo_penalty_phase(const DevProblem &dp, const d
         for (int i = lane + 5 * nthr; i < nh2; i += nthr) { const double2 v = h2[i]; hS[2 * i] = v.x; hS[2 * i + 1] = v.y; }      // (corridor blocks of more than 8 half-spaces)
     }
     const int pl = lane / lpp, jl = lane - pl * lpp;
-    double *mine = red + lane * 11;
+    // ONE-phase transpose here (the stage kernel's two halves exist to fit four workgroups of 29 KB on a CU; this workgroup owns 77 KB for the forward map and the
+    // adjoint anyway): all 20 partials of a lane in one [256][21] square, two barriers per pass instead of four; penalty_reduce is the stage kernels' own fixed-order sum.
+    double *mine = red + lane * 21;
 #pragma unroll 1
     for (int q0 = 0; q0 < N; q0 += ppg) {
         const int npieces = min(ppg, N - q0);
         const bool exists = pl < npieces;
         const int pfl = (dp.piece_active && exists) ? dp.piece_active[p0 + q0 + pl] : DV_EVAL;
         const bool active = exists && (pfl & DV_EVAL);
-        __syncthreads();                                                        // staging done (first pass) / the previous pass's second half has been summed
-        double o[20];
+        __syncthreads();                                                        // staging done (first pass) / the previous pass's partials have been summed
         if (active) {
+            double o[20];
             LdsView c(cS + (q0 + pl) * 18), hb(hS + (size_t)(q0 + pl) * hstride);
             const int K = (int)hb[3], kappa = dp.kappa;
             const double step = tS[q0 + pl];
             penalty_sample_partials<true>(dp, c, hb, K, Kmax, step * jl, step, (jl == 0 || jl == kappa) ? 0.5 : 1.0, dp.inv_kappa, jl, o);
+#pragma unroll
+            for (int i = 0; i < 20; i++) mine[i] = o[i];
+        } else if (exists) {                                                    // a piece that is switched off this round: its partials are zeros
+#pragma unroll
+            for (int i = 0; i < 20; i++) mine[i] = 0.0;
         }
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            if (half) __syncthreads();
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 10; i++) mine[i] = o[10 * half + i];
-            } else if (exists) {
-#pragma unroll
-                for (int i = 0; i < 10; i++) mine[i] = 0.0;
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int idx = lane; idx < npieces * 10; idx += nthr) {
-                const int p2 = idx / 10, v = idx - p2 * 10;
-                const double *src = red + (p2 * lpp) * 11 + v;
-                double s = 0.0;
-                if (LPP) {
-                    constexpr int BLK = LPP <= 24 ? (LPP ? LPP : 1) : 16;
-                    int l = 0;
-#pragma unroll
-                    for (; l + BLK <= (LPP ? LPP : 1); l += BLK) {
-                        double bb[BLK];
-#pragma unroll
-                        for (int j = 0; j < BLK; j++) bb[j] = src[(l + j) * 11];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < BLK; j++) s += bb[j];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (; l < LPP; l++) s += src[l * 11];
-                } else {
-                    int l = 0;
-                    for (; l + 16 <= lpp; l += 16) {
-                        double bb[16];
-#pragma unroll
-                        for (int j = 0; j < 16; j++) bb[j] = src[(l + j) * 11];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < 16; j++) s += bb[j];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll 4
-                    for (; l < lpp; l++) s += src[l * 11];
-                }
-                out20[(size_t)(p0 + q0 + p2) * 20 + 10 * half + v] = s;
-            }
-        }
+        __syncthreads();
+        penalty_reduce<false>(red, npieces, lpp, out20 + (size_t)(p0 + q0) * 20, lane, nthr, true);
     }
 }
 
