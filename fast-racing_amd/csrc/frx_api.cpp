@@ -499,7 +499,7 @@ int frx_problem_create(const frx_config *cfg, int device, int B, const int *coar
         // (the solo form: from the batch size on at which the stage launches' ramps and stage-buffer trips outweigh a lone workgroup's five penalty passes - measured,
         // profiles/NOTES.md round 6; FRX_EVAL_SOLO=0 never, =1 always, FRX_EVAL_SOLO_MIN_B=n moves the threshold)
         frx::eval_solo_geometry(ge, spp);
-        p->eval_solo = ge.lds_solo ? 1 : 0; p->eval_solo_min_B = 432; p->eval_solo_max_B = 512;
+        p->eval_solo = ge.lds_solo ? 1 : 0; p->eval_solo_min_B = 384; p->eval_solo_max_B = 512;
         if (const char *es = std::getenv("FRX_EVAL_SOLO")) { if (es[0] == '0') p->eval_solo = 0; else if (es[0] == '1' && ge.lds_solo) p->eval_solo = 2; }
         if (const char *mb = std::getenv("FRX_EVAL_SOLO_MIN_B")) { const int v = std::atoi(mb); if (v > 0) p->eval_solo_min_B = v; }
         if (const char *mb = std::getenv("FRX_EVAL_SOLO_MAX_B")) { const int v = std::atoi(mb); if (v > 0) p->eval_solo_max_B = v; }
@@ -790,8 +790,8 @@ int frx_eval_stage_times(frx_problem *p, const double *x, int reps, double *out3
     std::vector<double> f(p->B), g(p->NX);
     int rc;
     {   // (the stage kernels, not the one-launch form: their buffers are what the timed launches below read)
-        struct Stage { frx_problem *q; int was; ~Stage() { q->eval_fused = was; } } stage{p, p->eval_fused};
-        p->eval_fused = 0;
+        struct Stage { frx_problem *q; int was, was_solo; ~Stage() { q->eval_fused = was; q->eval_solo = was_solo; } } stage{p, p->eval_fused, p->eval_solo};
+        p->eval_fused = 0; p->eval_solo = 0;                             // (neither one-launch form leaves (T, C), the multipliers and the waypoint sums in global memory)
         rc = frx_objective_eval(p, x, f.data(), g.data());               // d_x, d_T, d_C, d_out20, pcrw all valid afterwards
     }
     if (rc != FRX_OK) return rc;

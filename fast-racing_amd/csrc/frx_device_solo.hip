@@ -17,7 +17,8 @@ int eval_solo_geometry(LaunchGeom &g, int samples_per_piece) {
     g.lds_solo = 0;
     // (one quadrature sample per lane: with kappa + 1 > 64 a lane of the stage kernel walks over several samples - k_penalty_lat's loop, not this kernel's passes)
     if (g.solver != SOLVER_KNOT_PCR || g.knot_threads != 64 || samples_per_piece > 64 || g.lpp != samples_per_piece || g.lpp < 1) return 0;
-    const size_t lds = std::max(std::max(g.lds_kfwd, g.lds_kbwd), sizeof(double) * solo_pen_lds(g.maxN, g.Kmax));
+    if (g.maxXb + 16 > (int)SOLO_RB) return 0;                             // (the search direction of a round's tap is parked in the bodies' row buffer)
+    const size_t lds = sizeof(double) * (size_t)solo_lds(g.maxN, g.maxXb, g.maxVb, g.maxCN, g.pcr_steps, 256 / g.lpp, g.Kmax).total;
     if (lds > (size_t)160 * 1024) return 0;
     g.lds_solo = lds;
     return 1;
@@ -47,7 +48,7 @@ int launch_eval_solo(const DevProblem &dp, const LaunchGeom &g, const double *x,
     if (!g.lds_solo) return (int)hipErrorInvalidValue;
     SoloArgs a;
     a.x = x; a.T = T; a.C = C; a.out20 = out20; a.f = f; a.g = grad; a.pcrw = g.pcrw;
-    a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppg = 256 / g.lpp; a.Kmax = g.Kmax;
+    a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppg = 256 / g.lpp; a.Kmax = g.Kmax; a.maxN = g.maxN;
     { const char *e = std::getenv("FRX_SOLO_DEBUG"); a.dbg = e ? std::atoi(e) : 0; }
     const LineSearchTap tap{tap_d, tap_flags, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round};
     if (g.lpp == 17) hipLaunchKernelGGL(k_eval_solo<17>, dim3(dp.B), dim3(256), g.lds_solo, (hipStream_t)stream, dp, a, tap);

@@ -1270,8 +1270,12 @@ __device__ __forceinline__ void pcr_matrix_wave64(double *rowbuf, int kk, int N,
 // MODE (bits; 0 for the stage kernels): 1 = the caller hands in resident operands (`ro`, not null) that THIS call fills - x and the polytopes are staged into
 // ro->xs / ro->vs here, with the index-table loads of the body in the same memory latency (the leader of the one-launch evaluation, frx_eval_kernel.hpp, keeps
 // them for the adjoint of the same launch); 2 = with `go` not null (GranuleOut) the coefficients and durations leave as granules instead of plain stores (the
-// one-launch evaluation; measured inside the resident round kernel as well - slower there than its drained phase word, profiles/NOTES.md).  What a caller does not ask for is not compiled into it.
-template <bool SH, int NR = 0, int MODE = 0>
+// one-launch evaluation; measured inside the resident round kernel as well - slower there than its drained phase word, profiles/NOTES.md); 4 = no global (C, T) at all: they
+// stay in ct_lds (the solo launch, whose penalty phase and adjoint read that copy).  What a caller does not ask for is not compiled into it.
+// RB > 0 (with NR = 64 and a ct_lds copy only): the caller's scratch holds RB doubles of row buffer instead of 36 nrow - the wave-specialised path uses the (D^-1, L)
+// rows of two buffers ([0, 1280) doubles) and the progress words at 24 nrow = 1536; the coefficients are collected in ct_lds (the solo launch, frx_solo_kernel.hpp: LDS is
+// what keeps a second workgroup off its CU).
+template <bool SH, int NR = 0, int MODE = 0, int RB = 0>
 __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow_rt, double *__restrict__ pcrw, int nsteps, int b, double *sm, double *ct_lds = nullptr, bool wt = true, const ResidentOps *ro = nullptr,
                                const KnotPre *pre = nullptr, const GranuleOut *go = nullptr) {
@@ -1282,7 +1286,8 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     const int c0 = pre ? pre->c0 : dp.coff[b], cN = pre ? pre->cN : dp.coff[b + 1] - c0;
     const int x0 = pre ? pre->x0 : dp.xoff[b];
     double *rowbuf = sm;
-    double *KP = rowbuf + (size_t)36 * nrow;          // knot positions  [3][nthr+1]
+    static_assert(RB == 0 || (NR == 64 && RB >= 24 * 64 + 2), "a short row buffer: the <= 64-piece path only, progress words included");
+    double *KP = rowbuf + (RB > 0 ? (size_t)RB : (size_t)36 * nrow);          // knot positions  [3][nthr+1]
     double *KV = KP + 3 * (nrow + 1);
     double *KA = KV + 3 * (nrow + 1);
     double *Tf = KA + 3 * (nrow + 1);
@@ -1355,7 +1360,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         hMine = Tc[r_pc - c0] / r_piv;
         Tf[k] = hMine;
         if ((MODE & 2) && SH && go && go->ll) rk_ll_put(go->ll + 2 * ((size_t)(p0 + k) * 19 + 18), hMine, go->tag, go->mxw ? true : wt);   // (mxw: where the consumers run is not known yet - early, off the critical path: write-through)
-        else stg<SH>(Tout + p0 + k, hMine, wt);
+        else if (!(MODE & 4)) stg<SH>(Tout + p0 + k, hMine, wt);             // (MODE & 4: (C, T) stay in the caller's ct_lds copy and never go to global memory - the solo launch)
         if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
     FRX_STAMP(2);
@@ -1486,6 +1491,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         // scattered 8-byte write-through stores (lane stride 144 bytes), and draining them cost the resident kernel ~2 us per round.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const bool wt_ll = ((MODE & 2) && SH && go && go->ll && go->mxw) ? progress[1] == 0u : wt;   // (granules: see the decision of wave 3 above)
+        if (!(MODE & 4))
         for (int i = k; i < 9 * N; i += 256) {                              // 9 pairs of doubles per piece
             const int pc = i / 9, q2 = 2 * (i - 9 * pc);
             const double v0 = cstage[pc * 19 + q2], v1 = cstage[pc * 19 + q2 + 1];
@@ -1621,7 +1627,7 @@ FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_forward_knot64(DevPr
 // orders one straight-line body itself).  The resident form below - the partial-independent work hoisted in front of the poll by hand - measured 0.4 us
 // SLOWER as a stage kernel (8.00 against 7.62 us, build against build on one box, round 5), so each caller keeps the order that suits it; the arithmetic
 // is expression for expression the same.
-template <bool SH>
+template <bool SH, int RB = 0>
 __device__ __forceinline__ void backward_knot_wsp64_stage(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, const double *__restrict__ pcrw, int nsteps,
@@ -1633,7 +1639,7 @@ __device__ __forceinline__ void backward_knot_wsp64_stage(const DevProblem &dp, 
     const int c0 = dp.coff[b], cN = dp.coff[b + 1] - c0;
     const int x0 = dp.xoff[b];
     double *rowbuf = sm;
-    double *KP = rowbuf + (size_t)36 * nrow;          // d f / d q_k per axis (for the waypoint layer)
+    double *KP = rowbuf + (RB > 0 ? (size_t)RB : (size_t)36 * nrow);          // d f / d q_k per axis (for the waypoint layer); RB: see forward_knot_body
     double *KV = KP + 3 * (nrow + 1);                 // duration adjoint of piece k, one row per axis
     double *KA = KV + 3 * (nrow + 1);
     double *Tf = KA + 3 * (nrow + 1);
@@ -2430,7 +2436,7 @@ __device__ __forceinline__ void backward_knot_wsp64(const DevProblem &dp, const 
 }
 
 // SH: out20 (and T, C) were written by workgroups of the same launch.
-template <bool SH, int NR = 0>
+template <bool SH, int NR = 0, int RB = 0>
 __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const double *__restrict__ x, const double *__restrict__ Tin,
                                 const double *__restrict__ Cin, const double *__restrict__ out20, double *__restrict__ f,
                                 double *__restrict__ g, int maxCN, int maxXb, int maxVb, int nrow_rt, const double *__restrict__ pcrw, int nsteps,
@@ -2438,7 +2444,7 @@ __device__ __forceinline__ void backward_knot_body(const DevProblem &dp, const d
     const int nrow = NR > 0 ? NR : nrow_rt;
     if (NR == 64 || (NR == 0 && nrow == 64 && blockDim.x == 256)) {              // <= 64 pieces: one wave per axis
         if (SH) backward_knot_wsp64<SH>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);       // resident caller: the order built around the poll
-        else backward_knot_wsp64_stage<SH>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);
+        else backward_knot_wsp64_stage<SH, RB>(dp, x, Tin, Cin, out20, f, g, maxCN, maxXb, maxVb, pcrw, nsteps, tap, b, sm, ct_lds, ro);
         return;
     }
     if (NR == 64) return;
