@@ -49,7 +49,6 @@ int launch_eval_solo(const DevProblem &dp, const LaunchGeom &g, const double *x,
     SoloArgs a;
     a.x = x; a.T = T; a.C = C; a.out20 = out20; a.f = f; a.g = grad; a.pcrw = g.pcrw;
     a.maxCN = g.maxCN; a.maxXb = g.maxXb; a.maxVb = g.maxVb; a.nsteps = g.pcr_steps; a.lpp = g.lpp; a.ppg = 256 / g.lpp; a.Kmax = g.Kmax; a.maxN = g.maxN;
-    { const char *e = std::getenv("FRX_SOLO_DEBUG"); a.dbg = e ? std::atoi(e) : 0; }
     const LineSearchTap tap{tap_d, tap_flags, (DvResult *)tap_res, tap_arrive, tap_flag, tap_round};
     if (g.lpp == 17) hipLaunchKernelGGL(k_eval_solo<17>, dim3(dp.B), dim3(256), g.lds_solo, (hipStream_t)stream, dp, a, tap);
     else if (g.lpp == 49) hipLaunchKernelGGL(k_eval_solo<49>, dim3(dp.B), dim3(256), g.lds_solo, (hipStream_t)stream, dp, a, tap);

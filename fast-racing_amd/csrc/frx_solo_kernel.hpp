@@ -25,7 +25,6 @@ struct SoloArgs {
     const double *x; double *T, *C, *out20, *f, *g;
     double *pcrw;
     int maxCN, maxXb, maxVb, nsteps, lpp, ppg, Kmax, maxN;
-    int dbg;                                 // measurements only (FRX_SOLO_DEBUG), unused by this form
 };
 
 enum { SOLO_RB = 24 * 64 + 4 };              // row buffer of the bodies: (D^-1, L) rows of two buffers + the matrix wave's progress words (forward_knot_body<.., RB>)
