@@ -253,3 +253,19 @@ extern "C" int hostcheck_initial_guess(const frx_config *cfg, int B, const int *
     frx::initial_guess_batch(*cfg, softT, cand, x_off, x0);
     return x_off[B];
 }
+
+// ---- round 6: host-side rules of the device layouts (pure functions of the product's headers) ----
+#include "../../fast-racing_amd/csrc/frx_device.hpp"
+#include "../../fast-racing_amd/csrc/frx_solo_layout.hpp"
+// k_lbfgs_pre's geometry and the row stride of its history for vectors of at most n elements: out4 = {E, W, 64 W E, stride}
+extern "C" void hostcheck_dv_rows(int n, int tight, int *out4) {
+    int E = 0, W = 0, PF = 0;
+    frx::dv_geometry(n, &E, &W, &PF);
+    out4[0] = E; out4[1] = W; out4[2] = 64 * W * E; out4[3] = E ? (int)frx::dv_row_stride(n, E, W, tight != 0) : 0;
+}
+// LDS layout of the solo launch (doubles): out8 = {ctl, xs, pw, wq, vs, ev, total, doubles the penalty phase needs from vs on}
+extern "C" void hostcheck_solo_lds(int maxN, int maxXb, int maxVb, int maxCN, int nsteps, int ppg, int Kmax, int *out8) {
+    const frx::SoloLds L = frx::solo_lds(maxN, maxXb, maxVb, maxCN, nsteps, ppg, Kmax);
+    out8[0] = L.ctl; out8[1] = L.xs; out8[2] = L.pw; out8[3] = L.wq; out8[4] = L.vs; out8[5] = L.ev; out8[6] = L.total;
+    out8[7] = (ppg < maxN ? ppg : maxN) * (Kmax + 1) * 4 + 256 * frx::SOLO_QS + 2;
+}

@@ -83,3 +83,41 @@ def test_initial_guess_of_the_host_code_matches_the_oracle_whatever_the_thread_c
     for nt in (2, 5, 8):                                           # the same solves in the same arithmetic: bit-identical for every partition
         _, x_par = _host_guess(hc, frx, cands, P, 16, threads=nt)
         assert np.array_equal(x_par, x_ser)
+
+
+def test_history_row_stride_rule(hc):
+    """k_lbfgs_pre's history rows (round 6): as long as the vector needs - n + 2 rounded up to 16 doubles, so that the row's last pair lies in its zero tail - when that is
+    shorter than the workgroup's shape 64 W E, the shape has at least 512 doubles, and only a thread's LAST pair can fall beyond the end (the kernel clamps that one)."""
+    hc.hostcheck_dv_rows.argtypes = [C.c_int, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+    out = np.zeros(4, np.int32)
+    for n in list(range(2, 2100, 7)) + [511, 512, 513, 639, 640, 641, 655, 656, 657, 767, 768, 769, 1024, 1025]:
+        hc.hostcheck_dv_rows(n, 1, out)
+        E, W, shape, stride = (int(v) for v in out)
+        if E == 0: continue
+        assert shape == 64 * W * E >= n
+        assert stride <= shape and stride % 2 == 0 and stride >= min(shape, n + 2)
+        if stride < shape:
+            assert shape >= 512 and stride % 16 == 0 and stride - n < 18
+            assert stride // 2 > 64 * W * (E // 2 - 1)                      # every slab of pairs but the last lies inside the row
+        hc.hostcheck_dv_rows(n, 0, out)
+        assert int(out[3]) == shape
+    hc.hostcheck_dv_rows(641, 1, out)
+    assert list(out) == [6, 2, 768, 656]                                   # the headline vector
+    hc.hostcheck_dv_rows(639, 1, out)
+    assert int(out[2]) == 640 == int(out[3])                               # the Monte-Carlo scenarios: already tight
+
+
+def test_solo_launch_lds_layout(hc):
+    """The solo launch's LDS (frx_solo_layout.hpp): resident operands in front, the polytopes LAST before the bodies' scratch so that the penalty phase's corridor blocks and
+    transpose square can lie over both; 16-byte aligned regions; the headline / Monte-Carlo geometry fits two workgroups on a CU (80 KB each)."""
+    hc.hostcheck_solo_lds.argtypes = [C.c_int] * 7 + [np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+    out = np.zeros(8, np.int32)
+    for maxN, maxXb, maxVb, maxCN, nsteps, ppg, Kmax in [(64, 641, 2100, 16, 6, 15, 8), (64, 639, 2058, 16, 6, 15, 8), (64, 700, 2400, 16, 6, 5, 14), (12, 90, 300, 3, 4, 28, 8), (64, 641, 2100, 16, 6, 128, 8)]:
+        hc.hostcheck_solo_lds(maxN, maxXb, maxVb, maxCN, nsteps, ppg, Kmax, out)
+        ctl, xs, pw, wq, vs, ev, total, pen = (int(v) for v in out)
+        assert 0 == ctl < xs < pw < wq < vs < ev < total and all(v % 2 == 0 for v in (xs, pw, wq, vs, ev, total))
+        assert xs - ctl >= 19 * maxN and pw - xs >= maxXb and wq - pw >= (8 * nsteps + 5) * 64 and vs - wq >= 256 and ev - vs >= maxVb
+        assert total - ev >= (24 * 64 + 4) + 9 * 65 + 2 * 64 + maxCN + 10    # the adjoint's scratch: rows | knot arrays | Tf, gT | gCo | partials
+        assert total - vs >= pen                                               # the penalty phase's scratch lies over the polytopes and the bodies' scratch
+    hc.hostcheck_solo_lds(64, 639, 2058, 16, 6, 15, 8, out)
+    assert 8 * int(out[6]) <= 80 * 1024
