@@ -41,8 +41,8 @@ struct EvalClusterArgs {                      // constant for the life of a hand
     int G, maxCN, maxXb, maxVb, nsteps, lpp, ppw, Kmax, pen_lds, maxN19;
 };
 
-// LDS of a workgroup (doubles): 2 control | leader: (C, T) copy, x, polytopes, multipliers, waypoint sums, evaluation scratch | member: 4 waves x pen_lds
-struct EvalClusterLds { int ctl, xs, vs, pw, wq, ev, total; };
+// LDS of a workgroup (doubles): 2 control | (C, T) copy, x, polytopes, multipliers, waypoint sums, evaluation scratch (leader AND members: both run the forward map) | members: 4 waves x pen_lds
+struct EvalClusterLds { int ctl, xs, vs, pw, wq, ev, mem, total; };
 __host__ __device__ inline EvalClusterLds eval_cluster_lds(int maxN19, int maxXb, int maxVb, int maxCN, int nsteps, int pen_lds) {
     EvalClusterLds L;
     int o = 2;
@@ -54,8 +54,8 @@ __host__ __device__ inline EvalClusterLds eval_cluster_lds(int maxN19, int maxXb
     L.ev = o;
     const int e = 36 * 64 + 9 * 65 + 2 * 64 + maxCN + 16;   // rows | knot arrays | Tf, gT | gCo | cross-wave partials (forward_knot_body / backward_knot_wsp64 with resident operands)
     o += (e + 1) & ~1;
-    const int member = 2 + 4 * pen_lds + 8;
-    L.total = o > member ? o : member;
+    L.mem = o;                                                          // members (round 6: they run the forward map themselves, in the leader's layout): 4 waves x pen_lds behind it
+    L.total = o + 4 * pen_lds + 8;
     return L;
 }
 
@@ -102,20 +102,49 @@ __global__ __launch_bounds__(256, 1) void k_eval_cluster(typename std::condition
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc = call.force_wt ? 0u : (my_xcc & 7u) + 1u;                  // 0: "nowhere" - never equal to a partner's
     const EvalClusterLds L = eval_cluster_lds(a.maxN19, a.maxXb, a.maxVb, a.maxCN, a.nsteps, a.pen_lds);
-    if (wg != 0) {
-        // every WAVE of a member is on its own from here (no workgroup barrier below): its task's corridor blocks, the gate, its granules, its samples, its partials
-        if (t == 0) __hip_atomic_store(flag + 8 + (wg - 1), (tag << 4) | my_xcc, FRX_RLX_AGENT);
-        const int task = (wg - 1) * 4 + wave;
-        if (task >= ntasks) return;
-        penalty_wave_ll<true>(a.dp, a.ctll, flag, tag, a.out20ll, a.lpp, a.ppw, a.Kmax, p0 + task * a.ppw, min(a.ppw, N - task * a.ppw), sm + 2 + (size_t)wave * a.pen_lds, lane, a.status, call.timeout_ticks, my_xcc, (k == 0 && wg == 1 && wave == 0) ? a.dp.stamps : nullptr);
-        return;
-    }
-    // ---- leader ----
+    // Round 6: the MEMBERS run the forward map too - the same body on the same x, so their (C, T) are the leader's bit for bit - instead of waiting for the leader's
+    // coefficients: until now (C, T) travelled as granules behind a gate word (sweep 0.7 us, gate seen 0.15, granules polled and staged 0.7 us on the members' side) while
+    // the members' four waves had nothing to do for the first 8 us of the launch.  The leader sends nothing; its XCD goes into the gate word at ENTRY (the members look at
+    // it when their partials leave, microseconds later; not there yet counts as "elsewhere": write-through).
     double *ctl = sm + L.ctl, *ev = sm + L.ev;
     ResidentOps ro;
     ro.xs = sm + L.xs; ro.vs = sm + L.vs; ro.dsv = sm + L.xs; ro.pw = sm + L.pw; ro.gs = nullptr; ro.vskew = 0; ro.wq = sm + L.wq; ro.gpub = nullptr; ro.gwt = true;
-    const GranuleOut go{a.ctll, tag, flag, (tag << 4) | (my_xcc ? my_xcc : 15u), call.force_wt ? nullptr : flag + 8, (ntasks + 3) / 4};   // (C, T) leave as granules; nothing is drained, no flag follows them
-    forward_knot_body<true, 64, 3>(a.dp, call.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro, nullptr, &go);
+    ro.quiet = wg != 0;
+    const int task = (wg - 1) * 4 + wave;                                  // (members) this wave's task: ppw pieces
+    const bool has_task = wg != 0 && task < ntasks;
+    const int gp0 = p0 + task * a.ppw, npieces = has_task ? min(a.ppw, N - task * a.ppw) : 0;
+    const int hstride = (a.Kmax + 1) * 4;
+    double *wsm = sm + L.mem + (size_t)wave * a.pen_lds, *hS = wsm, *red = wsm + (size_t)a.ppw * hstride;
+    if (wg == 0) { if (t == 0) __hip_atomic_store(flag, (tag << 4) | (my_xcc ? my_xcc : 15u), FRX_RLX_AGENT); }
+    else if (has_task) {   // corridor blocks of the wave's task: constant, in flight under the forward map
+        if (k == 0 && wg == 1 && wave == 0 && lane == 0 && a.dp.stamps) a.dp.stamps[44] = (long long)wall_clock64();
+        const double2 *h2 = (const double2 *)(a.dp.hblk + (size_t)gp0 * hstride);
+        const int nh2 = (npieces * hstride) >> 1;
+        for (int i0 = lane; i0 < nh2; i0 += 4 * 64) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u; v[u] = h2[i < nh2 ? i : nh2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u; if (i < nh2) { hS[2 * i] = v[u].x; hS[2 * i + 1] = v[u].y; } }
+        }
+    }
+    forward_knot_body<false, 64, 5>(a.dp, call.x, a.T, a.C, a.maxCN, a.maxXb, a.maxVb, 64, nullptr, a.nsteps, c, ev, ctl, true, &ro);   // MODE 1 | 4: stages x and the polytopes itself, (C, T) into ctl only
+    if (wg != 0) {
+        // every WAVE of a member is on its own from here (no workgroup barrier below): its samples out of the workgroup's (C, T) copy, its partials as granules
+        if (!has_task) return;
+        long long *const mst = (k == 0 && wg == 1 && wave == 0 && lane == 0) ? a.dp.stamps : nullptr;
+        if (mst) mst[46] = (long long)wall_clock64();
+        const int pl = lane / a.lpp, jl = lane - pl * a.lpp;
+        if (pl < npieces) penalty_lane_samples<true>(a.dp, ctl + (size_t)(task * a.ppw + pl) * 19, hS + (size_t)pl * hstride, ctl[(task * a.ppw + pl) * 19 + 18], jl, a.lpp, a.Kmax, red + lane * 21);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (mst) mst[47] = (long long)wall_clock64();
+        const unsigned gv = __hip_atomic_load(flag, FRX_RLX_AGENT);           // the leader's XCD, if it has arrived under this evaluation's tag
+        const bool wt = my_xcc == 0u || (gv >> 4) != tag || (gv & 15u) != my_xcc;   // plain stores when the leader runs on this XCD (its L2 is the meeting point), write-through otherwise
+        penalty_reduce<true>(red, npieces, a.lpp, nullptr, lane, 64, wt, a.out20ll + (size_t)gp0 * 40, tag);
+        if (mst) mst[48] = (long long)wall_clock64();
+        return;
+    }
+    // ---- leader ----
     if (a.dp.stamps && k == 0 && t == 0) a.dp.stamps[41] = (long long)wall_clock64();
     ro.o20ll = a.out20ll; ro.o20tag = tag; ro.status = a.status; ro.spin_ticks = call.timeout_ticks;
     const LineSearchTap tap{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr};

@@ -93,7 +93,8 @@ __device__ __forceinline__ double rk_ll_value(ll_u64 w0, ll_u64 w1) { return __l
 // multiple of 4 - the lanes of a wave, one waypoint per lane pair, then hit 8 of the 32 LDS double-banks, a four-way conflict on
 // every read of the waypoint map and of its adjoint, measured 2.7 k cycles for a 12-vertex pass); one double of skew makes the stride odd.  nullptr (the one-launch-per-stage kernels): everything is staged per call, as before.
 struct ResidentOps { double *xs, *vs, *dsv, *pw, *gs = nullptr; int vskew = 0; double *wq = nullptr; double *gpub = nullptr; bool gwt = true;
-                     const ll_u64 *o20ll = nullptr; unsigned o20tag = 0; unsigned *status = nullptr; ll_u64 spin_ticks = 0; };   // gs (optional): the gradient goes to this LDS array INSTEAD of g; gpub (optional, global): and to this array, for the other workgroups of the cluster (write-through unless gwt is false)
+                     const ll_u64 *o20ll = nullptr; unsigned o20tag = 0; unsigned *status = nullptr; ll_u64 spin_ticks = 0;
+                     bool quiet = false; };      // quiet: no cycle stamps from this caller (the members of the one-launch evaluation run the forward map of candidate 0 too)   // gs (optional): the gradient goes to this LDS array INSTEAD of g; gpub (optional, global): and to this array, for the other workgroups of the cluster (write-through unless gwt is false)
 
 // What the forward map reads from the problem's index tables at its top, per candidate and per thread: offsets, this thread's piece (coarse index, interval
 // count), its pair's waypoint (vertex count, first vertex, first variable), the fixed end states of its axis.  Constant for the length of a plan: a RESIDENT
@@ -1297,7 +1298,9 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     double *pwf = vs + maxVb;                          // [nrow][nsteps*8+5] reduction multipliers (wave-specialised path)
     if (ro) { xs = ro->xs; vs = ro->vs; if (nrow == 64 && nthr == 256) pwf = ro->pw; }
 #define KN(arr, axis, idx) arr[(axis) * (nrow + 1) + (idx)]
-    FRX_STAMP(0);
+#define FWD_STAMP(slot) do { if (!(ro && ro->quiet)) FRX_STAMP(slot); } while (0)
+#define FWD_STAMP_AX(slot) do { if (!(ro && ro->quiet)) FRX_STAMP_AX(slot); } while (0)
+    FWD_STAMP(0);
     // Every global read of the kernel is issued here, before the first barrier, so the whole kernel pays ONE memory
     // latency (loads placed in later phases cannot be hoisted over the barriers by the compiler: measured +4 us).
     int r_pc = 0, r_piv = 1, r_wnv = 1, r_wvb = 0, r_wxb = 0;
@@ -1335,7 +1338,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     // the durations are produced and consumed by wave 0 alone - and a build without them is bit-identical; it is also no faster: the duration is ready after
     // 1.3 k cycles either way.  What that stretch WAS waiting for were the index-table loads, see KnotPre.)
     __syncthreads();
-    FRX_STAMP(1);
+    FWD_STAMP(1);
 
     // forwardT (CPU.hpp:626-676)
     if (dp.soft) {
@@ -1363,7 +1366,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         else if (!(MODE & 4)) stg<SH>(Tout + p0 + k, hMine, wt);             // (MODE & 4: (C, T) stay in the caller's ct_lds copy and never go to global memory - the solo launch)
         if (ct_lds) ct_lds[k * 19 + 18] = hMine;
     }
-    FRX_STAMP(2);
+    FWD_STAMP(2);
     if (wsp64) {
         // ---- <= 64 pieces: wave 0 = matrix wave (pcr_matrix_wave64), waves 1-3 = one axis each ----
         const int wave = __builtin_amdgcn_readfirstlane(k >> 6), kk = k & 63;
@@ -1374,7 +1377,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             const double hLs = lane_up1(hMine);
             const bool act0 = kk >= 1 && kk <= N - 1;
             pcr_matrix_wave64(rowbuf, kk, N, act0 ? hLs : 1.0, act0 ? hMine : 1.0, pwf, pws, ro ? nullptr : pcrw, (size_t)(nsteps * 8 + 4), (size_t)p0, nsteps, progress);
-            FRX_STAMP(5);
+            FWD_STAMP(5);
         } else {
             const int ax = wave - 1;
             // forwardP (CPU.hpp:729-747) on PAIRS of lanes of the axis waves: q = v0 + (2/(1+|xi|^2))^2 * sum_a V_a xi_a^2
@@ -1410,9 +1413,9 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 KN(KP, t2, 0) = r_bs[0]; KN(KV, t2, 0) = r_bs[1]; KN(KA, t2, 0) = r_bs[2];
                 KN(KP, t2, N) = r_bs[3]; KN(KV, t2, N) = r_bs[4]; KN(KA, t2, N) = r_bs[5];
             }
-            FRX_STAMP_AX(8);
+            FWD_STAMP_AX(8);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // meets the matrix wave's only barrier: knot positions and Tf are in LDS
-            FRX_STAMP_AX(9);
+            FWD_STAMP_AX(9);
             // right-hand side of knot kk for this axis (knot_row_rhs; the fixed end states move to the right-hand side)
             const bool act = kk >= 1 && kk <= N - 1;
             const int kc = act ? kk : 1;
@@ -1433,7 +1436,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                     }
                 }
             }
-            FRX_STAMP_AX(10);
+            FWD_STAMP_AX(10);
             if ((MODE & 2) && SH && go && go->ll && go->mxw && wave == 3) {
                 // Do all consumers of the granules run on this XCD?  They said so, or not yet, in go->mxw[0 .. nmx) (write-through stores at their entry, microseconds ago);
                 // this wave has the slack for the trip - its reduction below follows the matrix wave, which is two steps into its six by now.  "Not yet" counts as no.
@@ -1457,7 +1460,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
                 const double n1 = r1 - (ab[2] * l0 + ab[3] * l1) - (ab[6] * h0 + ab[7] * h1);
                 r0 = n0; r1 = n1;
             }
-            FRX_STAMP_AX(11);
+            FWD_STAMP_AX(11);
             // everything of the Hermite stage that does not need the solution is computed while the matrix wave finishes: durations and their
             // powers, the position part of the coefficients (hermite_coeffs with v = a = 0), the fixed end states
             const int kp = kk < N ? kk : 0;
@@ -1485,7 +1488,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
 #pragma unroll
                 for (int q = 0; q < 6; q++) cstage[kk * 19 + q * 3 + ax] = cq[q];
             }
-            FRX_STAMP_AX(12);
+            FWD_STAMP_AX(12);
         }
         // C leaves the workgroup as ONE coalesced sweep of 16-byte stores by all four waves.  Stored straight from the axis lanes it was 1152
         // scattered 8-byte write-through stores (lane stride 144 bytes), and draining them cost the resident kernel ~2 us per round.
@@ -1503,7 +1506,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
         // the gate of the granules' consumers: set BEHIND the sweep, not drained - it tells the members' waves that a poll of their granules is now worth its trip
         // (polled from the start of the launch, by 49 k lanes, the granules cost more than they save: every poll is a transaction on the fabric between the XCDs)
         if ((MODE & 2) && SH && go && go->ll && go->gate && k == 255) __hip_atomic_store(go->gate, go->gate_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        FRX_STAMP(6);
+        FWD_STAMP(6);
         return;
     }
     // forwardP (CPU.hpp:729-747): waypoint w (= knot w+1) is handled by a QUAD of lanes, each taking every 4th vertex;
@@ -1538,7 +1541,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
     }
     __syncthreads();
 
-    FRX_STAMP(3);
+    FWD_STAMP(3);
     // knot system rows + PCR
     KnotRow me;
     double vk[3] = {0, 0, 0}, ak[3] = {0, 0, 0};
@@ -1565,7 +1568,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             me.U[0] = me.U[1] = me.U[2] = me.U[3] = 0.0;
         }
     }
-    FRX_STAMP(4);
+    FWD_STAMP(4);
     if (nrow == 128 && nthr == 256) {                               // wave-specialised reduction with two knots per lane (<= 64 pieces: wsp64 above)
         if (k >= 1 && k <= N - 1) {
             double2 *mr = (double2 *)rowbuf;
@@ -1584,7 +1587,7 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             for (int ax = 0; ax < 3; ax++) { KN(KV, ax, k) = vk[ax]; KN(KA, ax, k) = ak[ax]; }
         }
     }
-    FRX_STAMP(5);
+    FWD_STAMP(5);
     __syncthreads();
     // piece coefficients (quintic Hermite), 18 contiguous doubles per piece
     if (k < N) {
@@ -1597,8 +1600,10 @@ __device__ __forceinline__ void forward_knot_body(const DevProblem &dp, const do
             for (int q = 0; q < 6; q++) { stg<SH>(co + q * 3 + ax, c[q], wt); if (ct_lds) ct_lds[k * 19 + q * 3 + ax] = c[q]; }
         }
     }
-    FRX_STAMP(6);
+    FWD_STAMP(6);
 }
+#undef FWD_STAMP
+#undef FWD_STAMP_AX
 FRX_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_forward_knot(DevProblem dp, const double *__restrict__ x, double *__restrict__ Tout, double *__restrict__ Cout,
                                int maxCN, int maxXb, int maxVb, int nrow, double *__restrict__ pcrw, int nsteps) {
     extern __shared__ double sm[];
